@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code in the authoring container.
+
+    cd /root/repo && python tests/golden/make_golden.py
+
+Needs /root/reference (read-only) and therefore never runs on the GPU box; the committed .npz
+files are what travel.  Nothing of the reference's source is stored: fixtures hold inputs,
+seeds and the numbers the reference computed.
+
+* ``train_model_official`` imports cleanly (numpy/torch only).
+* ``record_landmarks_official`` / ``live_infer_official`` import cv2 and mediapipe at module top;
+  neither is installed here, so empty placeholder modules are registered for the *import*
+  only.  The functions sampled (mouth_width_px, extract_feature, crop_roi*) are plain
+  NumPy/Python arithmetic; crop_roi*'s two cv2 calls receive ``frame[y1:y2, x1:x2]`` of a frame
+  whose pixels encode their own coordinates, which is how the integer crop box is read back
+  without OpenCV.  OpenCV's gray/resize arithmetic itself is NOT sampled (parity unpinned).
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import weights as W  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "inactive"))
+    import train_model_official as tmo
+
+    for name in ("cv2", "mediapipe", "mediapipe.tasks", "mediapipe.tasks.python", "mediapipe.tasks.python.vision"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["mediapipe"].tasks = sys.modules["mediapipe.tasks"]
+    sys.modules["mediapipe.tasks"].python = sys.modules["mediapipe.tasks.python"]
+    sys.modules["mediapipe.tasks.python"].vision = sys.modules["mediapipe.tasks.python.vision"]
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:  # recorder does os.makedirs("clips_npz") at import
+        os.chdir(tmp)
+        try:
+            import record_landmarks_official as rec
+            import live_infer_official as live
+            import train_reduced as tred
+        finally:
+            os.chdir(cwd)
+    return tmo, rec, live, tred
+
+
+# ------------------------------------------------------------------ model cases
+MODEL_CASES = [
+    # name, cls ('train'|'live'), x_dim, C, roi_hw, B, T, lengths, layers
+    ("model_lm_only", "train", 84, 5, None, 4, 12, [12, 7, 1, 12], 2),
+    ("model_roi64", "train", 84, 5, (64, 64), 3, 8, [8, 5, 2], 2),
+    ("model_shipped", "train", 180, 10, (48, 96), 2, 10, [10, 6], 2),
+    ("model_live_l1", "live", 84, 5, (64, 64), 2, 6, [6, 3], 1),
+    ("model_live_l2", "live", 84, 5, (64, 64), 2, 6, [4, 6], 2),
+]
+
+
+def gen_model_case(tmo, live, name, cls, x_dim, C, roi_hw, B, T, lengths, layers, seed):
+    use_roi = roi_hw is not None
+    sd = W.make_state_dict(seed, x_dim, C, use_roi, gru_layers=layers)
+    X, L, R, y = W.make_inputs(seed, B, T, x_dim, C, roi_hw, lengths)
+    if use_roi:
+        # exercise the std clamp (train_model_official.py:290): constant and near-constant frames
+        R[0, 0] = 0
+        if T > 1:
+            R[0, 1] = 200
+        if T > 2:
+            R[0, 2] = 17
+            R[0, 2, 3, 5] = 18
+    if cls == "train":
+        m = tmo.BiGRUClassifier(x_dim, C, use_roi=use_roi, roi_emb=32, hidden=192)
+    else:
+        m = live.BiGRUClassifier(x_dim, C, use_roi=use_roi, roi_emb=32, hidden=192, gru_layers=layers)
+    ref_sd = m.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), (list(ref_sd.keys()), list(sd.keys()))
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd)
+    m.eval()
+    out = dict(seed=seed, x_dim=x_dim, num_classes=C, use_roi=int(use_roi), layers=layers, cls=cls,
+               X=X.numpy(), lengths=L.numpy(), y=y.numpy(), sd_checksum=W.checksum(sd))
+    if use_roi:
+        out["R"] = R.numpy()
+    hooks = {}
+
+    def roi_hook(mod, i, o):
+        hooks.setdefault("roi_e", o.detach().clone())
+
+    def pool_hook(mod, i, o):
+        hooks.setdefault("gru_out", i[0].detach().clone())
+        hooks.setdefault("pooled", o.detach().clone())
+
+    if use_roi:
+        m.roi_cnn.register_forward_hook(roi_hook)
+    m.pool.register_forward_hook(pool_hook)
+    logits = m(X, L, R)
+    out["logits"] = logits.detach().numpy()
+    for k, v in hooks.items():
+        out[k] = v.numpy()
+    if cls == "train":
+        # eval-mode gradients (both dropouts off) + one clip/Adam step, train_model_official.py:433-439
+        loss_fn = torch.nn.CrossEntropyLoss(label_smoothing=0.05)
+        opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+        loss = loss_fn(logits, y)
+        opt.zero_grad()
+        loss.backward()
+        out["loss"] = float(loss)
+        for k, p in m.named_parameters():
+            out["grad::" + k] = W.reduce_tensor(p.grad)
+        tn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        out["total_norm"] = float(tn)
+        opt.step()
+        for k, p in m.named_parameters():
+            out["step1::" + k] = W.reduce_tensor(p.detach())
+        # second step on the same batch pins the Adam state recursion
+        logits2 = m(X, L, R)
+        loss2 = loss_fn(logits2, y)
+        opt.zero_grad()
+        loss2.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        out["loss2"] = float(loss2)
+        out["logits_after2"] = m(X, L, R).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "logits", out["logits"][0][:3])
+
+
+# ------------------------------------------------------------------ real-weights KAT
+def gen_kat(tred):
+    ck = torch.load(os.path.join(REF, "inactive", "word_model_5.pt"), map_location="cpu", weights_only=True)
+    sd = ck["model"] if "model" in ck else ck
+    in_dim = sd["gru.weight_ih_l0"].shape[1]
+    hid = sd["gru.weight_hh_l0"].shape[1]
+    C = sd["head.0.weight"].shape[0]
+    m = tred.GRUClassifier(in_dim, C, hidden=hid)
+    m.load_state_dict(sd)
+    m.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 20, in_dim, generator=g) * 0.5
+    out, _ = m.gru(x)
+    logits = m(x)
+    save = {"w::" + k: v.numpy() for k, v in sd.items()}
+    save.update(x=x.numpy(), gru_out=out.detach().numpy(), logits=logits.detach().numpy())
+    np.savez_compressed(os.path.join(HERE, "kat_word_model_5.npz"), **save)
+    print("wrote kat_word_model_5", in_dim, hid, C)
+
+
+# ------------------------------------------------------------------ features
+class _P:
+    __slots__ = ("x", "y")
+
+    def __init__(self, x, y):
+        self.x, self.y = float(x), float(y)
+
+
+def synth_faces(seed, T, w=640, h=480):
+    """(T,478,2) float32 normalised landmarks; anchors placed so the mouth width is 60-150 px."""
+    rng = np.random.default_rng(seed)
+    base = np.stack([rng.uniform(0.3, 0.7, 478), rng.uniform(0.4, 0.8, 478)], 1)
+    lm = base[None] + rng.normal(0, 0.004, (T, 478, 2))
+    lm[:, 61] = [0.42, 0.61] + rng.normal(0, 0.003, (T, 2))
+    lm[:, 291] = [0.58, 0.61] + rng.normal(0, 0.003, (T, 2))
+    lm[:, 13] = [0.50, 0.59] + rng.normal(0, 0.003, (T, 2))
+    lm[:, 14] = [0.50, 0.63] + rng.normal(0, 0.006, (T, 2))
+    return lm.astype(np.float32)
+
+
+def gen_features(rec, live):
+    w, h = 640, 480
+    T = 14
+    lm = synth_faces(11, T, w, h)
+    idx88 = list(rec.FIXED_IDXS)
+    lip40 = sorted(set(rec.MOUTH_LOWER + rec.MOUTH_UPPER))
+    out = dict(lm=lm, w=w, h=h, idx88=np.array(idx88), idx40=np.array(lip40))
+    reset = np.zeros(T, bool)
+    reset[0] = True
+    reset[6] = True
+    out["reset"] = reset
+    for tag, idxs in (("88", idx88), ("40", lip40)):
+        for vname, mod in (("record", rec), ("live", live)):
+            feats, cens, fourth, mws = [], [], [], []
+            prev = None
+            for t in range(T):
+                face = [_P(*lm[t, i]) for i in range(478)]
+                if reset[t]:
+                    prev = None
+                feat, prev, c, s = mod.extract_feature(face, w, h, idxs, prev)
+                feats.append(feat)
+                cens.append(np.asarray(c))
+                fourth.append(float(s))
+                mws.append(mod.mouth_width_px(face, w, h))
+            out[f"feat_{vname}_{tag}"] = np.stack(feats)
+            out[f"center_{vname}_{tag}"] = np.stack(cens)
+            out[f"fourth_{vname}_{tag}"] = np.array(fourth, np.float64)
+            out[f"mw_{vname}_{tag}"] = np.array(mws, np.float64)
+            assert feats[0].dtype == np.float32 and feats[0].shape == (2 * len(idxs) + 4,)
+    np.savez_compressed(os.path.join(HERE, "features.npz"), **out)
+    print("wrote features", out["feat_record_88"].shape)
+
+
+# ------------------------------------------------------------------ crop boxes
+def gen_crop(rec, live):
+    cv2 = sys.modules["cv2"]
+    seen = {}
+
+    def cvt(roi, code=None):
+        seen["x1"], seen["y1"] = int(roi[0, 0, 0]), int(roi[0, 0, 1])
+        seen["hh"], seen["ww"] = roi.shape[:2]
+        return roi
+
+    cv2.cvtColor = cvt
+    cv2.resize = lambda roi, size, interpolation=None: roi
+    cv2.COLOR_BGR2GRAY = 6
+    cv2.INTER_AREA = 3
+
+    rng = np.random.default_rng(3)
+    rows = []
+    sizes = [(640, 480), (1280, 720), (320, 240)]
+    for (w, h) in sizes:
+        yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        frame = np.stack([xx, yy, xx * 0], -1).astype(np.int32)
+        cases = []
+        for _ in range(400):
+            cases.append((rng.uniform(-40, w + 40), rng.uniform(-40, h + 40), rng.uniform(0.0, 160.0)))
+        # borders, exact-integer edges, degenerate boxes
+        for s in (0.0, 1e-6, 0.4, 0.5, 1.0, 60.000001, 100.0, 150.000001, 400.0, 2000.0):
+            for cx, cy in ((0, 0), (w, h), (w / 2, h / 2), (1.0, h - 1.0), (w - 0.5, 0.5), (-5, -5), (w + 5, h + 5)):
+                cases.append((cx, cy, s))
+        for cx, cy, s in cases:
+            c32 = np.array([cx, cy], np.float32)
+            scale = float(s)
+            for variant, fn in (("record", rec.crop_roi), ("live", live.crop_roi_gray)):
+                seen.clear()
+                r = fn(frame, c32, scale)
+                if r is None:
+                    rows.append((w, h, c32[0], c32[1], scale, 0 if variant == "record" else 1, 0, -1, -1, -1, -1))
+                else:
+                    rows.append((w, h, c32[0], c32[1], scale, 0 if variant == "record" else 1, 1,
+                                 seen["x1"], seen["x1"] + seen["ww"], seen["y1"], seen["y1"] + seen["hh"]))
+    rows = np.array(rows, np.float64)
+    np.savez_compressed(os.path.join(HERE, "crop.npz"),
+                        wh=rows[:, :2].astype(np.int32), center=rows[:, 2:4].astype(np.float32),
+                        scale=rows[:, 4], variant=rows[:, 5].astype(np.int32), valid=rows[:, 6].astype(np.int32),
+                        box=rows[:, 7:11].astype(np.int32))
+    print("wrote crop", rows.shape, "valid frac", rows[:, 6].mean())
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    tmo, rec, live, tred = import_reference()
+    for i, case in enumerate(MODEL_CASES):
+        gen_model_case(tmo, live, *case, seed=100 + i)
+    gen_kat(tred)
+    gen_features(rec, live)
+    gen_crop(rec, live)
+
+
+if __name__ == "__main__":
+    main()
