@@ -1,0 +1,172 @@
+/* ss_hotpath.h -- C ABI of the MI355X (gfx950) Silent-Speech per-clip hot path.
+ *
+ * The reference (davdwan21/Silent-Speech) has no FFI: its path sits behind a Python nn.Module
+ * (train_model_official.py:253-310), NumPy helpers (record_landmarks_official.py:52-118,
+ * live_infer_official.py:141-187) and torch's optimiser/loss objects
+ * (train_model_official.py:403-405, 433-439).  This header is the boundary a maintainer would
+ * bind with ctypes: plain device pointers and sizes, no torch types.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless a comment says otherwise; buffers are borrowed for
+ *    the duration of the call (asynchronously: until the work enqueued on `stream` has finished);
+ *  - no entry point allocates, frees or synchronises; workspaces are passed in, so every call is
+ *    capturable into a hipGraph;
+ *  - `stream` is a hipStream_t (0 = the default stream); calls are re-entrant per stream;
+ *  - return value: 0 (SS_OK) or a negative ss_status; the Python shim raises RuntimeError on != 0;
+ *  - all floating-point buffers are fp32 row-major unless stated; gate order everywhere is
+ *    torch's r | z | n.
+ */
+#ifndef SS_HOTPATH_H
+#define SS_HOTPATH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ss_stream_t; /* hipStream_t */
+
+enum ss_status {
+  SS_OK = 0,
+  SS_ERR_ARG = -1,         /* null pointer / non-positive size / inconsistent flags */
+  SS_ERR_LAUNCH = -2,      /* hipGetLastError() after the launch was not hipSuccess */
+  SS_ERR_UNSUPPORTED = -3  /* shape outside what the kernels are built for (e.g. hidden size) */
+};
+
+/* ABI version, bumped on any signature change. */
+int ss_abi_version(void);
+const char* ss_status_string(int status);
+
+/* ---- a1: per-frame landmark feature fuse -------------------------------------------------
+ * replaces extract_feature + mouth_width_px (record_landmarks_official.py:52-100;
+ * live_infer_official.py:141-169).
+ * lm      (B,T,K,2) MediaPipe-normalised x,y of the K selected landmarks
+ * reset   (B,T) uint8 or NULL: non-zero = the velocity state prev_xy is None at that frame
+ *         (t == 0 always resets)
+ * a_*     positions of landmarks 61, 291, 13, 14 inside the K-list
+ * variant 0 = recorder arithmetic (mouth width in float64), 1 = live (float32 points)
+ * X       (B,T, ldx>=2K+4): [x0,y0,...,vel,open_px,width_px,aspect]
+ * center  (B,T,2) float32 pixel centre; fourth (B,T) float64: width+1e-6 (recorder) or width (live) */
+int ss_feature_fuse(const float* lm, const uint8_t* reset, int B, int T, int K, int w, int h, int a_left,
+                    int a_right, int a_up, int a_lo, int variant, float* X, int ldx, float* center,
+                    double* fourth, ss_stream_t stream);
+
+/* ---- a2: ROI crop rectangle ---------------------------------------------------------------
+ * replaces the index arithmetic of crop_roi (record_landmarks_official.py:106-114, variant 0) and
+ * crop_roi_gray (live_infer_official.py:172-181, variant 1).  Bit-exact integers.
+ * box (n,5) int32: x1, x2, y1, y2, valid */
+int ss_roi_crop_idx(const float* center, const double* scale, int n, int w, int h, int variant, int32_t* box,
+                    ss_stream_t stream);
+
+/* ---- a4+a5(+a6): ROI normalise + TinyROICNN, fused ------------------------------------------
+ * replaces train_model_official.py:286-291 and TinyROICNN.forward (:212-229); with
+ * standardize = 0 the live variant (live_infer_official.py:126-127).
+ * R    (N,H,W) uint8 raw 0..255;  H, W multiples of 4 (two 2x2 pools)
+ * w1 (8,1,3,3) b1 (8) w2 (16,8,3,3) b2 (16) w3 (24,16,3,3) b3 (24) wfc (E,24) bfc (E), E <= 64
+ * out  row n written at out + n*ld_out, E floats (pass Z + x_dim with ld_out = x_dim+E to fuse
+ *      the torch.cat of train_model_official.py:297) */
+int ss_roi_cnn_fwd(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
+                   const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
+                   const float* bfc, int E, float* out, int ld_out, ss_stream_t stream);
+
+/* Same forward, additionally writing what the backward needs (the six st_* pointers are either
+ * all NULL -- then this is ss_roi_cnn_fwd -- or all valid):
+ * st_a1 (N,8,H/2,W/2) f32 and st_i1 u8: pooled conv1 map and its 2x2 argmax (0..3, row-major window);
+ * st_a2 (N,16,H/4,W/4) f32 and st_i2 u8: the same for conv2; st_m3 (N,24,H/4*W/4) u8: conv3 output > 0;
+ * st_feat (N,24): globally averaged conv3 features. */
+int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
+                         const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
+                         const float* bfc, int E, float* out, int ld_out, float* st_a1, uint8_t* st_i1,
+                         float* st_a2, uint8_t* st_i2, uint8_t* st_m3, float* st_feat, ss_stream_t stream);
+
+/* autograd of the above w.r.t. the eight parameter tensors (the uint8 input has no gradient),
+ * i.e. what loss.backward() (train_model_official.py:437) leaves in roi_cnn.*.grad.
+ * d_out row n read at d_out + n*ld_dout (E floats).  Gradients are ACCUMULATED (+=) into g_*.
+ * Needs the stash of ss_roi_cnn_fwd_stash for the same R and weights. */
+int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
+                   const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
+                   const float* bfc, int E, const float* st_a1, const uint8_t* st_i1, const float* st_a2,
+                   const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat, const float* d_out,
+                   int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
+                   float* g_wfc, float* g_bfc, ss_stream_t stream);
+
+/* ---- dense contraction used by a7/a9 and their gradients -----------------------------------
+ * C[M,N] (+)= opA[M,K] * opB[K,N] (+ bias[N]) (then ReLU), exact-f32 MFMA.
+ * a_kcontig = 1: A is stored [M][K] (lda = row stride); 0: stored [K][M].
+ * b_kcontig = 1: B is stored [N][K] (torch Linear weight layout); 0: stored [K][N].
+ * *_group/_gstride/_off remap the storage ROW index r of that operand to
+ *   (r / group) * gstride + (r % group) + off   (identity: group = INT32_MAX, off = 0);
+ *   used to pair dG[b][t] with h[b][t-1] without materialising a shifted copy.
+ * flags bit0: accumulate into C; bit1: ReLU epilogue.  splits > 1 slices K over blockIdx.z and
+ * adds with float atomics (requires bit0, C pre-initialised). */
+int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
+                int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
+                float* C, int ldc, const float* bias, int flags, int splits, ss_stream_t stream);
+
+/* column sums: out[n] += sum_r A[r*lda + n]  (bias gradients) */
+int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_stream_t stream);
+
+/* ---- a7: one bidirectional GRU layer, recurrence only ---------------------------------------
+ * replaces pack_padded_sequence -> nn.GRU -> pad_packed_sequence (train_model_official.py:301-305).
+ * gi      (2, B*T, 3H): W_ih x + b_ih per direction (forward, reverse), from ss_gemm_f32
+ * lengths (B) int32, 1 <= len <= T
+ * out     (B,T,2H): forward states in [0,H), reverse in [H,2H); zeros for t >= len
+ * save    (2, B*T, 4, H) or NULL: r, z, n, W_hn h + b_hn for the backward pass
+ * H in {64, 192} */
+int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
+               const float* b_hh_r, const int32_t* lengths, int B, int T, int H, float* out, float* save,
+               ss_stream_t stream);
+
+/* BPTT.  d_out (B,T,2H) gradient of the layer output; d_g (2, B*T, 4, H) receives
+ * d(gi_r), d(gi_z), d(gi_n) and d(W_hn h + b_hn) = d(gi_n) * r; rows with t >= len are zero. */
+int ss_gru_bwd(const float* d_out, const float* out, const float* save, const float* w_hh_f,
+               const float* w_hh_r, const int32_t* lengths, int B, int T, int H, float* d_g,
+               ss_stream_t stream);
+
+/* ---- a8: AttnPool (train_model_official.py:231-248) ------------------------------------------
+ * h (B,T,D), score weight (D) + bias (1); masked (-1e9) softmax over t, weighted sum.
+ * attn (B,T) softmax weights (saved for backward), pooled (B,D). */
+int ss_attn_pool_fwd(const float* h, const int32_t* lengths, const float* w_score, const float* b_score, int B,
+                     int T, int D, float* attn, float* pooled, ss_stream_t stream);
+/* d_h (B,T,D) is written (not accumulated); g_w (D), g_b (1) are accumulated. */
+int ss_attn_pool_bwd(const float* h, const int32_t* lengths, const float* w_score, const float* attn,
+                     const float* d_pooled, int B, int T, int D, float* d_h, float* g_w, float* g_b,
+                     ss_stream_t stream);
+
+/* ---- a9: head = LayerNorm -> Linear -> ReLU -> Dropout -> Linear (train_model_official.py:271-277)
+ * The two Linear layers go through ss_gemm_f32; these are the LayerNorm halves.
+ * xhat (B,D) normalised rows and rstd (B) are saved for the backward. */
+int ss_layernorm_fwd(const float* x, const float* gamma, const float* beta, int B, int D, float eps, float* y,
+                     float* xhat, float* rstd, ss_stream_t stream);
+int ss_layernorm_bwd(const float* d_y, const float* xhat, const float* rstd, const float* gamma, int B, int D,
+                     float* d_x, float* g_gamma, float* g_beta, ss_stream_t stream);
+/* y = x * mask(philox(seed, offset)) / (1-p), or the same mask applied to a gradient; p = 0 is a no-op.
+ * relu_of (may be NULL): additionally zero where relu_of <= 0 (ReLU backward fused). */
+int ss_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint64_t offset, const float* relu_of,
+               ss_stream_t stream);
+
+/* ---- a10: loss, clip, Adam -------------------------------------------------------------------
+ * CrossEntropyLoss(label_smoothing) mean-reduced over `denom` clips (the GLOBAL batch under data
+ * parallelism), forward and d(loss)/d(logits) in one pass (train_model_official.py:405, 434-437).
+ * loss_sum (1) is accumulated: sum over this call's clips of the per-clip loss / denom.
+ * correct (1) int32 accumulated: argmax == y count (train_model_official.py:442). */
+int ss_ce_ls_fwd_bwd(const float* logits, const int64_t* y, int B, int C, float label_smoothing, float denom,
+                     float* d_logits, float* loss_sum, int32_t* correct, ss_stream_t stream);
+
+/* sumsq (1) += sum x^2 over the flat gradient bucket (clip_grad_norm_'s global L2 norm). */
+int ss_sumsq_f32(const float* x, long n, float* sumsq, ss_stream_t stream);
+
+/* clip_grad_norm_(max_norm) folded into Adam (torch defaults, no weight decay, no amsgrad)
+ * (train_model_official.py:403, 438-439): g' = g * grad_scale * min(1, max_norm / (sqrt(sumsq)*grad_scale + 1e-6)).
+ * grad_scale = 1/world after a summing all-reduce.  step >= 1.  p, m, v updated in place. */
+int ss_adam_clip(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float grad_scale,
+                 float max_norm, float lr, float beta1, float beta2, float eps, int step, ss_stream_t stream);
+
+/* strided row copy dst[r*ld_dst + c] = src[r*ld_src + c], c < cols (places X into Z, train_model_official.py:297) */
+int ss_copy_rows_f32(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, ss_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SS_HOTPATH_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of ``libss_hotpath.so`` (C ABI declared in ``include/ss_hotpath.h``).
+
+There is no fallback: if the shared library has not been built (``python -m silent_speech_amd.build``
+or ``__graft_entry__.build()``), every product entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libss_hotpath.so")
+
+_vp = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_l = C.c_long
+_u64 = C.c_uint64
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+SIGNATURES = {
+    "ss_abi_version": [],
+    "ss_status_string": [_i],
+    "ss_feature_fuse": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "ss_roi_crop_idx": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "ss_roi_cnn_fwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i, _vp],
+    "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_vp],
+    "ss_roi_cnn_bwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_vp, _i] + [_vp] * 8 + [_vp],
+    "ss_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp],
+    "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
+    "ss_gru_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "ss_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "ss_attn_pool_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "ss_attn_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "ss_layernorm_fwd": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "ss_layernorm_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "ss_dropout": [_vp, _vp, _l, _f, _u64, _u64, _vp, _vp],
+    "ss_ce_ls_fwd_bwd": [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
+    "ss_sumsq_f32": [_vp, _l, _vp, _vp],
+    "ss_adam_clip": [_vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _f, _f, _i, _vp],
+    "ss_copy_rows_f32": [_vp, _i, _vp, _i, _i, _i, _vp],
+}
+_RESTYPES = {"ss_status_string": C.c_char_p}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"silent_speech_amd: {LIB_PATH} is missing. Build the HIP extension first "
+            "(python -m silent_speech_amd.build). There is no CPU/PyTorch fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library disagree
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    lib = load()
+    st = getattr(lib, name)(*args)
+    if st != 0:
+        msg = lib.ss_status_string(st).decode()
+        raise RuntimeError(f"{name} failed: {msg} ({st})")

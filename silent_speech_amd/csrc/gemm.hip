@@ -1,0 +1,203 @@
+// f32 MFMA GEMM for the dense contractions of the path: GRU input projections, their data/weight
+// gradients, and the classifier head.  C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N]) (ReLU).
+//
+// Replaces the aten::linear / addmm calls inside nn.GRU and nn.Linear
+// (/root/reference/train_model_official.py:261-267, 271-277) and their autograd.
+//
+// 128x64x16 block tile, 256 threads = 4 waves as 2(M) x 2(N), wave tile 64x32 = 4x2 tiles of
+// v_mfma_f32_16x16x4_f32 (exact f32).  Operands are staged global -> registers -> LDS; an operand
+// whose K index is contiguous in memory is kept [row][k] and read back with one ds_read_b128 per
+// four k-steps, an operand whose M/N index is contiguous is kept [k][row] and read with ds_read_b32.
+// Inside a 16-wide k tile the MFMA slot (kk, g) carries k = 4g + kk for BOTH operands, which is
+// what lets the [row][k] form use a single 16-byte read.
+#include "ss_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 64, BK = 16;
+constexpr int LDK = BK + 4;    // [row][k] image, row stride 20 floats (80 B, 16-B aligned)
+constexpr int LDM_A = BM + 4;  // [k][row] image strides: == 4 (mod 8) so k rows 4 apart land 16 banks apart
+constexpr int LDM_B = BN + 4;
+
+struct RowMap {
+  int G, S, off;
+  __device__ __forceinline__ long operator()(int r) const { return (long)(r / G) * S + (r % G) + off; }
+};
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K;
+  int lda, ldb, ldc;
+  RowMap ra, rb;
+  int ksplit;  // K elements per blockIdx.z slice (multiple of BK)
+  int flags;   // bit0: accumulate into C (plain RMW when gridDim.z==1, atomics otherwise); bit1: ReLU
+};
+
+// stage one operand tile into LDS.  ROWS = BM or BN.
+// KCONTIG: memory is [row][k] (row-major over the GEMM's M or N index) -> LDS image [row][LDK]
+// else   : memory is [k][row]                                          -> LDS image [k][ROWS+4]
+template <int ROWS, bool KCONTIG>
+__device__ __forceinline__ void stage(float* __restrict__ lds, const float* __restrict__ P, int ld, const RowMap& rm,
+                                      int row0, int nrows, int k0, int kend, bool vec_ok) {
+  const int tid = threadIdx.x;
+  if (KCONTIG) {
+    // ROWS*16 floats = ROWS*4 float4; thread -> (row = q/4, kq = q%4)
+#pragma unroll
+    for (int it = 0; it < ROWS * 4 / 256; ++it) {
+      int q = tid + it * 256;
+      int r = q >> 2, kq = q & 3;
+      int gr = row0 + r, gk = k0 + 4 * kq;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gr < nrows) {
+        const float* src = P + rm(gr) * ld + gk;
+        if (vec_ok && gk + 3 < kend) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gk + e < kend) v[e] = src[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&lds[r * LDK + 4 * kq]) = v;
+    }
+  } else {
+    constexpr int LD = ROWS + 4;
+    // 16 k-rows x ROWS floats; thread -> (k = q / (ROWS/4), rq = q % (ROWS/4))
+#pragma unroll
+    for (int it = 0; it < ROWS * 4 / 256; ++it) {
+      int q = tid + it * 256;
+      int k = q / (ROWS / 4), rq = q % (ROWS / 4);
+      int gk = k0 + k, gr = row0 + 4 * rq;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gk < kend) {
+        const float* src = P + rm(gk) * ld + gr;
+        if (vec_ok && gr + 3 < nrows) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gr + e < nrows) v[e] = src[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&lds[k * LD + 4 * rq]) = v;
+    }
+  }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[(A_KCONTIG ? BM * LDK : BK * LDM_A) + (B_KCONTIG ? BN * LDK : BK * LDM_B)];
+  float* As = lds;
+  float* Bs = lds + (A_KCONTIG ? BM * LDK : BK * LDM_A);
+
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * p.ksplit;
+  const int kend = min(p.K, kbeg + p.ksplit);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int i = lane & 15, g = lane >> 4;
+
+  const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+  const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    stage<BM, A_KCONTIG>(As, p.A, p.lda, p.ra, m0, p.M, k0, kend, a_vec);
+    stage<BN, B_KCONTIG>(Bs, p.B, p.ldb, p.rb, n0, p.N, k0, kend, b_vec);
+    __syncthreads();
+
+    float a[4][4], b[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      int r = wm * 64 + mt * 16 + i;
+      if (A_KCONTIG) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&As[r * LDK + 4 * g]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[mt][kk] = v[kk];
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[mt][kk] = As[(4 * g + kk) * LDM_A + r];
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      int c = wn * 32 + nt * 16 + i;
+      if (B_KCONTIG) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[c * LDK + 4 * g]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b[nt][kk] = v[kk];
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b[nt][kk] = Bs[(4 * g + kk) * LDM_B + c];
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(a[mt][kk], b[nt][kk], acc[mt][nt]);
+    __syncthreads();
+  }
+
+  const bool accumulate = p.flags & 1, relu = p.flags & 2;
+  const bool atomic = gridDim.z > 1;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      int col = n0 + wn * 32 + nt * 16 + i;
+      if (col >= p.N) continue;
+      float bv = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = m0 + wm * 64 + mt * 16 + 4 * g + r;
+        if (row >= p.M) continue;
+        float v = acc[mt][nt][r] + bv;
+        float* dst = p.C + (long)row * p.ldc + col;
+        if (atomic) {
+          atomicAdd(dst, v);
+        } else {
+          if (accumulate) v += *dst;
+          if (relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
+                           int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
+                           float* C, int ldc, const float* bias, int flags, int splits, ss_stream_t stream) {
+  SS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, SS_ERR_ARG);
+  SS_REQUIRE(splits >= 1 && a_group > 0 && b_group > 0, SS_ERR_ARG);
+  // split-K accumulates with atomics: C must already hold the value to add to, and ReLU cannot apply
+  SS_REQUIRE(splits == 1 || ((flags & 1) && !(flags & 2)), SS_ERR_ARG);
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.ra = RowMap{a_group, a_gstride, a_off};
+  p.rb = RowMap{b_group, b_gstride, b_off};
+  int per = ceil_div(ceil_div(K, splits), BK) * BK;
+  p.ksplit = per;
+  int nz = ceil_div(K, per);
+  p.flags = flags;
+  dim3 grid(ceil_div(N, BN), ceil_div(M, BM), nz), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p);
+  else if (a_kcontig && !b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
+  else if (!a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
+  return ss_launch_status();
+}

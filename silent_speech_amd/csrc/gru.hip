@@ -1,0 +1,275 @@
+// Masked bidirectional GRU recurrence, forward and BPTT, with W_hh resident in registers.
+//
+// Replaces the packed nn.GRU call of /root/reference/train_model_official.py:301-305 (one layer,
+// both directions per launch; the input projection W_ih x + b_ih for all timesteps is a dense
+// GEMM done beforehand, ss_gemm_f32).  pack_padded_sequence semantics are reproduced by masking:
+// the forward direction freezes h and emits zeros for t >= len, the reverse direction walks
+// t = T-1 .. 0 and simply skips t >= len, so it starts from h = 0 at each clip's last valid frame.
+//
+// Work split: one workgroup per (16-clip slice, direction).  H/16 waves; wave w owns hidden units
+// [16w, 16w+16) of all three gates.  v_mfma_f32_16x16x4_f32 with A = W_hh rows (one VGPR per 16x4
+// fragment, 3*H/4 fragments per lane = the whole 3H x H matrix spread over the workgroup's
+// register file, loaded once), B = h^T (k x clip) read from a 2-slot LDS ring, D rows = hidden
+// unit, D cols = clip.  The three gate accumulators of one (unit, clip) land in the same lane, so
+// sigmoid/tanh/blend run in registers and each step costs one workgroup barrier.
+#include "ss_common.h"
+
+namespace {
+
+constexpr int SLICE = 16;  // clips per workgroup = MFMA N
+
+template <int H>
+struct GruCfg {
+  static constexpr int NW = H / 16;        // waves
+  static constexpr int KS = H / 4;         // k-steps of the h GEMM
+  static constexpr int KS_B = 3 * H / 4;   // k-steps of the transposed (BPTT) GEMM
+  // 12 waves (H=192) leave 168 VGPRs per lane: not enough for 144 weight fragments plus the working
+  // set, so the tail of each fragment list lives in LDS (lane-linear, conflict-free ds_read_b32).
+  static constexpr int KREG_F = (H > 128) ? 34 : KS;          // per gate, forward
+  static constexpr int KLDS_F = KS - KREG_F;
+  static constexpr int KREG_B = (H > 128) ? 108 : KS_B;       // backward
+  static constexpr int KLDS_B = KS_B - KREG_B;
+};
+
+struct GruFwdParams {
+  const float* gi;      // [2][B*T][3H]   W_ih x + b_ih, gate order r|z|n
+  const float* w_hh[2]; // [3H][H]
+  const float* b_hh[2]; // [3H]
+  const int* lengths;   // [B]
+  float* out;           // [B][T][2H]   forward dir in cols [0,H), reverse in [H,2H)
+  float* save;          // [2][B*T][4][H]  r, z, n, q=(W_hn h + b_hn); may be null (inference)
+  int B, T;
+};
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void gru_fwd_kernel(GruFwdParams p) {
+  using C = GruCfg<H>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * H * SLICE + 3 * H + 3 * C::KLDS_F * C::NW * 64];
+  float* hbuf = lds;                   // [2][H][16]
+  float* bias = lds + 2 * H * SLICE;   // [3H]
+  float* wlds = bias + 3 * H;          // [3*KLDS_F][NW][64]
+
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * SLICE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int j0 = 16 * w + 4 * g;  // first of this lane's 4 hidden units
+  const int clip = b0 + i;
+  const bool clip_ok = clip < p.B;
+  const int len = clip_ok ? p.lengths[clip] : 0;
+  const int T = p.T;
+
+  // W_hh fragments: A[i][k] = W[(gate*H + 16w + i)][4kk + g]
+  float wf[3][C::KREG_F];
+  {
+    const float* W = p.w_hh[dir];
+#pragma unroll
+    for (int G = 0; G < 3; ++G)
+#pragma unroll
+      for (int kk = 0; kk < C::KS; ++kk) {
+        float v = W[(long)(G * H + 16 * w + i) * H + 4 * kk + g];
+        if (kk < C::KREG_F) wf[G][kk] = v;
+        else wlds[((G * C::KLDS_F + kk - C::KREG_F) * C::NW + w) * 64 + lane] = v;
+      }
+  }
+  for (int q = threadIdx.x; q < 3 * H; q += blockDim.x) bias[q] = p.b_hh[dir][q];
+  for (int q = threadIdx.x; q < 2 * H * SLICE; q += blockDim.x) hbuf[q] = 0.f;
+  __syncthreads();
+
+  f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+  const long dir_off = (long)dir * p.B * T;
+  int cur = 0;
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? (T - 1 - s) : s;
+    const long frame = (long)clip * T + t;
+    // input-projection gates for this (clip, t): issued early, consumed after the MFMA chain
+    f32x4 gr = {0.f, 0.f, 0.f, 0.f}, gz = gr, gn = gr;
+    const bool valid = t < len;
+    if (valid) {
+      const float* gp = p.gi + (dir_off + frame) * (3 * H) + j0;
+      gr = *reinterpret_cast<const f32x4*>(gp);
+      gz = *reinterpret_cast<const f32x4*>(gp + H);
+      gn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+    }
+    f32x4 ar = *reinterpret_cast<const f32x4*>(&bias[j0]);
+    f32x4 az = *reinterpret_cast<const f32x4*>(&bias[H + j0]);
+    f32x4 an = *reinterpret_cast<const f32x4*>(&bias[2 * H + j0]);
+    const float* hb = hbuf + cur * H * SLICE;
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+      float b = hb[(4 * kk + g) * SLICE + i];
+      float w0, w1, w2;
+      if (kk < C::KREG_F) {
+        w0 = wf[0][kk]; w1 = wf[1][kk]; w2 = wf[2][kk];
+      } else {
+        const float* wl = wlds + ((kk - C::KREG_F) * C::NW + w) * 64 + lane;
+        w0 = wl[0];
+        w1 = wl[C::KLDS_F * C::NW * 64];
+        w2 = wl[2 * C::KLDS_F * C::NW * 64];
+      }
+      ar = mfma16(w0, b, ar);
+      az = mfma16(w1, b, az);
+      an = mfma16(w2, b, an);
+    }
+    f32x4 r, z, n, hn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r[e] = sigmoid_f(gr[e] + ar[e]);
+      z[e] = sigmoid_f(gz[e] + az[e]);
+      n[e] = tanh_f(gn[e] + r[e] * an[e]);
+      hn[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
+    }
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      hp = hn;
+      o = hn;
+    }
+    if (clip_ok) {
+      *reinterpret_cast<f32x4*>(p.out + frame * (2 * H) + dir * H + j0) = o;
+      if (p.save && valid) {
+        float* sp = p.save + (dir_off + frame) * (4 * H) + j0;
+        *reinterpret_cast<f32x4*>(sp) = r;
+        *reinterpret_cast<f32x4*>(sp + H) = z;
+        *reinterpret_cast<f32x4*>(sp + 2 * H) = n;
+        *reinterpret_cast<f32x4*>(sp + 3 * H) = an;
+      }
+    }
+    float* hnx = hbuf + (cur ^ 1) * H * SLICE;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hnx[(j0 + e) * SLICE + i] = hp[e];
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+struct GruBwdParams {
+  const float* d_out;   // [B][T][2H]  gradient w.r.t. this layer's output
+  const float* out;     // [B][T][2H]  forward output (h_{t-1} comes from here)
+  const float* save;    // [2][B*T][4][H]
+  const float* w_hh[2]; // [3H][H]
+  const int* lengths;
+  float* d_g;           // [2][B*T][4][H]: d a_r, d a_z, d a_n (= d gi), and d a_n * r (hh side of n)
+  int B, T;
+};
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void gru_bwd_kernel(GruBwdParams p) {
+  using C = GruCfg<H>;
+  __shared__ __attribute__((aligned(16))) float lds[3 * H * SLICE + C::KLDS_B * C::NW * 64];
+  float* db = lds;                      // [3H][16]
+  float* wlds = lds + 3 * H * SLICE;    // [KLDS_B][NW][64]
+
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * SLICE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int j0 = 16 * w + 4 * g;
+  const int clip = b0 + i;
+  const bool clip_ok = clip < p.B;
+  const int len = clip_ok ? p.lengths[clip] : 0;
+  const int T = p.T;
+
+  // transposed fragments: dh_prev[k] = sum_row W[row][k] * dgh[row];  A[i][slot] = W[4ks+g][16w+i]
+  float wf[C::KREG_B];
+  {
+    const float* W = p.w_hh[dir];
+#pragma unroll
+    for (int ks = 0; ks < C::KS_B; ++ks) {
+      float v = W[(long)(4 * ks + g) * H + 16 * w + i];
+      if (ks < C::KREG_B) wf[ks] = v;
+      else wlds[((ks - C::KREG_B) * C::NW + w) * 64 + lane] = v;
+    }
+  }
+
+  f32x4 dh = {0.f, 0.f, 0.f, 0.f};  // gradient flowing into h_t from later steps of the recurrence
+  const long dir_off = (long)dir * p.B * T;
+  for (int s = 0; s < T; ++s) {
+    // reverse of the forward iteration order
+    const int t = dir ? s : (T - 1 - s);
+    const int tp = dir ? t + 1 : t - 1;  // where h_prev was emitted
+    const long frame = (long)clip * T + t;
+    const bool valid = t < len;
+    f32x4 dar = {0.f, 0.f, 0.f, 0.f}, daz = dar, dan = dar, dqn = dar, dcarry = dh;
+    if (valid) {
+      f32x4 go = *reinterpret_cast<const f32x4*>(p.d_out + frame * (2 * H) + dir * H + j0);
+      const float* sp = p.save + (dir_off + frame) * (4 * H) + j0;
+      f32x4 r = *reinterpret_cast<const f32x4*>(sp);
+      f32x4 z = *reinterpret_cast<const f32x4*>(sp + H);
+      f32x4 n = *reinterpret_cast<const f32x4*>(sp + 2 * H);
+      f32x4 q = *reinterpret_cast<const f32x4*>(sp + 3 * H);
+      f32x4 hprev = {0.f, 0.f, 0.f, 0.f};
+      if (tp >= 0 && tp < len) hprev = *reinterpret_cast<const f32x4*>(p.out + ((long)clip * T + tp) * (2 * H) + dir * H + j0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float d = go[e] + dh[e];
+        float dn = d * (1.0f - z[e]);
+        float dz = d * (hprev[e] - n[e]);
+        dan[e] = dn * (1.0f - n[e] * n[e]);
+        dar[e] = dan[e] * q[e] * r[e] * (1.0f - r[e]);
+        daz[e] = dz * z[e] * (1.0f - z[e]);
+        dqn[e] = dan[e] * r[e];
+        dcarry[e] = d * z[e];
+      }
+    }
+    if (clip_ok) {
+      float* gp = p.d_g + (dir_off + frame) * (4 * H) + j0;
+      *reinterpret_cast<f32x4*>(gp) = dar;
+      *reinterpret_cast<f32x4*>(gp + H) = daz;
+      *reinterpret_cast<f32x4*>(gp + 2 * H) = dan;
+      *reinterpret_cast<f32x4*>(gp + 3 * H) = dqn;
+    }
+    __syncthreads();  // previous step's MFMA reads of db are done (also orders the wlds fill)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      db[(j0 + e) * SLICE + i] = dar[e];
+      db[(H + j0 + e) * SLICE + i] = daz[e];
+      db[(2 * H + j0 + e) * SLICE + i] = dqn[e];
+    }
+    __syncthreads();
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+    for (int ks = 0; ks < C::KS_B; ++ks) {
+      float a = (ks < C::KREG_B) ? wf[ks < C::KREG_B ? ks : 0] : wlds[((ks - C::KREG_B) * C::NW + w) * 64 + lane];
+      float b = db[(4 * ks + g) * SLICE + i];
+      if (ks % 3 == 0) a0 = mfma16(a, b, a0);
+      else if (ks % 3 == 1) a1 = mfma16(a, b, a1);
+      else a2 = mfma16(a, b, a2);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dh[e] = dcarry[e] + (a0[e] + a1[e]) + a2[e];
+  }
+}
+
+}  // namespace
+
+extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
+                          const float* b_hh_r, const int32_t* lengths, int B, int T, int H, float* out, float* save,
+                          ss_stream_t stream) {
+  SS_REQUIRE(gi && w_hh_f && w_hh_r && b_hh_f && b_hh_r && lengths && out, SS_ERR_ARG);
+  SS_REQUIRE(B > 0 && T > 0, SS_ERR_ARG);
+  GruFwdParams p;
+  p.gi = gi; p.w_hh[0] = w_hh_f; p.w_hh[1] = w_hh_r; p.b_hh[0] = b_hh_f; p.b_hh[1] = b_hh_r;
+  p.lengths = lengths; p.out = out; p.save = save; p.B = B; p.T = T;
+  dim3 grid(ceil_div(B, SLICE), 2);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (H == 192) hipLaunchKernelGGL(gru_fwd_kernel<192>, grid, dim3(768), 0, s, p);
+  else if (H == 64) hipLaunchKernelGGL(gru_fwd_kernel<64>, grid, dim3(256), 0, s, p);
+  else return SS_ERR_UNSUPPORTED;
+  return ss_launch_status();
+}
+
+extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* save, const float* w_hh_f,
+                          const float* w_hh_r, const int32_t* lengths, int B, int T, int H, float* d_g,
+                          ss_stream_t stream) {
+  SS_REQUIRE(d_out && out && save && w_hh_f && w_hh_r && lengths && d_g, SS_ERR_ARG);
+  SS_REQUIRE(B > 0 && T > 0, SS_ERR_ARG);
+  GruBwdParams p;
+  p.d_out = d_out; p.out = out; p.save = save; p.w_hh[0] = w_hh_f; p.w_hh[1] = w_hh_r;
+  p.lengths = lengths; p.d_g = d_g; p.B = B; p.T = T;
+  dim3 grid(ceil_div(B, SLICE), 2);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (H == 192) hipLaunchKernelGGL(gru_bwd_kernel<192>, grid, dim3(768), 0, s, p);
+  else if (H == 64) hipLaunchKernelGGL(gru_bwd_kernel<64>, grid, dim3(256), 0, s, p);
+  else return SS_ERR_UNSUPPORTED;
+  return ss_launch_status();
+}

@@ -1,0 +1,133 @@
+// Flat-bucket optimiser step: global-norm clip folded into Adam, plus the small streaming helpers
+// (row copy, column sums).  Replaces clip_grad_norm_ + torch.optim.Adam.step of
+// /root/reference/train_model_official.py:403, 438-439.  All HBM-bound: 16-byte lanes, grid-stride.
+#include <math.h>
+
+#include "ss_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const long n4 = n >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+    f32x4 v = x4[q];
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    float v = x[(n4 << 2) + threadIdx.x];
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+struct AdamParams {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long n;
+  const float* sumsq;
+  float grad_scale, max_norm, step_size, beta1, beta2, eps, inv_sqrt_bc2;
+};
+
+__global__ __launch_bounds__(256) void adam_clip_kernel(AdamParams a) {
+  const float total = sqrtf(a.sumsq[0]) * a.grad_scale;
+  const float coef = a.grad_scale * fminf(1.0f, a.max_norm / (total + 1e-6f));
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < a.n; q += (long)gridDim.x * 256) {
+    const float g = a.g[q] * coef;
+    const float m = a.beta1 * a.m[q] + (1.0f - a.beta1) * g;
+    const float v = a.beta2 * a.v[q] + (1.0f - a.beta2) * g * g;
+    a.m[q] = m;
+    a.v[q] = v;
+    const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+    a.p[q] -= a.step_size * (m / denom);
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst,
+                                                        int ld_dst, int rows, int cols) {
+  const long total = (long)rows * cols;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+    int r = (int)(q / cols), c = (int)(q % cols);
+    dst[(long)r * ld_dst + c] = src[(long)r * ld_src + c];
+  }
+}
+
+// grid (ceil(cols/64), row chunks); thread (c = tid&63, rr = tid>>6) strides rows by 4
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int rows, int cols, int lda,
+                                                     int rows_per_block, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rr = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc = 0.f;
+  if (c < cols)
+    for (int r = r0 + rr; r < r1; r += 4) acc += A[(long)r * lda + c];
+  red[rr][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rr == 0 && c < cols) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" int ss_sumsq_f32(const float* x, long n, float* sumsq, ss_stream_t stream) {
+  SS_REQUIRE(x && sumsq && n > 0, SS_ERR_ARG);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, SS_ERR_ARG);
+  int blocks = (int)(((n >> 2) + 255) / 256);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, sumsq);
+  return ss_launch_status();
+}
+
+extern "C" int ss_adam_clip(float* p, const float* g, float* m, float* v, long n, const float* sumsq,
+                            float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                            ss_stream_t stream) {
+  SS_REQUIRE(p && g && m && v && sumsq && n > 0 && step >= 1, SS_ERR_ARG);
+  AdamParams a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.sumsq = sumsq;
+  a.grad_scale = grad_scale; a.max_norm = max_norm;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  a.step_size = (float)((double)lr / bc1);
+  a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  int blocks = (int)((n + 255) / 256);
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return ss_launch_status();
+}
+
+extern "C" int ss_copy_rows_f32(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols,
+                                ss_stream_t stream) {
+  SS_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, SS_ERR_ARG);
+  long total = (long)rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld_src, dst,
+                     ld_dst, rows, cols);
+  return ss_launch_status();
+}
+
+extern "C" int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_stream_t stream) {
+  SS_REQUIRE(A && out && rows > 0 && cols > 0 && lda >= cols, SS_ERR_ARG);
+  int rpb = 256;
+  dim3 grid(ceil_div(cols, 64), ceil_div(rows, rpb));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), A, rows, cols, lda, rpb, out);
+  return ss_launch_status();
+}
+
+extern "C" int ss_abi_version(void) { return 1; }
+
+extern "C" const char* ss_status_string(int status) {
+  switch (status) {
+    case SS_OK: return "ok";
+    case SS_ERR_ARG: return "invalid argument";
+    case SS_ERR_LAUNCH: return "kernel launch failed";
+    case SS_ERR_UNSUPPORTED: return "unsupported shape";
+    default: return "unknown status";
+  }
+}

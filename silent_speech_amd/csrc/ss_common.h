@@ -1,0 +1,45 @@
+// Shared device helpers for the Silent-Speech hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ss_hotpath.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SS_WAVE 64
+
+// launch-site error handling: every entry point returns 0 or a negative ss_status
+#define SS_REQUIRE(cond, code) \
+  do {                         \
+    if (!(cond)) return (code); \
+  } while (0)
+
+static inline int ss_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SS_OK : SS_ERR_LAUNCH;
+}
+
+// v_mfma_f32_16x16x4_f32: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+// D[row=(lane>>4)*4+reg][col=lane&15].  Exact f32 fma chain.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh via one exp; saturates cleanly (exp->inf gives 1, exp->0 gives -1)
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

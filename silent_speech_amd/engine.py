@@ -1,0 +1,246 @@
+"""Kernel orchestration of the hot path: explicit forward / backward over raw device buffers.
+
+This is the host side of the C ABI (``include/ss_hotpath.h``): it owns the workspace layout in
+HBM and issues the HIP kernels on torch's current stream.  torch is used for device memory and
+streams only -- there is no aten compute op on this path and no CPU fallback.
+
+Data layout (fp32 row-major unless noted; N = B*T frames):
+    Z      (N, x_dim+E)      landmark features | ROI embedding   (the torch.cat, fused)
+    gi_l   (2, N, 3H)        W_ih x + b_ih per direction, layer l
+    out_l  (N, 2H)           GRU layer output, forward | reverse halves
+    save_l (2, N, 4, H)      r, z, n, W_hn h + b_hn                (training only)
+    dG_l   (2, N, 4, H)      d gi_r, d gi_z, d gi_n, d(W_hn h+b_hn) (training only)
+    CNN stash: pooled maps a1 (N,8,H/2,W/2), a2 (N,16,H/4,W/4), pool argmaxes (u8), conv3 sign
+    mask (u8), averaged features (N,24)                            (training only)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+
+INT_MAX = 2**31 - 1
+
+
+@dataclass
+class Config:
+    x_dim: int
+    num_classes: int
+    use_roi: bool
+    roi_emb: int = 32
+    hidden: int = 192
+    gru_layers: int = 2
+    roi_standardize: bool = True
+    gru_dropout: float = 0.1
+    head_dropout: float = 0.2
+    head_mid: int = 128
+    ln_eps: float = 1e-5
+
+    @property
+    def in_dim(self) -> int:
+        return self.x_dim + (self.roi_emb if self.use_roi else 0)
+
+
+def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, relu=False, splits=1,
+         a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0)):
+    """C[M,N] (+)= opA * opB (+bias)(ReLU); A/B/Cm are ints (device addresses)."""
+    flags = (1 if accumulate else 0) | (2 if relu else 0)
+    L.call("ss_gemm_f32", int(a_kc), int(b_kc), M, N, K, A, lda, a_map[0], a_map[1], a_map[2], B, ldb, b_map[0],
+           b_map[1], b_map[2], Cm, ldc, bias, flags, splits, L.stream())
+
+
+def _addr(t: torch.Tensor, offset_elems: int = 0) -> int:
+    return t.data_ptr() + offset_elems * t.element_size()
+
+
+class Workspace:
+    """Activation / gradient buffers for one (B, T, H, W) shape; reused across steps (hipGraph friendly)."""
+
+    def __init__(self, cfg: Config, B: int, T: int, roi_hw, device, train: bool):
+        self.cfg, self.B, self.T, self.roi_hw, self.train = cfg, B, T, roi_hw, train
+        N, H = B * T, cfg.hidden
+        f32 = dict(device=device, dtype=torch.float32)
+        u8 = dict(device=device, dtype=torch.uint8)
+        self.lengths = torch.empty(B, device=device, dtype=torch.int32)
+        self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
+        self.gi = [torch.empty(2, N, 3 * H, **f32) for _ in range(cfg.gru_layers)]
+        self.out = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers)]
+        self.attn = torch.empty(B, T, **f32)
+        self.pooled = torch.empty(B, 2 * H, **f32)
+        self.ln = torch.empty(B, 2 * H, **f32)
+        self.mid = torch.empty(B, cfg.head_mid, **f32)
+        self.logits = torch.empty(B, cfg.num_classes, **f32)
+        self.out_drop = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers - 1)]
+        self.mid_drop = torch.empty(B, cfg.head_mid, **f32)
+        if train:
+            self.save = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
+            self.dG = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
+            self.d_out = torch.empty(N, 2 * H, **f32)
+            self.xhat = torch.empty(B, 2 * H, **f32)
+            self.rstd = torch.empty(B, **f32)
+            self.d_logits = torch.empty(B, cfg.num_classes, **f32)
+            self.d_mid = torch.empty(B, cfg.head_mid, **f32)
+            self.d_ln = torch.empty(B, 2 * H, **f32)
+            self.d_pooled = torch.empty(B, 2 * H, **f32)
+            self.dZ = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
+            if cfg.use_roi:
+                Hh, Ww = roi_hw
+                self.st_a1 = torch.empty(N, 8, Hh // 2, Ww // 2, **f32)
+                self.st_i1 = torch.empty(N, 8, Hh // 2, Ww // 2, **u8)
+                self.st_a2 = torch.empty(N, 16, Hh // 4, Ww // 4, **f32)
+                self.st_i2 = torch.empty(N, 16, Hh // 4, Ww // 4, **u8)
+                self.st_m3 = torch.empty(N, 24, (Hh // 4) * (Ww // 4), **u8)
+                self.st_feat = torch.empty(N, 24, **f32)
+
+
+def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Tensor, R: Optional[torch.Tensor], *,
+            train: bool, stash: bool = False, seed: int = 0) -> torch.Tensor:
+    """Runs the forward kernels; returns ws.logits (B,C).  ``ws.lengths`` must already hold the int32 lengths.
+    ``train`` turns the two dropouts on (p from cfg); ``stash`` keeps what ``backward`` needs (needs a
+    Workspace built with train=True)."""
+    B, T, H, N = ws.B, ws.T, cfg.hidden, ws.B * ws.T
+    s = L.stream()
+    if stash and not ws.train:
+        raise RuntimeError("stash=True needs a training workspace")
+    # ---- ROI branch: normalise + CNN -> columns [x_dim, x_dim+E) of Z; X -> columns [0, x_dim)
+    if cfg.use_roi:
+        Hh, Ww = ws.roi_hw
+        ws_Z = ws.Z
+        L.call("ss_copy_rows_f32", X.data_ptr(), cfg.x_dim, ws_Z.data_ptr(), cfg.in_dim, N, cfg.x_dim, s)
+        cw = [P[k].data_ptr() for k in ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight",
+                                        "roi_cnn.net.3.bias", "roi_cnn.net.6.weight", "roi_cnn.net.6.bias",
+                                        "roi_cnn.fc.weight", "roi_cnn.fc.bias")]
+        st = ([ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
+               ws.st_m3.data_ptr(), ws.st_feat.data_ptr()] if stash else [None] * 6)
+        L.call("ss_roi_cnn_fwd_stash", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
+               _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, s)
+        layer_in, ld_in = ws_Z.data_ptr(), cfg.in_dim
+    else:
+        layer_in, ld_in = X.data_ptr(), cfg.x_dim
+    # ---- GRU layers
+    for l in range(cfg.gru_layers):
+        K = cfg.in_dim if l == 0 else 2 * H
+        for d, suf in enumerate(("", "_reverse")):
+            gemm(1, 1, N, 3 * H, K, layer_in, ld_in, P[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K,
+                 _addr(ws.gi[l], d * N * 3 * H), 3 * H, bias=P[f"gru.bias_ih_l{l}{suf}"].data_ptr())
+        L.call("ss_gru_fwd", ws.gi[l].data_ptr(), P[f"gru.weight_hh_l{l}"].data_ptr(),
+               P[f"gru.weight_hh_l{l}_reverse"].data_ptr(), P[f"gru.bias_hh_l{l}"].data_ptr(),
+               P[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.lengths.data_ptr(), B, T, H, ws.out[l].data_ptr(),
+               ws.save[l].data_ptr() if stash else None, s)
+        layer_in, ld_in = ws.out[l].data_ptr(), 2 * H
+        if train and l < cfg.gru_layers - 1 and cfg.gru_dropout > 0.0:
+            L.call("ss_dropout", ws.out[l].data_ptr(), ws.out_drop[l].data_ptr(), N * 2 * H, cfg.gru_dropout, seed,
+                   (l + 1) << 40, None, s)
+            layer_in = ws.out_drop[l].data_ptr()
+    top = ws.out[cfg.gru_layers - 1]
+    # ---- AttnPool + head
+    L.call("ss_attn_pool_fwd", top.data_ptr(), ws.lengths.data_ptr(), P["pool.score.weight"].data_ptr(),
+           P["pool.score.bias"].data_ptr(), B, T, 2 * H, ws.attn.data_ptr(), ws.pooled.data_ptr(), s)
+    L.call("ss_layernorm_fwd", ws.pooled.data_ptr(), P["head.0.weight"].data_ptr(), P["head.0.bias"].data_ptr(), B,
+           2 * H, cfg.ln_eps, ws.ln.data_ptr(), ws.xhat.data_ptr() if stash else None,
+           ws.rstd.data_ptr() if stash else None, s)
+    gemm(1, 1, B, cfg.head_mid, 2 * H, ws.ln.data_ptr(), 2 * H, P["head.1.weight"].data_ptr(), 2 * H,
+         ws.mid.data_ptr(), cfg.head_mid, bias=P["head.1.bias"].data_ptr(), relu=True)
+    mid = ws.mid
+    if train and cfg.head_dropout > 0.0:
+        L.call("ss_dropout", ws.mid.data_ptr(), ws.mid_drop.data_ptr(), B * cfg.head_mid, cfg.head_dropout, seed,
+               7 << 40, None, s)
+        mid = ws.mid_drop
+    gemm(1, 1, B, cfg.num_classes, cfg.head_mid, mid.data_ptr(), cfg.head_mid, P["head.4.weight"].data_ptr(),
+         cfg.head_mid, ws.logits.data_ptr(), cfg.num_classes, bias=P["head.4.bias"].data_ptr())
+    return ws.logits
+
+
+def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Tensor,
+             R: Optional[torch.Tensor], d_logits: torch.Tensor, *, train: bool, seed: int = 0,
+             d_X: Optional[torch.Tensor] = None) -> None:
+    """Accumulates d(loss)/d(param) into ``G`` (same keys as ``P``) given d(loss)/d(logits).
+    Must follow a ``forward(..., train=<same>, seed=<same>)`` on the same workspace."""
+    B, T, H, N = ws.B, ws.T, cfg.hidden, ws.B * ws.T
+    s = L.stream()
+    C, MID = cfg.num_classes, cfg.head_mid
+    drop_head = train and cfg.head_dropout > 0.0
+    mid_used = ws.mid_drop if drop_head else ws.mid
+    # ---- head
+    gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, mid_used.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
+         accumulate=True)
+    L.call("ss_colsum_f32", d_logits.data_ptr(), B, C, C, G["head.4.bias"].data_ptr(), s)
+    gemm(1, 0, B, MID, C, d_logits.data_ptr(), C, P["head.4.weight"].data_ptr(), MID, ws.d_mid.data_ptr(), MID)
+    # dropout mask (same seed/offset as the forward) and ReLU' in one pass
+    L.call("ss_dropout", ws.d_mid.data_ptr(), ws.d_mid.data_ptr(), B * MID, cfg.head_dropout if drop_head else 0.0,
+           seed, 7 << 40, ws.mid.data_ptr(), s)
+    gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
+         2 * H, accumulate=True)
+    L.call("ss_colsum_f32", ws.d_mid.data_ptr(), B, MID, MID, G["head.1.bias"].data_ptr(), s)
+    gemm(1, 0, B, 2 * H, MID, ws.d_mid.data_ptr(), MID, P["head.1.weight"].data_ptr(), 2 * H, ws.d_ln.data_ptr(),
+         2 * H)
+    L.call("ss_layernorm_bwd", ws.d_ln.data_ptr(), ws.xhat.data_ptr(), ws.rstd.data_ptr(),
+           P["head.0.weight"].data_ptr(), B, 2 * H, ws.d_pooled.data_ptr(), G["head.0.weight"].data_ptr(),
+           G["head.0.bias"].data_ptr(), s)
+    # ---- AttnPool -> d_out of the top GRU layer
+    top = ws.out[cfg.gru_layers - 1]
+    L.call("ss_attn_pool_bwd", top.data_ptr(), ws.lengths.data_ptr(), P["pool.score.weight"].data_ptr(),
+           ws.attn.data_ptr(), ws.d_pooled.data_ptr(), B, T, 2 * H, ws.d_out.data_ptr(),
+           G["pool.score.weight"].data_ptr(), G["pool.score.bias"].data_ptr(), s)
+    # ---- GRU layers, top down
+    ksplit = max(1, min(16, N // 512))
+    for l in range(cfg.gru_layers - 1, -1, -1):
+        K = cfg.in_dim if l == 0 else 2 * H
+        L.call("ss_gru_bwd", ws.d_out.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(),
+               P[f"gru.weight_hh_l{l}"].data_ptr(), P[f"gru.weight_hh_l{l}_reverse"].data_ptr(),
+               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), s)
+        if l == 0:
+            if cfg.use_roi:
+                lin, ld_in = ws.Z.data_ptr(), cfg.in_dim
+            else:
+                lin, ld_in = X.data_ptr(), cfg.x_dim
+        else:
+            use_drop = train and cfg.gru_dropout > 0.0
+            lin, ld_in = (ws.out_drop[l - 1] if use_drop else ws.out[l - 1]).data_ptr(), 2 * H
+        for d, suf in enumerate(("", "_reverse")):
+            dg = _addr(ws.dG[l], d * N * 4 * H)
+            # d W_ih = dGi^T . layer_in ; d b_ih = colsum(dGi)
+            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K,
+                 accumulate=True, splits=ksplit)
+            L.call("ss_colsum_f32", dg, N, 3 * H, 4 * H, G[f"gru.bias_ih_l{l}{suf}"].data_ptr(), s)
+            # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse)
+            a_map = (T - 1, T, 1) if d == 0 else (T - 1, T, 0)
+            b_map = (T - 1, T, 0) if d == 0 else (T - 1, T, 1)
+            hprev = _addr(ws.out[l], d * H)
+            gw = G[f"gru.weight_hh_l{l}{suf}"]
+            if T > 1:
+                gemm(0, 0, 2 * H, H, B * (T - 1), dg, 4 * H, hprev, 2 * H, gw.data_ptr(), H, accumulate=True,
+                     splits=ksplit, a_map=a_map, b_map=b_map)
+                gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, hprev, 2 * H, _addr(gw, 2 * H * H), H,
+                     accumulate=True, splits=ksplit, a_map=a_map, b_map=b_map)
+            gb = G[f"gru.bias_hh_l{l}{suf}"]
+            L.call("ss_colsum_f32", dg, N, 2 * H, 4 * H, gb.data_ptr(), s)
+            L.call("ss_colsum_f32", dg + 3 * H * 4, N, H, 4 * H, _addr(gb, 2 * H), s)
+        # d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r
+        need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
+        if need_dx:
+            if l > 0:
+                dst, ld_dst = ws.d_out.data_ptr(), 2 * H
+            elif cfg.use_roi:
+                dst, ld_dst = ws.dZ.data_ptr(), cfg.in_dim
+            else:
+                dst, ld_dst = d_X.data_ptr(), cfg.x_dim
+            for d, suf in enumerate(("", "_reverse")):
+                gemm(1, 0, N, K, 3 * H, _addr(ws.dG[l], d * N * 4 * H), 4 * H,
+                     P[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K, dst, ld_dst, accumulate=(d == 1))
+            if l > 0 and train and cfg.gru_dropout > 0.0:
+                L.call("ss_dropout", dst, dst, N * 2 * H, cfg.gru_dropout, seed, l << 40, None, s)
+    # ---- ROI CNN
+    if cfg.use_roi:
+        Hh, Ww = ws.roi_hw
+        if d_X is not None:
+            L.call("ss_copy_rows_f32", ws.dZ.data_ptr(), cfg.in_dim, d_X.data_ptr(), cfg.x_dim, N, cfg.x_dim, s)
+        names = ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight", "roi_cnn.net.3.bias",
+                 "roi_cnn.net.6.weight", "roi_cnn.net.6.bias", "roi_cnn.fc.weight", "roi_cnn.fc.bias")
+        L.call("ss_roi_cnn_bwd", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
+               cfg.roi_emb, ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
+               ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
+               *[G[k].data_ptr() for k in names], s)

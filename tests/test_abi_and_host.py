@@ -1,0 +1,82 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ss_hotpath.h declares; host-side
+logic (module surface, flat bucket, sharding) that needs no GPU."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ss_hotpath.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from silent_speech_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        from silent_speech_amd.build import build
+
+        build(verbose=False)
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ss_hotpath.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert lib.ss_abi_version() == 1
+    assert lib.ss_status_string(-3) == b"unsupported shape"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from silent_speech_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _lib.load()
+
+
+def test_module_surface_and_flat_bucket():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as W
+    import silent_speech_amd as ss
+
+    m = ss.BiGRUClassifier(84, 5, use_roi=True)
+    sd = m.state_dict()
+    ref = W.param_shapes(84, 5, True)
+    assert list(sd) == list(ref) and all(tuple(sd[k].shape) == ref[k] for k in ref)
+    assert sum(v.numel() for v in sd.values()) == 1079582
+    # parameters are views of one contiguous bucket, 16-byte aligned each
+    base = m.flat_params.data_ptr()
+    for p in m.parameters():
+        off = p.data_ptr() - base
+        assert 0 <= off < m.flat_params.numel() * 4 and off % 16 == 0
+    # load_state_dict writes through the views
+    new = W.make_state_dict(3, 84, 5, True)
+    m.load_state_dict(new)
+    views = m._views_of(m.flat_params)
+    for k, v in new.items():
+        assert torch.equal(views[k], v)
+    # CPU tensors are refused: the product has no CPU path
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m(torch.zeros(2, 4, 84), torch.tensor([4, 2]), torch.zeros(2, 4, 64, 64, dtype=torch.uint8))
+    # live variant / 1 layer keeps the reference's keys too
+    m1 = ss.BiGRUClassifier(84, 5, use_roi=False, gru_layers=1)
+    assert list(m1.state_dict()) == list(W.param_shapes(84, 5, False, gru_layers=1))
+
+
+def test_shard_range_partitions():
+    from silent_speech_amd import shard_range
+
+    for n, w in ((2048, 8), (256, 1), (10, 4), (7, 8)):
+        got = [shard_range(n, r, w) for r in range(w)]
+        assert got[0][0] == 0 and got[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+    assert [hi - lo for lo, hi in (shard_range(2048, r, 8) for r in range(8))] == [256] * 8

@@ -1,0 +1,504 @@
+"""GPU: every HIP kernel, called through the C ABI (ctypes), against the CPU oracle / fp64 math.
+
+Run on the MI355X box with ``python -m pytest tests -m gpu``.  Tolerances are written next to each
+check; integer outputs (crop boxes, pool argmaxes, masks) are compared exactly.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import features_ref as FR  # noqa: E402
+from oracle import model_ref as MR  # noqa: E402
+
+INT_MAX = 2**31 - 1
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from silent_speech_amd import _lib
+
+    _lib.load()
+    return _lib
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def report(name, got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    err = (got - ref).abs()
+    idx = int(err.argmax())
+    return f"{name}: max abs err {float(err.max()):.3e} at flat {idx} (got {float(got.reshape(-1)[idx]):.6g}, ref {float(ref.reshape(-1)[idx]):.6g}), ref scale {float(ref.abs().max()):.3e}"
+
+
+def assert_close(name, got, ref, atol, rtol=0.0):
+    g = got.detach().double().cpu()
+    r = ref.detach().double().cpu()
+    assert g.shape == r.shape, (name, g.shape, r.shape)
+    assert torch.isfinite(g).all(), name + " has non-finite values"
+    bad = (g - r).abs() > atol + rtol * r.abs()
+    assert not bad.any(), report(name, got, ref) + f"; {int(bad.sum())}/{bad.numel()} outside atol={atol} rtol={rtol}"
+
+
+# ------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K,pad", [(70, 50, 37, 3), (256, 576, 116, 0), (130, 64, 16, 4), (5, 128, 256, 0)])
+def test_gemm_layouts(L, a_kc, b_kc, M, N, K, pad):
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double() @ Bm.double() + bias.double()).float()
+    # storage with a padded leading dimension
+    a_st = (A if a_kc else A.t()).contiguous()
+    b_st = (Bm.t() if b_kc else Bm).contiguous()
+    lda, ldb, ldc = a_st.shape[1] + pad, b_st.shape[1] + pad, N + pad
+    a_buf = torch.zeros(a_st.shape[0], lda); a_buf[:, : a_st.shape[1]] = a_st
+    b_buf = torch.zeros(b_st.shape[0], ldb); b_buf[:, : b_st.shape[1]] = b_st
+    a_d, b_d, bias_d = dev(a_buf), dev(b_buf), dev(bias)
+    c_d = torch.full((M, ldc), 7.0, device="cuda")
+    L.call("ss_gemm_f32", a_kc, b_kc, M, N, K, a_d.data_ptr(), lda, INT_MAX, 0, 0, b_d.data_ptr(), ldb, INT_MAX, 0, 0,
+           c_d.data_ptr(), ldc, bias_d.data_ptr(), 0, 1, L.stream())
+    sync()
+    assert_close("gemm", c_d[:, :N], ref, atol=2e-5 * K ** 0.5, rtol=1e-5)
+    if pad:
+        assert torch.all(c_d[:, N:] == 7.0), "wrote outside the N columns"
+
+
+def test_gemm_accumulate_relu_splitk_rowmap(L):
+    g = torch.Generator().manual_seed(5)
+    # accumulate + relu
+    M, N, K = 96, 80, 64
+    A, Bm, C0 = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
+    a_d, b_d, c_d = dev(A), dev(Bm), dev(C0)
+    L.call("ss_gemm_f32", 1, 1, M, N, K, a_d.data_ptr(), K, INT_MAX, 0, 0, b_d.data_ptr(), K, INT_MAX, 0, 0,
+           c_d.data_ptr(), N, None, 3, 1, L.stream())
+    sync()
+    assert_close("acc+relu", c_d, F.relu(C0.double() + A.double() @ Bm.double().t()).float(), atol=2e-4)
+    # split-K with atomics, [K][M] x [K][N] operands and the (b,t)->(b,t-1) row pairing
+    Bc, T, Mm, Nn = 6, 9, 48, 40
+    dG = torch.randn(Bc * T, Mm, generator=g)
+    Hh = torch.randn(Bc * T, Nn, generator=g)
+    ref = torch.zeros(Mm, Nn, dtype=torch.float64)
+    for b in range(Bc):
+        for t in range(1, T):
+            ref += torch.outer(dG[b * T + t].double(), Hh[b * T + t - 1].double())
+    dg_d, h_d = dev(dG), dev(Hh)
+    c_d = torch.zeros(Mm, Nn, device="cuda")
+    L.call("ss_gemm_f32", 0, 0, Mm, Nn, Bc * (T - 1), dg_d.data_ptr(), Mm, T - 1, T, 1, h_d.data_ptr(), Nn, T - 1, T, 0,
+           c_d.data_ptr(), Nn, None, 1, 3, L.stream())
+    sync()
+    assert_close("splitk+rowmap", c_d, ref.float(), atol=3e-4)
+
+
+# ------------------------------------------------------------------------------------- GRU
+def _gru_case(H, In, B, T, seed, lengths=None):
+    g = torch.Generator().manual_seed(seed)
+    a = 1.5 / H ** 0.5
+    mk = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * a
+    sd = {}
+    for suf in ("", "_reverse"):
+        sd[f"gru.weight_ih_l0{suf}"] = mk(3 * H, In)
+        sd[f"gru.weight_hh_l0{suf}"] = mk(3 * H, H)
+        sd[f"gru.bias_ih_l0{suf}"] = mk(3 * H)
+        sd[f"gru.bias_hh_l0{suf}"] = mk(3 * H)
+    x = torch.randn(B, T, In, generator=g)
+    if lengths is None:
+        lengths = torch.randint(1, T + 1, (B,), generator=g)
+        lengths[0] = T
+        if B > 2:
+            lengths[2] = 1
+    return sd, x, torch.as_tensor(lengths, dtype=torch.int64)
+
+
+@pytest.mark.parametrize("H,B,T", [(192, 5, 7), (192, 37, 12), (64, 3, 20), (192, 16, 1)])
+def test_gru_fwd_bwd(L, H, B, T):
+    In = 20
+    sd, x, lengths = _gru_case(H, In, B, T, seed=H + B + T)
+    N = B * T
+    # reference: explicit masked GRU on CPU with autograd
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xg = x.clone().requires_grad_(True)
+    gi_ref = [F.linear(xg, leaves["gru.weight_ih_l0" + s], leaves["gru.bias_ih_l0" + s]) for s in ("", "_reverse")]
+    for t_ in gi_ref:
+        t_.retain_grad()
+
+    def direction(gi_all, suf, reverse):
+        h = x.new_zeros(B, H)
+        outs = [None] * T
+        for t in (range(T - 1, -1, -1) if reverse else range(T)):
+            valid = (lengths > t).float().unsqueeze(1)
+            hn = MR.gru_cell(gi_all[:, t], h, leaves["gru.weight_hh_l0" + suf], leaves["gru.bias_hh_l0" + suf])
+            h = valid * hn + (1 - valid) * h
+            outs[t] = valid * h
+        return torch.stack(outs, 1)
+
+    out_ref = torch.cat([direction(gi_ref[0], "", False), direction(gi_ref[1], "_reverse", True)], 2)
+    wgt = torch.randn(B, T, 2 * H, generator=torch.Generator().manual_seed(1))
+    (out_ref * wgt).sum().backward()
+
+    gi_d = dev(torch.stack([gi_ref[0].detach().reshape(N, 3 * H), gi_ref[1].detach().reshape(N, 3 * H)]))
+    P = {k: dev(v) for k, v in sd.items()}
+    len_d = dev(lengths.to(torch.int32))
+    out_d = torch.full((N, 2 * H), 9.0, device="cuda")
+    save_d = torch.zeros(2, N, 4, H, device="cuda")
+    L.call("ss_gru_fwd", gi_d.data_ptr(), P["gru.weight_hh_l0"].data_ptr(), P["gru.weight_hh_l0_reverse"].data_ptr(),
+           P["gru.bias_hh_l0"].data_ptr(), P["gru.bias_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H,
+           out_d.data_ptr(), save_d.data_ptr(), L.stream())
+    sync()
+    assert_close("gru out", out_d.view(B, T, 2 * H), out_ref, atol=2e-5)
+    # inference form (no stash) gives the same bits
+    out2 = torch.empty_like(out_d)
+    L.call("ss_gru_fwd", gi_d.data_ptr(), P["gru.weight_hh_l0"].data_ptr(), P["gru.weight_hh_l0_reverse"].data_ptr(),
+           P["gru.bias_hh_l0"].data_ptr(), P["gru.bias_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H,
+           out2.data_ptr(), None, L.stream())
+    sync()
+    assert torch.equal(out2, out_d)
+
+    dout_d = dev(wgt.reshape(N, 2 * H))
+    dg_d = torch.full((2, N, 4, H), 5.0, device="cuda")
+    L.call("ss_gru_bwd", dout_d.data_ptr(), out_d.data_ptr(), save_d.data_ptr(), P["gru.weight_hh_l0"].data_ptr(),
+           P["gru.weight_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H, dg_d.data_ptr(), L.stream())
+    sync()
+    for d in range(2):
+        dgi_ref = gi_ref[d].grad.reshape(N, 3 * H)
+        assert_close(f"d gi dir{d}", dg_d[d, :, :3].reshape(N, 3 * H), dgi_ref, atol=3e-5, rtol=1e-4)
+        suf = "" if d == 0 else "_reverse"
+        # 4th block = d(W_hn h + b_hn): its column sum is the n-part of d b_hh
+        db_hh = leaves["gru.bias_hh_l0" + suf].grad
+        assert_close(f"d b_hh n dir{d}", dg_d[d, :, 3].sum(0), db_hh[2 * H:], atol=2e-4, rtol=1e-4)
+        assert_close(f"d b_hh rz dir{d}", dg_d[d, :, :2].reshape(N, 2 * H).sum(0), db_hh[: 2 * H], atol=2e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------- AttnPool / LayerNorm / CE
+def test_attn_pool(L):
+    B, T, D = 7, 11, 384
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(B, T, D, generator=g)
+    lengths = torch.tensor([11, 1, 5, 11, 2, 7, 3])
+    for b in range(B):
+        h[b, lengths[b]:] = 0
+    sd = {"pool.score.weight": torch.randn(1, D, generator=g) * 0.2, "pool.score.bias": torch.randn(1, generator=g)}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hg = h.clone().requires_grad_(True)
+    pooled_ref = MR.attn_pool(hg, lengths, leaves)
+    dp = torch.randn(B, D, generator=g)
+    (pooled_ref * dp).sum().backward()
+    h_d, len_d, w_d, b_d = dev(h), dev(lengths.to(torch.int32)), dev(sd["pool.score.weight"]), dev(sd["pool.score.bias"])
+    attn = torch.empty(B, T, device="cuda")
+    pooled = torch.empty(B, D, device="cuda")
+    L.call("ss_attn_pool_fwd", h_d.data_ptr(), len_d.data_ptr(), w_d.data_ptr(), b_d.data_ptr(), B, T, D,
+           attn.data_ptr(), pooled.data_ptr(), L.stream())
+    sync()
+    assert_close("pooled", pooled, pooled_ref, atol=2e-6, rtol=1e-5)
+    assert_close("attn rows sum to 1", attn.sum(1), torch.ones(B), atol=1e-6)
+    dh = torch.full((B, T, D), 3.0, device="cuda")
+    gw, gb = torch.zeros(D, device="cuda"), torch.zeros(1, device="cuda")
+    L.call("ss_attn_pool_bwd", h_d.data_ptr(), len_d.data_ptr(), w_d.data_ptr(), attn.data_ptr(), dev(dp).data_ptr(), B, T,
+           D, dh.data_ptr(), gw.data_ptr(), gb.data_ptr(), L.stream())
+    sync()
+    mask = (torch.arange(T).unsqueeze(0) < lengths.unsqueeze(1)).unsqueeze(-1)
+    assert_close("d h", dh, hg.grad * mask, atol=3e-6, rtol=1e-5)
+    assert_close("d w_score", gw, leaves["pool.score.weight"].grad.reshape(-1), atol=2e-5, rtol=1e-5)
+    assert abs(float(gb)) < 1e-5
+
+
+def test_layernorm(L):
+    B, D = 9, 384
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, D, generator=g) * 3 + 1
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    xg, gg, bg = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xg, (D,), gg, bg, 1e-5)
+    dy = torch.randn(B, D, generator=g)
+    (y_ref * dy).sum().backward()
+    y, xhat, rstd = (torch.empty(B, D, device="cuda"), torch.empty(B, D, device="cuda"), torch.empty(B, device="cuda"))
+    x_d, g_d, b_d = dev(x), dev(gamma), dev(beta)
+    L.call("ss_layernorm_fwd", x_d.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), B, D, 1e-5, y.data_ptr(), xhat.data_ptr(),
+           rstd.data_ptr(), L.stream())
+    dx, ggam, gbet = torch.empty(B, D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    L.call("ss_layernorm_bwd", dev(dy).data_ptr(), xhat.data_ptr(), rstd.data_ptr(), g_d.data_ptr(), B, D, dx.data_ptr(),
+           ggam.data_ptr(), gbet.data_ptr(), L.stream())
+    sync()
+    assert_close("ln y", y, y_ref, atol=3e-6, rtol=1e-5)
+    assert_close("ln dx", dx, xg.grad, atol=3e-6, rtol=1e-5)
+    assert_close("ln dgamma", ggam, gg.grad, atol=1e-5, rtol=1e-5)
+    assert_close("ln dbeta", gbet, bg.grad, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,C", [(8, 5), (300, 10), (3, 100)])
+def test_ce_label_smoothing(L, B, C):
+    g = torch.Generator().manual_seed(B + C)
+    logits = torch.randn(B, C, generator=g) * 3
+    y = torch.randint(0, C, (B,), generator=g)
+    lg = logits.clone().requires_grad_(True)
+    loss_ref = F.cross_entropy(lg, y, label_smoothing=0.05)
+    loss_ref.backward()
+    d = torch.empty(B, C, device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    correct = torch.zeros(1, device="cuda", dtype=torch.int32)
+    L.call("ss_ce_ls_fwd_bwd", dev(logits).data_ptr(), dev(y).data_ptr(), B, C, 0.05, float(B), d.data_ptr(),
+           loss.data_ptr(), correct.data_ptr(), L.stream())
+    sync()
+    assert abs(float(loss) - float(loss_ref)) < 2e-6 * max(1.0, abs(float(loss_ref)))
+    assert_close("d logits", d, lg.grad, atol=1e-7, rtol=1e-5)
+    assert int(correct) == int((logits.argmax(1) == y).sum())
+
+
+def test_sumsq_adam_clip(L):
+    n = 100003
+    g = torch.Generator().manual_seed(8)
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.01
+    m, v = torch.zeros(n), torch.zeros(n)
+    p_d, g_d, m_d, v_d = dev(p), dev(gr), dev(m), dev(v)
+    ss = torch.zeros(1, device="cuda")
+    pr = p.clone()
+    for step in (1, 2, 3):
+        ss.zero_()
+        L.call("ss_sumsq_f32", g_d.data_ptr(), n, ss.data_ptr(), L.stream())
+        L.call("ss_adam_clip", p_d.data_ptr(), g_d.data_ptr(), m_d.data_ptr(), v_d.data_ptr(), n, ss.data_ptr(), 1.0, 1.0,
+               3e-4, 0.9, 0.999, 1e-8, step, L.stream())
+        sync()
+        total = float(gr.double().norm())
+        assert abs(float(ss.sqrt()) - total) < 1e-5 * total
+        MR.adam_step(pr, gr * MR.clip_coef(total, 1.0), m, v, step)
+        assert_close(f"adam p step {step}", p_d, pr, atol=2e-7, rtol=1e-6)
+    # grad_scale (mean over ranks after a summing all-reduce)
+    p2, m2, v2 = dev(p), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    g4 = dev(gr * 4)
+    ss.zero_()
+    L.call("ss_sumsq_f32", g4.data_ptr(), n, ss.data_ptr(), L.stream())
+    L.call("ss_adam_clip", p2.data_ptr(), g4.data_ptr(), m2.data_ptr(), v2.data_ptr(), n, ss.data_ptr(), 0.25, 1.0, 3e-4,
+           0.9, 0.999, 1e-8, 1, L.stream())
+    p3, m3, v3 = dev(p), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    ss.zero_()
+    L.call("ss_sumsq_f32", g_d.data_ptr(), n, ss.data_ptr(), L.stream())
+    L.call("ss_adam_clip", p3.data_ptr(), g_d.data_ptr(), m3.data_ptr(), v3.data_ptr(), n, ss.data_ptr(), 1.0, 1.0, 3e-4,
+           0.9, 0.999, 1e-8, 1, L.stream())
+    sync()
+    assert_close("grad_scale", p2, p3, atol=1e-7)
+
+
+def test_dropout_mask_is_reproducible_and_unbiased(L):
+    n = 1 << 20
+    x = torch.ones(n, device="cuda")
+    y1, y2, y3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    L.call("ss_dropout", x.data_ptr(), y1.data_ptr(), n, 0.2, 11, 5 << 40, None, L.stream())
+    L.call("ss_dropout", x.data_ptr(), y2.data_ptr(), n, 0.2, 11, 5 << 40, None, L.stream())
+    L.call("ss_dropout", x.data_ptr(), y3.data_ptr(), n, 0.2, 12, 5 << 40, None, L.stream())
+    sync()
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    keep = float((y1 > 0).float().mean())
+    assert abs(keep - 0.8) < 3e-3
+    assert abs(float(y1.mean()) - 1.0) < 5e-3
+    assert set(torch.unique(y1).tolist()) == {0.0, 1.25}
+
+
+# ------------------------------------------------------------------------------------- ROI CNN
+def _cnn_sd(seed):
+    import weights as W
+
+    sd = W.make_state_dict(seed, 84, 5, True)
+    return {k: v for k, v in sd.items() if k.startswith("roi_cnn.")}
+
+
+CNN_KEYS = ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight", "roi_cnn.net.3.bias",
+            "roi_cnn.net.6.weight", "roi_cnn.net.6.bias", "roi_cnn.fc.weight", "roi_cnn.fc.bias")
+
+
+def _cnn_frames(N, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    R = torch.randint(0, 256, (N, H, W), generator=g, dtype=torch.uint8)
+    ramp = (torch.arange(W).view(1, 1, W) * 255 // (W - 1)).to(torch.int32)
+    R = ((R.to(torch.int32) + ramp) // 2).to(torch.uint8)
+    R[0] = 0
+    if N > 1:
+        R[1] = 200
+    if N > 2:
+        R[2] = 17
+        R[2, 3, 5] = 18
+    return R
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (48, 96)])
+@pytest.mark.parametrize("standardize", [1, 0])
+def test_roi_cnn_fwd(L, H, W, standardize):
+    N = 300 if (H, W) == (64, 64) else 19  # 300 > 256 workgroups: exercises the persistent frame walk
+    sd = _cnn_sd(21)
+    R = _cnn_frames(N, H, W, 2)
+    ref = MR.roi_cnn(MR.roi_normalise(R.unsqueeze(0), bool(standardize)), sd)[0]
+    P = [dev(sd[k]) for k in CNN_KEYS]
+    ld = 40
+    out = torch.full((N, ld), -3.0, device="cuda")
+    L.call("ss_roi_cnn_fwd", dev(R).data_ptr(), N, H, W, standardize, *[p.data_ptr() for p in P], 32,
+           out.data_ptr() + 8 * 4, ld, L.stream())
+    sync()
+    assert_close("roi_e", out[:, 8:], ref, atol=2e-5, rtol=1e-4)
+    assert torch.all(out[:, :8] == -3.0)
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (48, 96)])
+def test_roi_cnn_stash_and_bwd(L, H, W):
+    N = 270 if (H, W) == (64, 64) else 11
+    sd = _cnn_sd(22)
+    R = _cnn_frames(N, H, W, 3)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = MR.roi_normalise(R.unsqueeze(0), True)[0]  # (N,1,H,W)
+    c1 = F.relu(F.conv2d(x, leaves[CNN_KEYS[0]], leaves[CNN_KEYS[1]], padding=1))
+    a1, i1 = F.max_pool2d(c1, 2, return_indices=True)
+    c2 = F.relu(F.conv2d(a1, leaves[CNN_KEYS[2]], leaves[CNN_KEYS[3]], padding=1))
+    a2, i2 = F.max_pool2d(c2, 2, return_indices=True)
+    c3 = F.relu(F.conv2d(a2, leaves[CNN_KEYS[4]], leaves[CNN_KEYS[5]], padding=1))
+    feat = c3.mean((2, 3))
+    out_ref = F.linear(feat, leaves[CNN_KEYS[6]], leaves[CNN_KEYS[7]])
+    d_out = torch.randn(N, 32, generator=torch.Generator().manual_seed(9))
+    (out_ref * d_out).sum().backward()
+
+    P = [dev(sd[k]) for k in CNN_KEYS]
+    R_d = dev(R)
+    out = torch.empty(N, 32, device="cuda")
+    H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+    st_a1 = torch.empty(N, 8, H2, W2, device="cuda")
+    st_i1 = torch.empty(N, 8, H2, W2, device="cuda", dtype=torch.uint8)
+    st_a2 = torch.empty(N, 16, H4, W4, device="cuda")
+    st_i2 = torch.empty(N, 16, H4, W4, device="cuda", dtype=torch.uint8)
+    st_m3 = torch.empty(N, 24, H4 * W4, device="cuda", dtype=torch.uint8)
+    st_feat = torch.empty(N, 24, device="cuda")
+    st = [st_a1, st_i1, st_a2, st_i2, st_m3, st_feat]
+    L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out.data_ptr(), 32,
+           *[s.data_ptr() for s in st], L.stream())
+    sync()
+    assert_close("roi_e", out, out_ref, atol=2e-5, rtol=1e-4)
+    assert_close("stash a1", st_a1, a1, atol=1e-5, rtol=1e-5)
+    assert_close("stash a2", st_a2, a2, atol=2e-5, rtol=1e-5)
+    assert_close("stash feat", st_feat, feat, atol=1e-5, rtol=1e-5)
+
+    # argmax: compare where the winner is positive and clearly separated (ties / relu zeros carry no gradient)
+    def idx_to_win(idx, w_in):  # flat index in the (2h x 2w) plane -> 0..3 inside its window
+        yy, xx = idx // w_in, idx % w_in
+        return ((yy % 2) * 2 + (xx % 2)).to(torch.uint8)
+
+    def top2_gap(c):  # gap between the best and second best of every 2x2 window
+        n_, ch, hh, ww = c.shape
+        win = c.reshape(n_, ch, hh // 2, 2, ww // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n_, ch, hh // 2, ww // 2, 4)
+        top = win.topk(2, dim=-1).values
+        return top[..., 0] - top[..., 1]
+
+    for name, st_i, idx, c, a in (("i1", st_i1, i1, c1, a1), ("i2", st_i2, i2, c2, a2)):
+        sure = (a > 1e-4) & (top2_gap(c.detach()) > 1e-4)
+        got = st_i.cpu()[sure]
+        want = idx_to_win(idx, c.shape[3])[sure]
+        assert torch.equal(got, want), f"{name}: {(got != want).sum()} argmax mismatches of {sure.sum()}"
+    m3_ref = (c3.detach() > 0).reshape(N, 24, -1)
+    sure3 = (c3.detach().abs() > 1e-4).reshape(N, 24, -1)
+    assert torch.equal(st_m3.cpu().bool()[sure3], m3_ref[sure3])
+
+    G = [torch.zeros_like(p) for p in P]
+    L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
+           dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
+    sync()
+    for k, gg in zip(CNN_KEYS, G):
+        ref = leaves[k].grad
+        scale = float(ref.abs().max())
+        assert_close("grad " + k, gg, ref, atol=3e-4 * max(scale, 1e-3), rtol=1e-3)
+    # gradients accumulate: a second call doubles them
+    L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
+           dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
+    sync()
+    assert_close("accumulate", G[4], 2 * leaves[CNN_KEYS[4]].grad, atol=6e-4 * float(leaves[CNN_KEYS[4]].grad.abs().max()),
+                 rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------- features / crop
+def _anchors(idxs):
+    idxs = [int(v) for v in idxs]
+    return idxs.index(61), idxs.index(291), idxs.index(13), idxs.index(14)
+
+
+@pytest.mark.parametrize("tag", ["88", "40"])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_feature_fuse_vs_golden(L, golden_dir, tag, variant):
+    d = np.load(os.path.join(golden_dir, "features.npz"))
+    idxs = d["idx" + tag]
+    lm = torch.from_numpy(d["lm"][:, idxs]).unsqueeze(0)  # (1,T,K,2)
+    T, K = lm.shape[1], lm.shape[2]
+    reset = torch.from_numpy(d["reset"].astype(np.uint8)).unsqueeze(0)
+    X = torch.zeros(1, T, 2 * K + 4, device="cuda")
+    cen = torch.zeros(1, T, 2, device="cuda")
+    fourth = torch.zeros(1, T, device="cuda", dtype=torch.float64)
+    L.call("ss_feature_fuse", dev(lm).data_ptr(), dev(reset).data_ptr(), 1, T, K, int(d["w"]), int(d["h"]), *_anchors(idxs),
+           variant, X.data_ptr(), 2 * K + 4, cen.data_ptr(), fourth.data_ptr(), L.stream())
+    sync()
+    vname = "record" if variant == 0 else "live"
+    ref = d[f"feat_{vname}_{tag}"]
+    assert np.array_equal(cen[0].cpu().numpy(), d[f"center_{vname}_{tag}"]), "centre must be bit-exact"
+    np.testing.assert_allclose(fourth[0].cpu().numpy(), d[f"fourth_{vname}_{tag}"], rtol=1e-15 if variant == 0 else 2e-7)
+    got = X[0].cpu().numpy()
+    np.testing.assert_allclose(got[:, : 2 * K], ref[:, : 2 * K], rtol=0, atol=1.2e-7)
+    np.testing.assert_allclose(got[:, 2 * K:], ref[:, 2 * K:], rtol=1e-6, atol=1e-7)
+    assert np.all(got[d["reset"], 2 * K] == 0.0)
+
+
+def test_feature_fuse_batched_vs_oracle(L):
+    B, T, K, w, h = 33, 30, 40, 640, 480
+    rng = np.random.default_rng(0)
+    lm = (rng.uniform(0.3, 0.7, (B, 1, K, 2)) + rng.normal(0, 0.004, (B, T, K, 2))).astype(np.float32)
+    lm[:, :, 8] = [0.42, 0.61]; lm[:, :, 25] = [0.58, 0.61]; lm[:, :, 1] = [0.5, 0.59]; lm[:, :, 2] = [0.5, 0.63]
+    lm += rng.normal(0, 0.002, lm.shape).astype(np.float32)
+    X = torch.zeros(B, T, 2 * K + 4, device="cuda")
+    cen = torch.zeros(B, T, 2, device="cuda")
+    fourth = torch.zeros(B, T, device="cuda", dtype=torch.float64)
+    L.call("ss_feature_fuse", dev(torch.from_numpy(lm)).data_ptr(), None, B, T, K, w, h, 8, 25, 1, 2, 0, X.data_ptr(),
+           2 * K + 4, cen.data_ptr(), fourth.data_ptr(), L.stream())
+    sync()
+    for b in (0, 7, 32):
+        Xr, cr, fr = FR.extract_clip(lm[b], w, h, (8, 25, 1, 2), None, "record")
+        assert np.array_equal(cen[b].cpu().numpy(), cr)
+        np.testing.assert_allclose(fourth[b].cpu().numpy(), fr, rtol=1e-15)
+        np.testing.assert_allclose(X[b].cpu().numpy(), Xr, rtol=1e-6, atol=1.2e-7)
+
+
+def test_crop_idx_bit_exact(L, golden_dir):
+    d = np.load(os.path.join(golden_dir, "crop.npz"))
+    checked = 0
+    for (w, h) in {tuple(v) for v in d["wh"].tolist()}:
+        for variant in (0, 1):
+            sel = (d["wh"][:, 0] == w) & (d["wh"][:, 1] == h) & (d["variant"] == variant)
+            n = int(sel.sum())
+            box = torch.zeros(n, 5, device="cuda", dtype=torch.int32)
+            L.call("ss_roi_crop_idx", dev(torch.from_numpy(d["center"][sel])).data_ptr(),
+                   dev(torch.from_numpy(d["scale"][sel])).data_ptr(), n, int(w), int(h), variant, box.data_ptr(),
+                   L.stream())
+            sync()
+            got = box.cpu().numpy()
+            assert np.array_equal(got[:, 4], d["valid"][sel])
+            ok = d["valid"][sel] == 1
+            assert np.array_equal(got[ok][:, :4], d["box"][sel][ok])
+            checked += int(ok.sum())
+    assert checked > 2000
+    # random sweep against the oracle (which the golden file pins), including invalid boxes' coordinates
+    rng = np.random.default_rng(1)
+    n = 20000
+    cen = rng.uniform(-50, 700, (n, 2)).astype(np.float32)
+    sc = rng.uniform(0, 200, n)
+    for variant in (0, 1):
+        box = torch.zeros(n, 5, device="cuda", dtype=torch.int32)
+        L.call("ss_roi_crop_idx", dev(torch.from_numpy(cen)).data_ptr(), dev(torch.from_numpy(sc)).data_ptr(), n, 640, 480,
+               variant, box.data_ptr(), L.stream())
+        sync()
+        got = box.cpu().numpy()
+        ref = np.array([FR.crop_box(cen[k], sc[k], 640, 480, "record" if variant == 0 else "live") for k in range(n)])
+        assert np.array_equal(got, ref)

@@ -1,0 +1,215 @@
+"""GPU: the drop-in module, autograd path and fused trainer against the golden vectors (which the
+reference produced) and against the CPU oracle on fresh seeded inputs.
+
+Bar (BASELINE.json north_star): logits within 1e-3 fp32 of the CPU reference.  The checks below
+use the much tighter tolerances the fp32 kernels actually reach.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import weights as W  # noqa: E402
+from oracle import model_ref as MR  # noqa: E402
+
+LOGIT_TOL = 1e-3  # the contract
+TIGHT = 5e-5      # what we hold ourselves to
+
+
+@pytest.fixture(scope="module")
+def ss():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import silent_speech_amd as ss_
+
+    return ss_
+
+
+def load_case(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    use_roi = bool(int(d["use_roi"]))
+    sd = W.make_state_dict(int(d["seed"]), int(d["x_dim"]), int(d["num_classes"]), use_roi, gru_layers=int(d["layers"]))
+    X, Lh, y = torch.from_numpy(d["X"]), torch.from_numpy(d["lengths"]), torch.from_numpy(d["y"])
+    R = torch.from_numpy(d["R"]) if use_roi else None
+    return d, sd, X, Lh, R, y
+
+
+def build(ss, d, sd, standardize=True):
+    m = ss.BiGRUClassifier(int(d["x_dim"]), int(d["num_classes"]), use_roi=bool(int(d["use_roi"])),
+                           gru_layers=int(d["layers"]), roi_standardize=standardize)
+    m.load_state_dict(sd)  # strict: key names and shapes are the reference's
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("name", ["model_lm_only", "model_roi64", "model_shipped", "model_live_l1", "model_live_l2"])
+def test_logits_match_reference_golden(ss, golden_dir, name):
+    d, sd, X, Lh, R, y = load_case(golden_dir, name)
+    m = build(ss, d, sd, standardize=(str(d["cls"]) == "train"))
+    with torch.no_grad():
+        logits = m(X.cuda(), Lh, R.cuda() if R is not None else None)  # lengths stay on the host, as in the reference
+    err = float((logits.cpu() - torch.from_numpy(d["logits"])).abs().max())
+    assert err < LOGIT_TOL, err
+    assert err < TIGHT, f"{name}: logit max-abs-err {err:.3e}"
+
+
+def test_state_dict_surface(ss):
+    m = ss.BiGRUClassifier(180, 10, use_roi=True)
+    ref = W.param_shapes(180, 10, True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, shp in ref.items():
+        assert tuple(sd[k].shape) == shp and sd[k].dtype == torch.float32
+    assert sum(v.numel() for v in sd.values()) == 1190819
+    m2 = ss.BiGRUClassifier(84, 5, use_roi=False)
+    assert not any(k.startswith("roi_cnn") for k in m2.state_dict())
+    with pytest.raises(RuntimeError):
+        m2(torch.zeros(1, 3, 84), torch.tensor([3]))  # CPU tensors: no CPU path, must fail loudly
+
+
+@pytest.mark.parametrize("name", ["model_lm_only", "model_roi64", "model_shipped"])
+def test_autograd_grads_match_oracle_and_golden(ss, golden_dir, name):
+    d, sd, X, Lh, R, y = load_case(golden_dir, name)
+    m = build(ss, d, sd)
+    logits = m(X.cuda(), Lh.cuda(), R.cuda() if R is not None else None)
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda(), label_smoothing=0.05)
+    loss.backward()
+    assert abs(float(loss) - float(d["loss"])) < 2e-5
+    _, _, grads = MR.loss_and_grads(sd, X, Lh, R, y)
+    for k, p in m.named_parameters():
+        ref = grads[k]
+        got = p.grad.cpu()
+        scale = max(float(ref.abs().max()), 1e-4)
+        bad = (got - ref).abs() > 2e-4 * scale + 2e-3 * ref.abs()
+        assert not bad.any(), f"{k}: max err {float((got - ref).abs().max()):.3e} vs scale {scale:.3e}"
+        # and the reference's own numbers (reduced form)
+        np.testing.assert_allclose(W.reduce_tensor(got), d["grad::" + k], atol=3e-4 * scale * max(1.0, np.sqrt(got.numel() / 53)),
+                                   rtol=5e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["model_lm_only", "model_roi64"])
+def test_fused_trainer_two_steps_match_reference(ss, golden_dir, name):
+    d, sd, X, Lh, R, y = load_case(golden_dir, name)
+    m = build(ss, d, sd)
+    tr = ss.Trainer(m, dropout=False)
+    Xd, Ld, yd = X.cuda(), Lh.cuda(), y.cuda()
+    Rd = R.cuda() if R is not None else None
+    loss1, correct1 = tr.step(Xd, Ld, Rd, yd)
+    assert abs(float(loss1) - float(d["loss"])) < 2e-5
+    assert abs(float(tr.grad_norm()) - float(d["total_norm"])) < 1e-3 * float(d["total_norm"])
+    sd1 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for k, v in sd1.items():
+        atol = 6.1e-4 if k == "pool.score.bias" else 3e-6  # see tests/test_oracle_golden.py
+        np.testing.assert_allclose(W.reduce_tensor(v), d["step1::" + k], atol=atol, rtol=2e-5, err_msg=k)
+    loss2, _ = tr.step(Xd, Ld, Rd, yd)
+    assert abs(float(loss2) - float(d["loss2"])) < 5e-5
+    with torch.no_grad():
+        after = m(Xd, Ld, Rd)
+    err = float((after.cpu() - torch.from_numpy(d["logits_after2"])).abs().max())
+    assert err < LOGIT_TOL and err < 2e-4, err
+
+
+def test_padding_never_leaks_and_batch_permutes(ss, golden_dir):
+    d, sd, X, Lh, R, y = load_case(golden_dir, "model_roi64")
+    m = build(ss, d, sd)
+    with torch.no_grad():
+        a = m(X.cuda(), Lh, R.cuda())
+        X2, R2 = X.clone(), R.clone()
+        for b, n in enumerate(Lh.tolist()):
+            X2[b, n:] = 123.0
+            R2[b, n:] = 77
+        b_ = m(X2.cuda(), Lh, R2.cuda())
+        perm = torch.tensor([2, 0, 1])
+        c = m(X[perm].cuda(), Lh[perm], R[perm].cuda())
+    assert torch.equal(a, b_), "values past a clip's length changed its logits"
+    assert torch.equal(a[perm], c), "a clip's logits depend on its position in the batch"
+
+
+def test_config2_shapes_vs_oracle(ss):
+    """BASELINE config 2 geometry (D=84, 64x64 ROI, T=30) at a batch the CPU oracle finishes in seconds."""
+    B, T = 24, 30
+    sd = W.make_state_dict(7, 84, 5, True)
+    X, Lh, R, y = W.make_inputs(7, B, T, 84, 5, (64, 64))
+    m = ss.BiGRUClassifier(84, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    with torch.no_grad():
+        logits = m(X.cuda(), Lh, R.cuda())
+    ref = MR.forward(sd, X, Lh, R, impl="aten")
+    err = float((logits.cpu() - ref).abs().max())
+    assert err < TIGHT, err
+    # one fused step vs the oracle's step
+    tr = ss.Trainer(m, dropout=False)
+    loss, _ = tr.step(X.cuda(), Lh.cuda(), R.cuda(), y.cuda())
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    loss_ref, _, _, total = MR.train_step(sd2, {}, X, Lh, R, y, impl="aten")
+    assert abs(float(loss) - float(loss_ref)) < 2e-5
+    assert abs(float(tr.grad_norm()) - total) < 1e-3 * total
+    with torch.no_grad():
+        after = m(X.cuda(), Lh, R.cuda())
+    ref_after = MR.forward(sd2, X, Lh, R, impl="aten")
+    assert float((after.cpu() - ref_after).abs().max()) < 2e-4
+
+
+def test_full_size_properties(ss):
+    """BASELINE config 2 at full size (B=256): properties that need no oracle run."""
+    B, T = 256, 30
+    sd = W.make_state_dict(9, 84, 5, True)
+    X, Lh, R, y = W.make_inputs(9, B, T, 84, 5, (64, 64))
+    m = ss.BiGRUClassifier(84, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    Xd, Rd = X.cuda(), R.cuda()
+    with torch.no_grad():
+        a = m(Xd, Lh, Rd)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
+        b = m(Xd[perm.cuda()], Lh[perm], Rd[perm.cuda()])
+        sub = m(Xd[:16].contiguous(), Lh[:16], Rd[:16].contiguous())
+    assert torch.isfinite(a).all()
+    assert torch.equal(a[perm.cuda()], b)
+    assert torch.equal(a[:16], sub), "a clip's logits depend on the batch size"
+    # training decreases the loss on a fixed batch, and stays finite
+    tr = ss.Trainer(m, dropout=True)
+    m.train()
+    losses = [float(tr.step(Xd, Lh.cuda(), Rd, y.cuda())[0]) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_train_mode_dropout_is_active_and_seeded(ss, golden_dir):
+    d, sd, X, Lh, R, y = load_case(golden_dir, "model_lm_only")
+    m = build(ss, d, sd).train()
+    Xd = X.cuda()
+    with torch.no_grad():
+        a = m(Xd, Lh)
+        b = m(Xd, Lh)
+        m.eval()
+        c = m(Xd, Lh)
+    assert not torch.equal(a, c)          # dropout changes the logits
+    assert torch.equal(a, b)              # same step seed -> same mask (no_grad calls do not advance it)
+    assert float((a - c).abs().max()) < 1.0
+
+
+def test_real_weights_kat_gru(ss, golden_dir):
+    """inactive/word_model_5.pt (1-layer BiGRU 83->64): trained weights through the GEMM + recurrence kernels."""
+    from silent_speech_amd import _lib as L
+    from silent_speech_amd import engine as E
+
+    d = np.load(os.path.join(golden_dir, "kat_word_model_5.npz"))
+    sd = {k[3:]: torch.from_numpy(d[k]).cuda() for k in d.files if k.startswith("w::")}
+    x = torch.from_numpy(d["x"]).cuda()
+    B, T, In = x.shape
+    H, N = 64, B * T
+    gi = torch.empty(2, N, 3 * H, device="cuda")
+    for di, suf in enumerate(("", "_reverse")):
+        E.gemm(1, 1, N, 3 * H, In, x.data_ptr(), In, sd["gru.weight_ih_l0" + suf].data_ptr(), In,
+               gi.data_ptr() + di * N * 3 * H * 4, 3 * H, bias=sd["gru.bias_ih_l0" + suf].data_ptr())
+    out = torch.empty(N, 2 * H, device="cuda")
+    lens = torch.full((B,), T, device="cuda", dtype=torch.int32)
+    L.call("ss_gru_fwd", gi.data_ptr(), sd["gru.weight_hh_l0"].data_ptr(), sd["gru.weight_hh_l0_reverse"].data_ptr(),
+           sd["gru.bias_hh_l0"].data_ptr(), sd["gru.bias_hh_l0_reverse"].data_ptr(), lens.data_ptr(), B, T, H,
+           out.data_ptr(), None, L.stream())
+    torch.cuda.synchronize()
+    err = float((out.view(B, T, 2 * H).cpu() - torch.from_numpy(d["gru_out"])).abs().max())
+    assert err < 2e-5, err
