@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec of the fused training step (forward + CE + backward + [all-reduce] +
+clip + Adam) on BASELINE.json config 2 -- landmark (K=40 -> D=84) + 64x64 grayscale ROI CNN + 2-layer
+BiGRU(192), T=30, batch 256 per GPU, fp32 -- on synthetic clips resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  ``value`` = clips of all ranks / max-over-ranks wall time of exactly K steps.
+``roofline`` prices the slowest kernel of the step against the f32-MFMA peak with its ALGORITHMIC FLOPs
+(2 x MACs of the contraction it implements) over its HIP-event launch duration.
+``cpu_baseline`` = the CPU oracle's train step (same ATen kernels as the reference) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_gflop(tag, B, T, D, E, H, C, roi):
+    """FLOPs (2 per MAC) one launch of each kernel family implements at this config (per launch, not per step)."""
+    N = B * T
+    Hh, Ww = roi
+    px1, px2, px3 = Hh * Ww, (Hh // 2) * (Ww // 2), (Hh // 4) * (Ww // 4)
+    cnn_fwd = 2.0 * N * (px1 * 8 * 9 + px2 * 16 * 72 + px3 * 24 * 144 + 24 * E)
+    # backward: dW3 + da2 + dW2 + da1 + dW1 (conv1 has no dX) + fc
+    cnn_bwd = 2.0 * N * (2 * px3 * 24 * 144 + 2 * px2 * 16 * 72 + px1 * 8 * 9 + 2 * 24 * E)
+    gru_rec = 2.0 * 2 * N * 3 * H * H  # both directions of one layer
+    return {
+        "ss_roi_cnn_fwd_stash": cnn_fwd / 1e9,
+        "ss_roi_cnn_bwd": cnn_bwd / 1e9,
+        "ss_gru_fwd": gru_rec / 1e9,
+        "ss_gru_bwd": gru_rec / 1e9,
+    }.get(tag)
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box gives one
+    GPU's share of a large host; os.cpu_count() would oversubscribe it many times over)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("SS_BENCH_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(args, D, C):
+    """Oracle (``port``) timed on the host cores: bounded sample of the same workload (smaller batch)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as W
+    from oracle import model_ref as MR
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    Bc = args.cpu_batch
+    sd = W.make_state_dict(0, D, C, True)
+    X, L, R, y = W.make_inputs(0, Bc, args.frames, D, C, (args.roi, args.roi), lengths=[args.frames] * Bc)
+    state = {}
+    t0 = time.perf_counter()
+    MR.train_step(sd, state, X, L, R, y, impl="aten")  # warm-up
+    warm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        MR.train_step(sd, state, X, L, R, y, impl="aten")
+        n += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or n >= 20 or (n == 1 and max(warm, el) > args.cpu_seconds):
+            break
+    return {"value": round(Bc * n / el, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps (fwd+CE+bwd+clip+Adam, dropout off) of the CPU oracle at batch {Bc}, T={args.frames}, "
+                      f"{args.roi}x{args.roi} ROI, torch {torch.__version__} ATen CPU kernels, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU (weak scaling)")
+    ap.add_argument("--frames", type=int, default=30)
+    ap.add_argument("--landmarks", type=int, default=40)
+    ap.add_argument("--roi", type=int, default=64)
+    ap.add_argument("--classes", type=int, default=5)
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-times", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    import silent_speech_amd as ss
+    from silent_speech_amd import _lib as L
+
+    B, T, K, C, roi = args.batch, args.frames, args.landmarks, args.classes, args.roi
+    D, E, H = 2 * K + 4, 32, 192
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    # synthetic clips: landmarks -> K1 feature fuse on device; uint8 ROI; full lengths
+    base = torch.rand(B, 1, K, 2, device=dev, generator=g) * torch.tensor([0.4, 0.4], device=dev) + torch.tensor([0.3, 0.4], device=dev)
+    lm = base + 0.004 * torch.randn(B, T, K, 2, device=dev, generator=g)
+    lm[:, :, 8] = torch.tensor([0.42, 0.61], device=dev)   # landmark 61 sits at position 8 of the sorted 40-lip list
+    lm[:, :, 25] = torch.tensor([0.58, 0.61], device=dev)  # 291
+    lm[:, :, 1] = torch.tensor([0.50, 0.59], device=dev)   # 13
+    lm[:, :, 2] = torch.tensor([0.50, 0.63], device=dev)   # 14
+    lm = (lm + 0.002 * torch.randn(B, T, K, 2, device=dev, generator=g)).contiguous()
+    X = torch.empty(B, T, D, device=dev)
+    L.call("ss_feature_fuse", lm.data_ptr(), None, B, T, K, 640, 480, 8, 25, 1, 2, 0, X.data_ptr(), D, None, None, L.stream())
+    R = torch.randint(0, 256, (B, T, roi, roi), device=dev, dtype=torch.uint8, generator=g)
+    lengths = torch.full((B,), T, device=dev, dtype=torch.int64)
+    y = torch.randint(0, C, (B,), device=dev, generator=g)
+
+    torch.manual_seed(0)
+    model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).train()
+    if world > 1:
+        dist.broadcast(model.flat_params, src=0)
+    trainer = ss.Trainer(model, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(X, lengths, R, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(X, lengths, R, y)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax)
+    final_loss = float(loss)
+    assert final_loss == final_loss, "loss is NaN"
+
+    # ---- per-kernel launch durations over K more steps, HIP events on the launch stream
+    kernels, roof = {}, None
+    if not args.no_kernel_times:
+        L.PROFILE = {}
+        for _ in range(args.steps):
+            trainer.step(X, lengths, R, y)
+        torch.cuda.synchronize()
+        prof, L.PROFILE = L.PROFILE, None
+        for tag, evs in prof.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            kernels[tag] = {"launches_per_step": len(ms) / args.steps, "avg_ms": sum(ms) / len(ms),
+                            "ms_per_step": sum(ms) / args.steps}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        gf = algorithmic_gflop(dom, B, T, D, E, H, C, (roi, roi))
+        if gf is not None:
+            achieved = gf / kernels[dom]["avg_ms"]  # GFLOP / ms = TFLOP/s
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "algorithmic_gflop_per_launch": round(gf, 3), "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
+
+    out = {
+        "metric": "clips/sec (30-frame, fwd+bwd)", "value": round(B * world * args.steps / elapsed, 1), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 2: landmark (K={K}, D={D}) + {roi}x{roi} uint8 ROI CNN + 2-layer BiGRU(192), "
+                               f"T={T}, C={C}, train step = fwd + CE(ls .05) + bwd + grad all-reduce + clip(1.0) + Adam, dropout on",
+                   "batch_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}"},
+        "final_loss": round(final_loss, 5),
+    }
+    if roof:
+        out["roofline"] = roof
+    if kernels:
+        out["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, D, C)
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -6,8 +6,13 @@ Drop-in surface of the reference's per-clip path:
 All arithmetic runs in ``libss_hotpath.so`` (hand-written HIP, C ABI in ``include/ss_hotpath.h``);
 there is no CPU or PyTorch-op fallback.
 """
+from . import checkpoint, data, features
+from .checkpoint import load_classifier, save_checkpoint, topk_from_logits
 from .engine import Config
+from .features import crop_boxes, extract_features
 from .model import AttnPool, BiGRUClassifier, TinyROICNN
 from .train import Trainer, allreduce_flat_grads, shard_range
 
-__all__ = ["Config", "BiGRUClassifier", "TinyROICNN", "AttnPool", "Trainer", "allreduce_flat_grads", "shard_range"]
+__all__ = ["Config", "BiGRUClassifier", "TinyROICNN", "AttnPool", "Trainer", "allreduce_flat_grads", "shard_range",
+           "extract_features", "crop_boxes", "load_classifier", "save_checkpoint", "topk_from_logits", "features",
+           "data", "checkpoint"]

@@ -76,9 +76,21 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def call(name: str, *args):
+# Optional per-launch timing (bench.py): when PROFILE is a dict, every call is bracketed by HIP events on the
+# stream the kernel is launched on (torch's current stream) and (start, end) pairs are collected per tag.
+PROFILE = None
+
+
+def call(name: str, *args, tag: str = None):
     lib = load()
-    st = getattr(lib, name)(*args)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st = getattr(lib, name)(*args)
+        e1.record()
+        PROFILE.setdefault(tag or name, []).append((e0, e1))
+    else:
+        st = getattr(lib, name)(*args)
     if st != 0:
         msg = lib.ss_status_string(st).decode()
         raise RuntimeError(f"{name} failed: {msg} ({st})")

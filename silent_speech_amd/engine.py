@@ -45,11 +45,11 @@ class Config:
 
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, relu=False, splits=1,
-         a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0)):
+         a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0), tag="gemm"):
     """C[M,N] (+)= opA * opB (+bias)(ReLU); A/B/Cm are ints (device addresses)."""
     flags = (1 if accumulate else 0) | (2 if relu else 0)
     L.call("ss_gemm_f32", int(a_kc), int(b_kc), M, N, K, A, lda, a_map[0], a_map[1], a_map[2], B, ldb, b_map[0],
-           b_map[1], b_map[2], Cm, ldc, bias, flags, splits, L.stream())
+           b_map[1], b_map[2], Cm, ldc, bias, flags, splits, L.stream(), tag=tag)
 
 
 def _addr(t: torch.Tensor, offset_elems: int = 0) -> int:
@@ -125,7 +125,7 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
         K = cfg.in_dim if l == 0 else 2 * H
         for d, suf in enumerate(("", "_reverse")):
             gemm(1, 1, N, 3 * H, K, layer_in, ld_in, P[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K,
-                 _addr(ws.gi[l], d * N * 3 * H), 3 * H, bias=P[f"gru.bias_ih_l{l}{suf}"].data_ptr())
+                 _addr(ws.gi[l], d * N * 3 * H), 3 * H, bias=P[f"gru.bias_ih_l{l}{suf}"].data_ptr(), tag="gemm_gru_ih")
         L.call("ss_gru_fwd", ws.gi[l].data_ptr(), P[f"gru.weight_hh_l{l}"].data_ptr(),
                P[f"gru.weight_hh_l{l}_reverse"].data_ptr(), P[f"gru.bias_hh_l{l}"].data_ptr(),
                P[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.lengths.data_ptr(), B, T, H, ws.out[l].data_ptr(),
@@ -204,7 +204,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             dg = _addr(ws.dG[l], d * N * 4 * H)
             # d W_ih = dGi^T . layer_in ; d b_ih = colsum(dGi)
             gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K,
-                 accumulate=True, splits=ksplit)
+                 accumulate=True, splits=ksplit, tag="gemm_gru_dW")
             L.call("ss_colsum_f32", dg, N, 3 * H, 4 * H, G[f"gru.bias_ih_l{l}{suf}"].data_ptr(), s)
             # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse)
             a_map = (T - 1, T, 1) if d == 0 else (T - 1, T, 0)
@@ -213,9 +213,9 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             gw = G[f"gru.weight_hh_l{l}{suf}"]
             if T > 1:
                 gemm(0, 0, 2 * H, H, B * (T - 1), dg, 4 * H, hprev, 2 * H, gw.data_ptr(), H, accumulate=True,
-                     splits=ksplit, a_map=a_map, b_map=b_map)
+                     splits=ksplit, a_map=a_map, b_map=b_map, tag="gemm_gru_dW")
                 gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, hprev, 2 * H, _addr(gw, 2 * H * H), H,
-                     accumulate=True, splits=ksplit, a_map=a_map, b_map=b_map)
+                     accumulate=True, splits=ksplit, a_map=a_map, b_map=b_map, tag="gemm_gru_dW")
             gb = G[f"gru.bias_hh_l{l}{suf}"]
             L.call("ss_colsum_f32", dg, N, 2 * H, 4 * H, gb.data_ptr(), s)
             L.call("ss_colsum_f32", dg + 3 * H * 4, N, H, 4 * H, _addr(gb, 2 * H), s)
@@ -230,7 +230,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                 dst, ld_dst = d_X.data_ptr(), cfg.x_dim
             for d, suf in enumerate(("", "_reverse")):
                 gemm(1, 0, N, K, 3 * H, _addr(ws.dG[l], d * N * 4 * H), 4 * H,
-                     P[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K, dst, ld_dst, accumulate=(d == 1))
+                     P[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K, dst, ld_dst, accumulate=(d == 1), tag="gemm_gru_dX")
             if l > 0 and train and cfg.gru_dropout > 0.0:
                 L.call("ss_dropout", dst, dst, N * 2 * H, cfg.gru_dropout, seed, l << 40, None, s)
     # ---- ROI CNN

@@ -28,12 +28,20 @@ def L():
     return _lib
 
 
+_KEEP = []
+
+
 def dev(t):
-    return t.contiguous().cuda()
+    """Host -> device copy that stays alive until the next sync(): a bare ``dev(x).data_ptr()`` would free the
+    temporary at once and let the caching allocator hand its memory to the next ``dev()`` call."""
+    d = t.contiguous().cuda()
+    _KEEP.append(d)
+    return d
 
 
 def sync():
     torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def report(name, got, ref):
@@ -50,7 +58,8 @@ def assert_close(name, got, ref, atol, rtol=0.0):
     assert g.shape == r.shape, (name, g.shape, r.shape)
     assert torch.isfinite(g).all(), name + " has non-finite values"
     bad = (g - r).abs() > atol + rtol * r.abs()
-    assert not bad.any(), report(name, got, ref) + f"; {int(bad.sum())}/{bad.numel()} outside atol={atol} rtol={rtol}"
+    if bad.any():
+        pytest.fail(report(name, got, ref) + f"; {int(bad.sum())}/{bad.numel()} outside atol={atol} rtol={rtol}", pytrace=False)
 
 
 # ------------------------------------------------------------------------------------- GEMM
@@ -212,7 +221,8 @@ def test_attn_pool(L):
     sync()
     mask = (torch.arange(T).unsqueeze(0) < lengths.unsqueeze(1)).unsqueeze(-1)
     assert_close("d h", dh, hg.grad * mask, atol=3e-6, rtol=1e-5)
-    assert_close("d w_score", gw, leaves["pool.score.weight"].grad.reshape(-1), atol=2e-5, rtol=1e-5)
+    gw_ref = leaves["pool.score.weight"].grad.reshape(-1)
+    assert_close("d w_score", gw, gw_ref, atol=2e-6 * float(gw_ref.abs().max()), rtol=1e-5)
     assert abs(float(gb)) < 1e-5
 
 
@@ -289,7 +299,7 @@ def test_sumsq_adam_clip(L):
     L.call("ss_adam_clip", p3.data_ptr(), g_d.data_ptr(), m3.data_ptr(), v3.data_ptr(), n, ss.data_ptr(), 1.0, 1.0, 3e-4,
            0.9, 0.999, 1e-8, 1, L.stream())
     sync()
-    assert_close("grad_scale", p2, p3, atol=1e-7)
+    assert_close("grad_scale", p2, p3, atol=1e-7, rtol=1e-6)
 
 
 def test_dropout_mask_is_reproducible_and_unbiased(L):
@@ -444,7 +454,9 @@ def test_feature_fuse_vs_golden(L, golden_dir, tag, variant):
     sync()
     vname = "record" if variant == 0 else "live"
     ref = d[f"feat_{vname}_{tag}"]
-    assert np.array_equal(cen[0].cpu().numpy(), d[f"center_{vname}_{tag}"]), "centre must be bit-exact"
+    if not np.array_equal(cen[0].cpu().numpy(), d[f"center_{vname}_{tag}"]):
+        pytest.fail("centre must be bit-exact: max diff %g" % np.abs(cen[0].cpu().numpy() - d[f"center_{vname}_{tag}"]).max(),
+                    pytrace=False)
     np.testing.assert_allclose(fourth[0].cpu().numpy(), d[f"fourth_{vname}_{tag}"], rtol=1e-15 if variant == 0 else 2e-7)
     got = X[0].cpu().numpy()
     np.testing.assert_allclose(got[:, : 2 * K], ref[:, : 2 * K], rtol=0, atol=1.2e-7)

@@ -1,0 +1,68 @@
+"""CPU: .npz clip dataset / collate and .pt checkpoint round trip (host logic, no GPU)."""
+import os
+import random
+
+import numpy as np
+import torch
+
+import silent_speech_amd as ss
+from silent_speech_amd import data as D
+
+
+def _clip(tmp, name, T, Dm=180, roi=True, label="yes"):
+    rng = np.random.default_rng(abs(hash(name)) % 2**32)
+    X = rng.normal(size=(T, Dm)).astype(np.float32)
+    R = rng.integers(0, 256, (T + 1, 48, 96), dtype=np.uint8) if roi else None
+    p = os.path.join(tmp, name + ".npz")
+    D.save_clip(p, X, np.arange(T), label, "me", np.arange(88), R)
+    return p, X
+
+
+def test_npz_schema_and_pad_trim(tmp_path):
+    tmp = str(tmp_path)
+    p1, X1 = _clip(tmp, "a", 20)
+    p2, X2 = _clip(tmp, "b", 120, label="no")
+    p3, X3 = _clip(tmp, "c", 7, roi=False)
+    d = np.load(p1, allow_pickle=True)
+    assert set(d.files) == {"X", "ts", "label", "speaker", "idxs", "roi"} and str(d["label"]) == "yes"
+    assert d["roi"].shape == (20, 48, 96) and d["roi"].dtype == np.uint8  # trimmed to len(X), record…:245-248
+    ds = D.NPZWordDataset([p1, p2, p3], {"yes": 0, "no": 1}, max_t=90, augment=False)
+    X, T, R, y = ds[0]
+    assert X.shape == (90, 180) and int(T) == 20 and R.shape == (90, 48, 96) and int(y) == 0
+    assert torch.equal(X[:20], torch.from_numpy(X1)) and float(X[20:].abs().sum()) == 0 and int(R[20:].sum()) == 0
+    X, T, R, y = ds[1]
+    assert int(T) == 90 and torch.equal(X, torch.from_numpy(X2[:90])) and int(y) == 1
+    Xb, Tb, Rb, yb = D.collate_fn([ds[0], ds[1], ds[2]])
+    assert Xb.shape == (3, 90, 180) and Tb.tolist() == [20, 90, 7] and Rb.shape == (3, 90, 48, 96) and Rb.dtype == torch.uint8
+    assert int(Rb[2].sum()) == 0 and Tb.dtype == torch.int64 and yb.dtype == torch.int64
+    Xn, Tn, Rn, yn = D.collate_fn([ds[2]])
+    assert Rn is None
+
+
+def test_augmentation_follows_reference_rules(tmp_path):
+    p, X0 = _clip(str(tmp_path), "a", 30)
+    ds = D.NPZWordDataset([p], {"yes": 0}, augment=True)
+    random.seed(0)
+    np.random.seed(0)
+    lens = set()
+    for _ in range(40):
+        X, T, R, y = ds[0]
+        lens.add(int(T))
+        assert 28 <= int(T) <= 30 and torch.equal(X[0, :0], X[0, :0])
+    assert lens == {28, 29, 30}  # 0, 1 or 2 interior frames dropped
+
+
+def test_checkpoint_round_trip(tmp_path):
+    m = ss.BiGRUClassifier(180, 3, use_roi=True)
+    path = str(tmp_path / "word_model_points_roi.pt")
+    ss.save_checkpoint(path, m, ["aura", "no", "yes"])
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    for key in ("model", "x_dim", "max_t", "use_roi", "roi_w", "roi_h", "labels", "label_to_id", "id_to_label", "seed"):
+        assert key in ck  # train_model_official.py:489-500
+    assert ck["id_to_label"] == {0: "aura", 1: "no", 2: "yes"}
+    m2, id_to_label, max_t, use_roi = ss.load_classifier(path, device="cpu")
+    assert max_t == 90 and use_roi and not m2.training
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    top = ss.topk_from_logits(torch.tensor([[0.1, 2.0, -1.0]]), id_to_label, k=3)
+    assert [t[0] for t in top] == ["no", "aura", "yes"] and abs(sum(t[1] for t in top) - 1) < 1e-6
