@@ -98,11 +98,13 @@ int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const
  * *_group/_gstride/_off remap the storage ROW index r of that operand to
  *   (r / group) * gstride + (r % group) + off   (identity: group = INT32_MAX, off = 0);
  *   used to pair dG[b][t] with h[b][t-1] without materialising a shifted copy.
+ * a_colsum (may be NULL; needs a_kcontig = 0): a_colsum[m] += sum_k A[k][m] -- the bias gradient of a
+ *   Linear layer rides on its weight-gradient GEMM instead of a separate reduction pass.
  * flags bit0: accumulate into C; bit1: ReLU epilogue.  splits > 1 slices K over blockIdx.z and
  * adds with float atomics (requires bit0, C pre-initialised). */
 int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
                 int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
-                float* C, int ldc, const float* bias, int flags, int splits, ss_stream_t stream);
+                float* C, int ldc, const float* bias, float* a_colsum, int flags, int splits, ss_stream_t stream);
 
 /* column sums: out[n] += sum_r A[r*lda + n]  (bias gradients) */
 int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_stream_t stream);
@@ -123,6 +125,11 @@ int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const 
 int ss_gru_bwd(const float* d_out, const float* out, const float* save, const float* w_hh_f,
                const float* w_hh_r, const int32_t* lengths, int B, int T, int H, float* d_g,
                ss_stream_t stream);
+
+/* bias gradients of one GRU layer from d_g: g_bih_* (3H) += colsum(d_g[dir][:, 0:3H]),
+ * g_bhh_* (3H) += colsum(d_g[dir][:, 0:2H] | d_g[dir][:, 3H:4H]).  N = B*T rows per direction. */
+int ss_gru_bias_grad(const float* d_g, int N, int H, float* g_bih_f, float* g_bhh_f, float* g_bih_r, float* g_bhh_r,
+                     ss_stream_t stream);
 
 /* ---- a8: AttnPool (train_model_official.py:231-248) ------------------------------------------
  * h (B,T,D), score weight (D) + bias (1); masked (-1e9) softmax over t, weighted sum.

@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libss_hotpath.so")
+# SS_HOTPATH_LIB selects the diagnostic build (tools/stamp_report.py); the product always loads the in-tree library
+LIB_PATH = os.environ.get("SS_HOTPATH_LIB", os.path.join(_HERE, "libss_hotpath.so"))
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -28,10 +29,11 @@ SIGNATURES = {
     "ss_roi_cnn_fwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i, _vp],
     "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_vp],
     "ss_roi_cnn_bwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_vp, _i] + [_vp] * 8 + [_vp],
-    "ss_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp],
+    "ss_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
     "ss_gru_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "ss_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "ss_gru_bias_grad": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ss_attn_pool_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "ss_attn_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "ss_layernorm_fwd": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],

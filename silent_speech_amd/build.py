@@ -29,7 +29,16 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, stamp: bool = False) -> str:
+    """``stamp=True`` builds the diagnostic library (in-kernel stage timers) next to the real one."""
+    if stamp:
+        out = os.path.join(HERE, "libss_hotpath_stamp.so")
+        srcs = [os.path.join(CSRC, s) for s in SOURCES]
+        cmd = [_hipcc(), *FLAGS, "-DSS_STAMP", "-shared", "-o", out, *srcs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return out
     hdrs = [os.path.join(CSRC, "ss_common.h"), os.path.join(HERE, "..", "include", "ss_hotpath.h")]
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = []
@@ -54,4 +63,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, stamp="--stamp" in sys.argv)

@@ -32,66 +32,78 @@ struct GemmParams {
   int M, N, K;
   int lda, ldb, ldc;
   RowMap ra, rb;
+  float* asum; // optional: asum[m] += sum_k A[k][m] (A stored [k][m]); the bias gradient rides on the dW GEMM
   int ksplit;  // K elements per blockIdx.z slice (multiple of BK)
   int flags;   // bit0: accumulate into C (plain RMW when gridDim.z==1, atomics otherwise); bit1: ReLU
 };
 
-// stage one operand tile into LDS.  ROWS = BM or BN.
+// One operand tile, staged global -> registers (fetch) -> LDS (store) so the loads of tile k+1 are in
+// flight while tile k is multiplied.  ROWS = BM or BN.
 // KCONTIG: memory is [row][k] (row-major over the GEMM's M or N index) -> LDS image [row][LDK]
 // else   : memory is [k][row]                                          -> LDS image [k][ROWS+4]
 template <int ROWS, bool KCONTIG>
-__device__ __forceinline__ void stage(float* __restrict__ lds, const float* __restrict__ P, int ld, const RowMap& rm,
-                                      int row0, int nrows, int k0, int kend, bool vec_ok) {
-  const int tid = threadIdx.x;
-  if (KCONTIG) {
-    // ROWS*16 floats = ROWS*4 float4; thread -> (row = q/4, kq = q%4)
+struct Stager {
+  static constexpr int NV = ROWS * 4 / 256;
+  f32x4 v[NV];
+
+  __device__ __forceinline__ void fetch(const float* __restrict__ P, int ld, const RowMap& rm, int row0, int nrows, int k0,
+                                        int kend, bool vec_ok) {
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int it = 0; it < ROWS * 4 / 256; ++it) {
-      int q = tid + it * 256;
-      int r = q >> 2, kq = q & 3;
-      int gr = row0 + r, gk = k0 + 4 * kq;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gr < nrows) {
-        const float* src = P + rm(gr) * ld + gk;
-        if (vec_ok && gk + 3 < kend) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {
+    for (int it = 0; it < NV; ++it) {
+      const int q = tid + it * 256;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (KCONTIG) {
+        const int r = q >> 2, kq = q & 3;  // thread -> (row, 4-wide k group)
+        const int gr = row0 + r, gk = k0 + 4 * kq;
+        if (gr < nrows) {
+          const float* src = P + rm(gr) * ld + gk;
+          if (vec_ok && gk + 3 < kend) {
+            x = *reinterpret_cast<const f32x4*>(src);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (gk + e < kend) v[e] = src[e];
+            for (int e = 0; e < 4; ++e)
+              if (gk + e < kend) x[e] = src[e];
+          }
+        }
+      } else {
+        const int k = q / (ROWS / 4), rq = q % (ROWS / 4);  // thread -> (k row, 4-wide row group)
+        const int gk = k0 + k, gr = row0 + 4 * rq;
+        if (gk < kend) {
+          const float* src = P + rm(gk) * ld + gr;
+          if (vec_ok && gr + 3 < nrows) {
+            x = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gr + e < nrows) x[e] = src[e];
+          }
         }
       }
-      *reinterpret_cast<f32x4*>(&lds[r * LDK + 4 * kq]) = v;
-    }
-  } else {
-    constexpr int LD = ROWS + 4;
-    // 16 k-rows x ROWS floats; thread -> (k = q / (ROWS/4), rq = q % (ROWS/4))
-#pragma unroll
-    for (int it = 0; it < ROWS * 4 / 256; ++it) {
-      int q = tid + it * 256;
-      int k = q / (ROWS / 4), rq = q % (ROWS / 4);
-      int gk = k0 + k, gr = row0 + 4 * rq;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gk < kend) {
-        const float* src = P + rm(gk) * ld + gr;
-        if (vec_ok && gr + 3 < nrows) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (gr + e < nrows) v[e] = src[e];
-        }
-      }
-      *reinterpret_cast<f32x4*>(&lds[k * LD + 4 * rq]) = v;
+      v[it] = x;
     }
   }
-}
+
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int q = tid + it * 256;
+      if (KCONTIG) {
+        *reinterpret_cast<f32x4*>(&lds[(q >> 2) * LDK + 4 * (q & 3)]) = v[it];
+      } else {
+        constexpr int LD = ROWS + 4;
+        *reinterpret_cast<f32x4*>(&lds[(q / (ROWS / 4)) * LD + 4 * (q % (ROWS / 4))]) = v[it];
+      }
+    }
+  }
+};
 
 template <bool A_KCONTIG, bool B_KCONTIG>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[(A_KCONTIG ? BM * LDK : BK * LDM_A) + (B_KCONTIG ? BN * LDK : BK * LDM_B)];
-  float* As = lds;
-  float* Bs = lds + (A_KCONTIG ? BM * LDK : BK * LDM_A);
+  constexpr int A_SZ = A_KCONTIG ? BM * LDK : BK * LDM_A;
+  constexpr int B_SZ = B_KCONTIG ? BN * LDK : BK * LDM_B;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_SZ + B_SZ)];
 
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = blockIdx.z * p.ksplit;
@@ -108,12 +120,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float asum = 0.f;  // column sums of the [k][row] A tile (bias gradient), thread t < BM owns row m0 + t
+  const bool want_asum = (!A_KCONTIG) && p.asum && blockIdx.x == 0;
 
+  Stager<BM, A_KCONTIG> sa;
+  Stager<BN, B_KCONTIG> sb;
+  sa.fetch(p.A, p.lda, p.ra, m0, p.M, kbeg, kend, a_vec);
+  sb.fetch(p.B, p.ldb, p.rb, n0, p.N, kbeg, kend, b_vec);
+  sa.store(lds);
+  sb.store(lds + A_SZ);
+  __syncthreads();
+
+  int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    stage<BM, A_KCONTIG>(As, p.A, p.lda, p.ra, m0, p.M, k0, kend, a_vec);
-    stage<BN, B_KCONTIG>(Bs, p.B, p.ldb, p.rb, n0, p.N, k0, kend, b_vec);
-    __syncthreads();
-
+    const float* As = lds + cur * (A_SZ + B_SZ);
+    const float* Bs = As + A_SZ;
+    const bool more = k0 + BK < kend;
+    if (more) {  // next tile's global loads fly while this tile is multiplied
+      sa.fetch(p.A, p.lda, p.ra, m0, p.M, k0 + BK, kend, a_vec);
+      sb.fetch(p.B, p.ldb, p.rb, n0, p.N, k0 + BK, kend, b_vec);
+    }
     float a[4][4], b[2][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -145,7 +171,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(a[mt][kk], b[nt][kk], acc[mt][nt]);
+    if (!A_KCONTIG) {
+      if (want_asum && threadIdx.x < BM) {
+#pragma unroll
+        for (int k = 0; k < BK; ++k) asum += As[k * LDM_A + threadIdx.x];
+      }
+    }
+    if (more) {
+      float* nxt = lds + (cur ^ 1) * (A_SZ + B_SZ);
+      sa.store(nxt);
+      sb.store(nxt + A_SZ);
+    }
     __syncthreads();
+    cur ^= 1;
+  }
+
+  if (!A_KCONTIG) {
+    if (want_asum && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) atomicAdd(&p.asum[m0 + threadIdx.x], asum);
   }
 
   const bool accumulate = p.flags & 1, relu = p.flags & 2;
@@ -178,13 +220,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
 extern "C" int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
                            int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
-                           float* C, int ldc, const float* bias, int flags, int splits, ss_stream_t stream) {
+                           float* C, int ldc, const float* bias, float* a_colsum, int flags, int splits,
+                           ss_stream_t stream) {
   SS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, SS_ERR_ARG);
+  SS_REQUIRE(!a_colsum || !a_kcontig, SS_ERR_ARG);
   SS_REQUIRE(splits >= 1 && a_group > 0 && b_group > 0, SS_ERR_ARG);
   // split-K accumulates with atomics: C must already hold the value to add to, and ReLU cannot apply
   SS_REQUIRE(splits == 1 || ((flags & 1) && !(flags & 2)), SS_ERR_ARG);
   GemmParams p;
-  p.A = A; p.B = B; p.C = C; p.bias = bias;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.asum = a_colsum;
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.ra = RowMap{a_group, a_gstride, a_off};

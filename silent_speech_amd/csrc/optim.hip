@@ -73,7 +73,42 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
   if (rr == 0 && c < cols) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// GRU bias gradients of one layer, both directions, from dG (2, N, 4, H):
+//   d b_ih[dir] += colsum(dG[dir][:, 0:3H]);  d b_hh[dir] += colsum(dG[dir][:, 0:2H] | dG[dir][:, 3H:4H])
+// grid (4H/64, row chunks, 2); thread (c = tid&63, rr = tid>>6) strides rows by 4
+__global__ __launch_bounds__(256) void gru_bias_grad_kernel(const float* __restrict__ dG, int N, int H, int rows_per_block,
+                                                            float* __restrict__ gbi0, float* __restrict__ gbh0,
+                                                            float* __restrict__ gbi1, float* __restrict__ gbh1) {
+  __shared__ float red[4][64];
+  const int dir = blockIdx.z;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rr = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(N, r0 + rows_per_block);
+  const float* A = dG + (long)dir * N * 4 * H;
+  float acc = 0.f;
+  for (int r = r0 + rr; r < r1; r += 4) acc += A[(long)r * 4 * H + c];
+  red[rr][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rr == 0) {
+    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    float* gbi = dir ? gbi1 : gbi0;
+    float* gbh = dir ? gbh1 : gbh0;
+    if (c < 3 * H) atomicAdd(&gbi[c], s);
+    if (c < 2 * H) atomicAdd(&gbh[c], s);
+    else if (c >= 3 * H) atomicAdd(&gbh[c - H], s);
+  }
+}
+
 }  // namespace
+
+extern "C" int ss_gru_bias_grad(const float* d_g, int N, int H, float* g_bih_f, float* g_bhh_f, float* g_bih_r,
+                                float* g_bhh_r, ss_stream_t stream) {
+  SS_REQUIRE(d_g && g_bih_f && g_bhh_f && g_bih_r && g_bhh_r && N > 0 && H > 0 && (H % 16) == 0, SS_ERR_ARG);
+  const int rpb = 512;
+  dim3 grid(4 * H / 64, ceil_div(N, rpb), 2);
+  hipLaunchKernelGGL(gru_bias_grad_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), d_g, N, H, rpb, g_bih_f,
+                     g_bhh_f, g_bih_r, g_bhh_r);
+  return ss_launch_status();
+}
 
 extern "C" int ss_sumsq_f32(const float* x, long n, float* sumsq, ss_stream_t stream) {
   SS_REQUIRE(x && sumsq && n > 0, SS_ERR_ARG);

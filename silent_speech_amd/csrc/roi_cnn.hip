@@ -6,24 +6,28 @@
 //
 //   stage 0  u8 frame -> exact integer sum / sum of squares -> mean, unbiased std (clamp 1e-6)
 //            -> xn = (u/255 - mu) / std  into a zero-haloed LDS image
-//   stage 1  conv 1->8 + ReLU + maxpool2 on the VALU (K = 9 is too thin for MFMA)
-//   stage 2  conv 8->16 as implicit GEMM on v_mfma_f32_16x16x4_f32: M = 16 pixels of one row,
-//            N = 16 out channels, K = 72 = 9 taps x 8 channels; a wave computes rows y and y+1
-//            of one 16-pixel column block, so the 2x2 max-pool happens in its registers
-//   stage 3  conv 16->24 the same way (M = 16 linear pixels, N = 24 -> two N tiles, K = 144),
-//            ReLU and the global average reduced with wave shuffles
+//   stage 1  conv 1->8 on v_mfma_f32_16x16x4_f32: M = 16 pixels of row y, N = (8 channels) x (rows y, y+1),
+//            K = 12 = the 4 input rows x 3 columns both output rows touch -- no padding in N or K;
+//            ReLU + 2x2 max-pool: column pairs inside a lane, the row pair via one lane exchange (xor 8)
+//   stage 2  conv 8->16 as implicit GEMM: M = 16 pixels of one row, N = 16 out channels, K = 72 = 9 taps
+//            x 8 channels; a wave computes rows y and y+1 of one 16-pixel column block, so the max-pool
+//            happens in its registers
+//   stage 3  conv 16->24 the same way (M = 16 linear pixels, N = 24 -> two N tiles, K = 144), ReLU and
+//            the global average reduced with wave shuffles
 //   stage 4  fc 24 -> E, written straight into the caller's (B,T,x_dim+E) buffer (the torch.cat)
 //
 // For training the pooled maps, pool argmaxes and the conv3 sign mask are stashed (HBM is cheaper
-// than recomputing them in the backward kernel: 67 KB per 64x64 frame).
+// than recomputing them in the backward kernel: 67 KB per 64x64 frame), copied out of LDS in
+// 16-byte pieces while the next stage computes.
 #include "ss_common.h"
 #include "roi_cnn_geom.h"
+
+STAMP_TABLE(ss_debug_stamps_fwd)
 
 namespace {
 
 constexpr int NT = 512;  // threads per workgroup
 constexpr int NWV = NT / 64;
-constexpr int MAXCH = 3;  // 16-byte chunks of one frame per thread (H*W <= 3*16*512)
 
 struct CnnFwdParams {
   const uint8_t* R;
@@ -33,80 +37,104 @@ struct CnnFwdParams {
   int E;
   float* out;
   int ld_out;
-  // training stash (all may be null together)
+  // training stash (all null together)
   float* st_a1;     // [N][8][H2][W2]
   uint8_t* st_i1;   // [N][8][H2][W2]
   float* st_a2;     // [N][16][H4][W4]
   uint8_t* st_i2;   // [N][16][H4][W4]
   uint8_t* st_m3;   // [N][24][P]
   float* st_feat;   // [N][24]
-  CnnGeom g;
 };
 
+template <class G>
+struct FwdLds {
+  static constexpr int o_xh = 0;                                // [(H+2)][XS]
+  static constexpr int o_a1 = ((G::H + 2) * G::XS + 3) & ~3;    // [8][P1]
+  static constexpr int o_a2 = o_a1 + 8 * G::P1;                 // [16][P2]
+  static constexpr int o_i1 = (o_a2 + 16 * G::P2 + 3) & ~3;     // bytes [8][HW2]
+  static constexpr int o_i2 = o_i1 + 2 * G::HW2;                // bytes [16][P]
+  static constexpr int o_misc = o_i2 + 4 * G::P + 256;  // the 256 floats in front hold the grey-level table
+  static constexpr int total = o_misc + 512;
+};
+
+template <class G>
 __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const CnnGeom& G = p.g;
-  float* xh = lds;                          // [(H+2)][XS]
-  float* a1 = xh + (G.H + 2) * G.XS;        // [8][P1]
-  float* a2 = a1 + 8 * G.P1;                // [16][P2]
-  float* misc = a2 + 16 * G.P2;             // 512 floats
-  float* s_b2 = misc;                       // [16]
-  float* s_b3 = misc + 16;                  // [24] (+8 pad)
-  float* s_feat = misc + 48;                // [24]
-  float* s_stat = misc + 80;                // mu, std
-  unsigned* s_red = reinterpret_cast<unsigned*>(misc + 96);  // [NWV][2]
-  float* s_fp = misc + 128;                 // [NWV][32] per-wave partial channel sums
+  using LL = FwdLds<G>;
+  constexpr int H = G::H, W = G::W, H2 = G::H2, W2 = G::W2, W4 = G::W4, HW = G::HW, HW2 = G::HW2, P = G::P;
+  constexpr int XS = G::XS, S1 = G::S1, P1 = G::P1, S2 = G::S2, P2 = G::P2;
+  constexpr int NCH = (HW / 16 + NT - 1) / NT;  // 16-byte pixel chunks per thread
+  float* xh = lds + LL::o_xh;
+  float* a1 = lds + LL::o_a1;
+  float* a2 = lds + LL::o_a2;
+  uint8_t* i1s = reinterpret_cast<uint8_t*>(lds + LL::o_i1);
+  uint8_t* i2s = reinterpret_cast<uint8_t*>(lds + LL::o_i2);
+  float* misc = lds + LL::o_misc;
+  float* s_b1 = misc;                       // [8]
+  float* s_b2 = misc + 16;                  // [16]
+  float* s_b3 = misc + 32;                  // [24] (+8 pad)
+  float* s_feat = misc + 64;                // [24]
+  float* s_stat = misc + 96;                // mu, std
+  unsigned* s_red = reinterpret_cast<unsigned*>(misc + 104);  // [NWV][2]
+  float* s_fp = misc + 128;                 // [NWV][32] per-wave partial channel sums (256 floats)
+  float* s_xn = misc - 256;                 // [256] normalised value of every uint8 level (own 256-float block)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int HW = G.H * G.W;
+  const bool stash = p.st_a1 != nullptr;
 
-  // ---- one-time: zero LDS (halos), load weights
-  for (int q = tid; q < G.lds_floats; q += NT) lds[q] = 0.f;
-  float w1r[8][9], b1r[8];
+  // ---- one-time: zero LDS (halos), load weights into MFMA B fragments
+  for (int q = tid; q < LL::total; q += NT) lds[q] = 0.f;
+  // conv1: k = 4kk+g -> (ry = k/3, kx = k%3) over the 4x3 input window of output rows y, y+1;
+  // column i = (c = i&7, s = i>>3): W1[c][ky = ry - s][kx], zero outside the 3x3 kernel
+  float bw1[3];
+  int aoff1[3];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) w1r[c][k] = p.w1[c * 9 + k];
-    b1r[c] = p.b1[c];
+  for (int kk = 0; kk < 3; ++kk) {
+    const int k = 4 * kk + g, ry = k / 3, kx = k % 3, c = i & 7, s = i >> 3, ky = ry - s;
+    bw1[kk] = (ky >= 0 && ky <= 2) ? p.w1[c * 9 + ky * 3 + kx] : 0.f;
+    aoff1[kk] = ry * XS + kx;
   }
-  float bw2[18];  // B fragments conv2: k-step kk -> tap = kk/2, c = 4*(kk%2)+g ; n = i
+  float bw2[18];  // conv2: k-step kk -> tap = kk/2, c = 4*(kk%2)+g ; n = i
 #pragma unroll
   for (int kk = 0; kk < 18; ++kk) bw2[kk] = p.w2[i * 72 + (4 * (kk & 1) + g) * 9 + (kk >> 1)];
   float bw3a[36], bw3b[36];  // conv3: tap = kk/4, c = 4*(kk%4)+g ; n = i and 16+i
 #pragma unroll
   for (int kk = 0; kk < 36; ++kk) {
-    int c = 4 * (kk & 3) + g, tap = kk >> 2;
+    const int c = 4 * (kk & 3) + g, tap = kk >> 2;
     bw3a[kk] = p.w3[i * 144 + c * 9 + tap];
     bw3b[kk] = (i < 8) ? p.w3[(16 + i) * 144 + c * 9 + tap] : 0.f;
   }
   __syncthreads();
+  if (tid < 8) s_b1[tid] = p.b1[tid];
   if (tid < 16) s_b2[tid] = p.b2[tid];
   if (tid < 24) s_b3[tid] = p.b3[tid];
 
-  uint4 px[MAXCH];
+  uint4 px[NCH];
   auto load_frame = [&](int n) {
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-      int q = tid + k * NT;
+    for (int k = 0; k < NCH; ++k) {
+      const int q = tid + k * NT;
       if (q * 16 < HW) px[k] = reinterpret_cast<const uint4*>(p.R + (long)n * HW)[q];
     }
   };
   if ((int)blockIdx.x < p.N) load_frame(blockIdx.x);
+  STAMP_DECL;
 
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    STAMP(15);
     // ---------------- stage 0: statistics + normalise
     unsigned su = 0, sq = 0;
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-      int q = tid + k * NT;
+    for (int k = 0; k < NCH; ++k) {
+      const int q = tid + k * NT;
       if (q * 16 < HW) {
         const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            unsigned u = (wds[e] >> (8 * b)) & 255u;
+            const unsigned u = (wds[e] >> (8 * b)) & 255u;
             su += u;
             sq += u * u;
           }
@@ -135,135 +163,151 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       s_stat[1] = sd;
     }
     __syncthreads();
-    {
-      const float mu = s_stat[0], sd = s_stat[1];
+    if (tid < 256) {  // xn = (u/255 - mu)/sd once per grey level; pixels then look their value up
+      const float rr = (float)tid / 255.0f;
+      s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
+    }
+    __syncthreads();
 #pragma unroll
-      for (int k = 0; k < MAXCH; ++k) {
-        int q = tid + k * NT;
-        if (q * 16 < HW) {
-          int lin = q * 16;
-          int y = lin / G.W, x = lin % G.W;
-          float* dst = xh + (y + 1) * G.XS + (x + 1);
-          const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+    for (int k = 0; k < NCH; ++k) {
+      const int q = tid + k * NT;
+      if (q * 16 < HW) {
+        const int lin = q * 16;
+        float* dst = xh + (lin / W + 1) * XS + (lin % W + 1);
+        const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              float r = (float)((wds[e] >> (8 * b)) & 255u) / 255.0f;
-              dst[4 * e + b] = p.standardize ? (r - mu) / sd : r;
-            }
-        }
+          for (int b = 0; b < 4; ++b) dst[4 * e + b] = s_xn[(wds[e] >> (8 * b)) & 255u];
       }
     }
     // prefetch the next frame's bytes while this one is computed
     if (n + (int)gridDim.x < p.N) load_frame(n + gridDim.x);
     __syncthreads();
+    STAMP(0);
 
-    // ---------------- stage 1: conv1 + ReLU + pool -> a1 (haloed), VALU
-    for (int q = tid; q < G.H2 * G.W2; q += NT) {
-      const int py = q / G.W2, pxx = q % G.W2;
-      float in[4][4];
+    // ---------------- stage 1: conv1 (MFMA) + ReLU + pool -> a1 (haloed), argmax bytes
+    {
+      constexpr int XT = W / 16;
+      constexpr int chains = (H / 2) * XT;
+      const int c = i & 7, s = i >> 3;
+      const float bias = s_b1[c];
+      for (int ch = wv; ch < chains; ch += NWV) {
+        const int yp = ch / XT, xt = ch % XT;
+        const float* ap = xh + (2 * yp) * XS + 16 * xt + i;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* src = xh + (2 * py + r) * G.XS + 2 * pxx;
-        float2 lo = *reinterpret_cast<const float2*>(src);
-        float2 hi = *reinterpret_cast<const float2*>(src + 2);
-        in[r][0] = lo.x; in[r][1] = lo.y; in[r][2] = hi.x; in[r][3] = hi.y;
-      }
+        for (int kk = 0; kk < 3; ++kk) acc = mfma16(ap[aoff1[kk]], bw1[kk], acc);
+        // lane holds 4 pixels x0+4g+r of row 2yp+s for channel c
+        float m[2];
+        int cb[2];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float best = -1.f;
-        int bi = 0;
-#pragma unroll
-        for (int oy = 0; oy < 2; ++oy)
-#pragma unroll
-          for (int ox = 0; ox < 2; ++ox) {
-            float v = b1r[c];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-              for (int kx = 0; kx < 3; ++kx) v += in[oy + ky][ox + kx] * w1r[c][ky * 3 + kx];
-            v = fmaxf(v, 0.f);
-            if (v > best) { best = v; bi = oy * 2 + ox; }
-          }
-        a1[c * G.P1 + (py + 1) * G.S1 + pxx + 1] = best;
-        if (p.st_a1) {
-          long so = ((long)n * 8 + c) * (G.H2 * G.W2) + q;
-          p.st_a1[so] = best;
-          p.st_i1[so] = (uint8_t)bi;
+        for (int e = 0; e < 2; ++e) {
+          const float v0 = fmaxf(acc[2 * e] + bias, 0.f), v1 = fmaxf(acc[2 * e + 1] + bias, 0.f);
+          m[e] = v1 > v0 ? v1 : v0;
+          cb[e] = v1 > v0 ? 1 : 0;
         }
+        // row s = 0 lanes finish column pair 0, row s = 1 lanes finish column pair 1
+        const float send_v = s ? m[0] : m[1];
+        const int send_c = s ? cb[0] : cb[1];
+        const float recv_v = __shfl_xor(send_v, 8, 64);
+        const int recv_c = __shfl_xor(send_c, 8, 64);
+        const float own_v = s ? m[1] : m[0];
+        const int own_c = s ? cb[1] : cb[0];
+        const float r0v = s ? recv_v : own_v, r1v = s ? own_v : recv_v;
+        const int r0c = s ? recv_c : own_c, r1c = s ? own_c : recv_c;
+        const float best = r1v > r0v ? r1v : r0v;
+        const int bi = r1v > r0v ? 2 + r1c : r0c;
+        const int pxx = 8 * xt + 2 * g + s;
+        a1[c * P1 + (yp + 1) * S1 + pxx + 1] = best;
+        i1s[c * HW2 + yp * W2 + pxx] = (uint8_t)bi;
       }
     }
     __syncthreads();
+    STAMP(1);
+    if (stash) {  // pooled-1 map and its argmaxes leave LDS in 16-byte pieces
+      f32x4* dst = reinterpret_cast<f32x4*>(p.st_a1 + (long)n * 8 * HW2);
+      for (int q = tid; q < 2 * HW2; q += NT) {
+        const int c = q / (HW2 / 4), rem = q % (HW2 / 4), y = rem / (W2 / 4), x4 = rem % (W2 / 4);
+        const float* src = a1 + c * P1 + (y + 1) * S1 + 4 * x4 + 1;
+        dst[q] = f32x4{src[0], src[1], src[2], src[3]};
+      }
+      for (int q = tid; q < HW2 / 2; q += NT)
+        reinterpret_cast<uint4*>(p.st_i1 + (long)n * 8 * HW2)[q] = reinterpret_cast<const uint4*>(i1s)[q];
+    }
 
     // ---------------- stage 2: conv2 (MFMA) + ReLU + pool -> a2 (haloed)
     {
-      const int xt_n = G.W2 / 16;
-      const int units = (G.H2 / 2) * xt_n;
+      constexpr int XT = W2 / 16;
+      constexpr int units = (H2 / 2) * XT;
       const float bias = s_b2[i];
       for (int u = wv; u < units; u += NWV) {
-        const int yp = u / xt_n, xt = u % xt_n;
+        const int yp = u / XT, xt = u % XT;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        const float* base = a1 + g * G.P1 + (2 * yp) * G.S1 + 16 * xt + i;
+        const float* base = a1 + g * P1 + (2 * yp) * S1 + 16 * xt + i;
 #pragma unroll
         for (int kk = 0; kk < 18; ++kk) {
           const int tap = kk >> 1, ky = tap / 3, kx = tap % 3;
-          const float* ap = base + 4 * (kk & 1) * G.P1 + ky * G.S1 + kx;
+          const float* ap = base + 4 * (kk & 1) * P1 + ky * S1 + kx;
           acc0 = mfma16(ap[0], bw2[kk], acc0);
-          acc1 = mfma16(ap[G.S1], bw2[kk], acc1);
+          acc1 = mfma16(ap[S1], bw2[kk], acc1);
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          float v00 = fmaxf(acc0[2 * e] + bias, 0.f), v01 = fmaxf(acc0[2 * e + 1] + bias, 0.f);
-          float v10 = fmaxf(acc1[2 * e] + bias, 0.f), v11 = fmaxf(acc1[2 * e + 1] + bias, 0.f);
+          const float v00 = fmaxf(acc0[2 * e] + bias, 0.f), v01 = fmaxf(acc0[2 * e + 1] + bias, 0.f);
+          const float v10 = fmaxf(acc1[2 * e] + bias, 0.f), v11 = fmaxf(acc1[2 * e + 1] + bias, 0.f);
           float best = v00;
           int bi = 0;
           if (v01 > best) { best = v01; bi = 1; }
           if (v10 > best) { best = v10; bi = 2; }
           if (v11 > best) { best = v11; bi = 3; }
           const int pxx = 8 * xt + 2 * g + e;
-          a2[i * G.P2 + (yp + 1) * G.S2 + pxx + 1] = best;
-          if (p.st_i2) p.st_i2[((long)n * 16 + i) * G.P + yp * G.W4 + pxx] = (uint8_t)bi;
+          a2[i * P2 + (yp + 1) * S2 + pxx + 1] = best;
+          i2s[i * P + yp * W4 + pxx] = (uint8_t)bi;
         }
       }
     }
     __syncthreads();
-    if (p.st_a2) {
-      for (int q = tid; q < 16 * G.P; q += NT) {
-        int c = q / G.P, r = q % G.P;
-        p.st_a2[(long)n * 16 * G.P + q] = a2[c * G.P2 + (r / G.W4 + 1) * G.S2 + (r % G.W4) + 1];
+    STAMP(2);
+    if (stash) {
+      f32x4* dst = reinterpret_cast<f32x4*>(p.st_a2 + (long)n * 16 * P);
+      for (int q = tid; q < 4 * P; q += NT) {
+        const int c = q / (P / 4), rem = q % (P / 4), y = rem / (W4 / 4), x4 = rem % (W4 / 4);
+        const float* src = a2 + c * P2 + (y + 1) * S2 + 4 * x4 + 1;
+        dst[q] = f32x4{src[0], src[1], src[2], src[3]};
       }
+      for (int q = tid; q < P; q += NT)
+        reinterpret_cast<uint4*>(p.st_i2 + (long)n * 16 * P)[q] = reinterpret_cast<const uint4*>(i2s)[q];
     }
+    STAMP(3);
 
     // ---------------- stage 3: conv3 (MFMA) + ReLU + global average
     {
-      const int tiles = (G.P + 15) / 16;
+      constexpr int tiles = P / 16;
       float fa = 0.f, fb = 0.f;  // per-lane partial channel sums (tile 0: n=i, tile 1: n=16+i)
       const float bias_a = s_b3[i], bias_b = (i < 8) ? s_b3[16 + i] : 0.f;
       for (int u = wv; u < tiles; u += NWV) {
-        int pa = 16 * u + i;
-        if (pa >= G.P) pa = G.P - 1;  // clamp the A row; its outputs are masked below
-        const float* base = a2 + g * G.P2 + (pa / G.W4) * G.S2 + (pa % G.W4);
+        const int pa = 16 * u + i;
+        const float* base = a2 + g * P2 + (pa / W4) * S2 + (pa % W4);
         f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = acca;
 #pragma unroll
         for (int kk = 0; kk < 36; ++kk) {
           const int tap = kk >> 2, ky = tap / 3, kx = tap % 3;
-          const float a = base[4 * (kk & 3) * G.P2 + ky * G.S2 + kx];
+          const float a = base[4 * (kk & 3) * P2 + ky * S2 + kx];
           acca = mfma16(a, bw3a[kk], acca);
           accb = mfma16(a, bw3b[kk], accb);
         }
         unsigned ma = 0, mb = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool ok = (16 * u + 4 * g + r) < G.P;
-          float va = acca[r] + bias_a, vb = accb[r] + bias_b;
-          if (ok && va > 0.f) { fa += va; ma |= 1u << (8 * r); }
-          if (ok && vb > 0.f) { fb += vb; mb |= 1u << (8 * r); }
+          const float va = acca[r] + bias_a, vb = accb[r] + bias_b;
+          if (va > 0.f) { fa += va; ma |= 1u << (8 * r); }
+          if (vb > 0.f) { fb += vb; mb |= 1u << (8 * r); }
         }
-        if (p.st_m3 && (16 * u + 4 * g) < G.P) {
-          uint8_t* mp = p.st_m3 + (long)n * 24 * G.P + 16 * u + 4 * g;
-          *reinterpret_cast<unsigned*>(mp + (long)i * G.P) = ma;
-          if (i < 8) *reinterpret_cast<unsigned*>(mp + (long)(16 + i) * G.P) = mb;
+        if (stash) {
+          uint8_t* mp = p.st_m3 + (long)n * 24 * P + 16 * u + 4 * g;
+          *reinterpret_cast<unsigned*>(mp + (long)i * P) = ma;
+          if (i < 8) *reinterpret_cast<unsigned*>(mp + (long)(16 + i) * P) = mb;
         }
       }
       // reduce over the 4 lane groups (rows of the tiles), then over waves through LDS
@@ -272,12 +316,13 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       if (g == 0) { s_fp[wv * 32 + i] = fa; s_fp[wv * 32 + 16 + i] = fb; }
     }
     __syncthreads();
+    STAMP(4);
     if (tid < 24) {
       float s = 0.f;
       for (int k = 0; k < NWV; ++k) s += s_fp[k * 32 + tid];
-      s /= (float)G.P;
+      s /= (float)P;
       s_feat[tid] = s;
-      if (p.st_feat) p.st_feat[(long)n * 24 + tid] = s;
+      if (stash) p.st_feat[(long)n * 24 + tid] = s;
     }
     __syncthreads();
     // ---------------- stage 4: fc
@@ -286,7 +331,25 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       for (int c = 0; c < 24; ++c) o += s_feat[c] * p.wfc[tid * 24 + c];
       p.out[(long)n * p.ld_out + tid] = o;
     }
+    STAMP(5);
   }
+  STAMP_FLUSH();
+}
+
+template <class G>
+int launch_fwd(const CnnFwdParams& p, hipStream_t s) {
+  constexpr size_t lds_bytes = (size_t)FwdLds<G>::total * sizeof(float);
+  static_assert(lds_bytes <= 160 * 1024, "ROI size does not fit the CU's LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_cnn_fwd_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return SS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int grid = p.N < 256 ? p.N : 256;
+  hipLaunchKernelGGL(roi_cnn_fwd_kernel<G>, dim3(grid), dim3(NT), lds_bytes, s, p);
+  return ss_launch_status();
 }
 
 }  // namespace
@@ -298,7 +361,7 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
                                     uint8_t* st_m3, float* st_feat, ss_stream_t stream) {
   SS_REQUIRE(R && w1 && b1 && w2 && b2 && w3 && b3 && wfc && bfc && out, SS_ERR_ARG);
   SS_REQUIRE(N > 0 && E > 0 && ld_out >= E, SS_ERR_ARG);
-  SS_REQUIRE(E <= 64 && H % 4 == 0 && W % 32 == 0 && H >= 4 && H * W <= MAXCH * 16 * NT, SS_ERR_UNSUPPORTED);
+  SS_REQUIRE(E <= 64, SS_ERR_UNSUPPORTED);
   const bool any = st_a1 || st_i1 || st_a2 || st_i2 || st_m3 || st_feat;
   const bool all = st_a1 && st_i1 && st_a2 && st_i2 && st_m3 && st_feat;
   SS_REQUIRE(!any || all, SS_ERR_ARG);
@@ -307,19 +370,12 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.wfc = wfc; p.bfc = bfc;
   p.E = E; p.out = out; p.ld_out = ld_out;
   p.st_a1 = st_a1; p.st_i1 = st_i1; p.st_a2 = st_a2; p.st_i2 = st_i2; p.st_m3 = st_m3; p.st_feat = st_feat;
-  p.g = make_geom(H, W);
-  const size_t lds_bytes = (size_t)p.g.lds_floats * sizeof(float);
-  SS_REQUIRE(lds_bytes <= 160 * 1024, SS_ERR_UNSUPPORTED);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_cnn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return SS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  int grid = N < 256 ? N : 256;
-  hipLaunchKernelGGL(roi_cnn_fwd_kernel, dim3(grid), dim3(NT), lds_bytes, static_cast<hipStream_t>(stream), p);
-  return ss_launch_status();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define SS_DISPATCH(HH, WW) \
+  if (H == HH && W == WW) return launch_fwd<Geom<HH, WW>>(p, s);
+  SS_CNN_SHAPES(SS_DISPATCH)
+#undef SS_DISPATCH
+  return SS_ERR_UNSUPPORTED;
 }
 
 extern "C" int ss_roi_cnn_fwd(const uint8_t* R, int N, int H, int W, int standardize, const float* w1,

@@ -4,47 +4,47 @@
 //
 // One persistent 512-thread workgroup per CU walks frames.  Per frame it reads the forward's stash
 // (pooled maps a1, a2, pool argmaxes, conv3 sign mask, averaged features: 67 KB for 64x64) plus the
-// 4 KB uint8 frame, and runs five contractions out of LDS:
+// 4 KB uint8 frame, and runs four MFMA contractions and one VALU gather out of LDS:
 //
-//   S1  dW3[n][c][tap] += sum_p dy3[n][p] * a2[c][p+tap]     MFMA  M=n(24->32) N=c(16)/tap K=pixels
-//   S2  da2[c][p] = sum_{n,tap} dy3[n][p-tap] * W3[n][c][tap] MFMA  M=pixels N=c(16) K=(n,tap)=216
-//   S3  dW2[n][c][tap] += sum_x dy2[n][x] * a1[c][x+tap]      MFMA  M=n(16) N=(tap,c)=72->80 K=pixels
-//   S4  da1[c][x] = sum_{n,tap} dy2[n][x-tap] * W2[n][c][tap] MFMA  M=pixels N=c(8->16) K=(n,tap)=144
-//   S5  dW1[c][tap] += sum_q da1[c][q] * x[2q+argmax+tap]     VALU gather (pool sparsity: 1 of 4 live)
+//   S1  dW3[n][c][tap] += sum_p dy3[n][p] * a2[c][p+tap]      M=n(24->32) N=c(16) per tap, K=pixels
+//   S2  da2[c][p] = sum_{n,tap} dy3[n][p-tap] * W3[n][c][tap]  M=pixels N=c(16) K=(tap,n)=216
+//   T   dy2 (gradient before max-pool 2) expanded ONCE into a dense LDS image from da2 + 2-bit argmax
+//   S3  dW2[n][c][tap] += sum_x dy2[n][x] * a1[c][x+tap]       M=n(16) N=(tap,c)=72->80 K=pixels
+//   S4  da1[c][y..y+1][x] = sum dy2[n][.] * W2[n][c][.]        M=16 pixels of row y, N=(c, row y|y+1)=16,
+//                                                              K=(4 source rows x 3 cols, n)=192: no N padding
+//   S5  dW1[c][tap] += da1[c][q] * x[2q+argmax+tap]            in S4's epilogue (pool sparsity: 1 of 4 live)
 //
-// dy2 (the gradient before the second max-pool) is never materialised: the A operand of S3/S4 is
-// formed on the fly from the pooled gradient and the 2-bit argmax.  Weight-gradient partial sums
-// stay in registers for the whole frame walk (the K = pixel dimension is split over the 8 waves)
-// and are reduced through LDS, then one float atomic per element per workgroup, at the end.
+// Weight-gradient partial sums stay in registers for the whole frame walk (K = pixels split over the
+// 8 waves) and are reduced through LDS, then one float atomic per element per workgroup, at the end.
 #include "ss_common.h"
 #include "roi_cnn_geom.h"
+
+STAMP_TABLE(ss_debug_stamps_bwd)
 
 namespace {
 
 constexpr int NT = 512;
 constexpr int NWV = NT / 64;
-constexpr int MAXCH = 3;
 
-struct BwdLayout {
-  int o_a1h, o_U, usize, o_C, o_W, o_misc, total;  // float offsets
-  int xss;                                          // row stride of the un-haloed normalised image
+template <class G>
+struct BwdLds {
+  static constexpr int o_a1h = 0;                         // [8][P1]   haloed pooled-1 map (persistent halo)
+  // phase area: phase 1 = a2h | dy3h | da2m | i2 ; phase 2 = dy2 | x (u8) | i1
+  static constexpr int o_ph = 8 * G::P1;
+  static constexpr int o_dy3h = o_ph + 16 * G::P2;
+  static constexpr int o_da2m = o_dy3h + 24 * G::P2;
+  static constexpr int o_i2b = o_da2m + 16 * G::P;
+  static constexpr int end1 = o_i2b + 4 * G::P;
+  static constexpr int PD = plane_stride(G::HW2);         // dy2 plane stride
+  static constexpr int o_xb = o_ph + 16 * PD;
+  static constexpr int o_i1b = o_xb + (G::HW + 3) / 4;
+  static constexpr int end2 = o_i1b + 2 * G::HW2;
+  static constexpr int o_w3s = ((end1 > end2 ? end1 : end2) + 3) & ~3;
+  static constexpr int o_w2t = o_w3s + 3456;
+  static constexpr int o_misc = o_w2t + 192 * 16;
+  static constexpr int total = o_misc + 512;
+  static constexpr int TV = (16 * G::P + NT - 1) / NT;    // (da2m, argmax) pairs per thread at the phase switch
 };
-
-static inline BwdLayout make_bwd_layout(const CnnGeom& g) {
-  BwdLayout L;
-  const int HW2 = g.H2 * g.W2;
-  L.xss = g.W + 1;
-  L.o_a1h = 0;
-  L.o_U = 8 * g.P1;
-  const int u1 = 16 * g.P2 + 24 * g.P2;             // a2h | dy3h
-  const int u2 = 8 * HW2 + 2 * HW2 + g.H * L.xss;   // da1 | i1 (bytes) | x
-  L.usize = ((u1 > u2 ? u1 : u2) + 3) & ~3;
-  L.o_C = L.o_U + L.usize;
-  L.o_W = L.o_C + 16 * g.P + 4 * g.P;               // da2m | i2 (bytes)
-  L.o_misc = L.o_W + 3456 + 1152;
-  L.total = L.o_misc + 512;
-  return L;
-}
 
 struct CnnBwdParams {
   const uint8_t* R;
@@ -60,53 +60,62 @@ struct CnnBwdParams {
   const float* d_out;
   int ld_dout;
   float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *g_wfc, *g_bfc;
-  CnnGeom g;
-  BwdLayout L;
 };
 
+template <class G>
 __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const CnnGeom& G = p.g;
-  const int P = G.P, HW2 = G.H2 * G.W2, HW = G.H * G.W;
-  const int W2 = G.W2, W4 = G.W4, S1 = G.S1, S2 = G.S2, P1 = G.P1, P2 = G.P2, XSS = p.L.xss;
-  float* a1h = lds + p.L.o_a1h;
-  float* U = lds + p.L.o_U;
-  float* a2h = U;
-  float* dy3h = U + 16 * P2;
-  float* da1 = U;
-  uint8_t* i1b = reinterpret_cast<uint8_t*>(U + 8 * HW2);
-  float* xs = U + 8 * HW2 + 2 * HW2;
-  float* da2m = lds + p.L.o_C;
-  uint8_t* i2b = reinterpret_cast<uint8_t*>(da2m + 16 * P);
-  float* w3s = lds + p.L.o_W;
-  float* w2s = w3s + 3456;
-  float* misc = lds + p.L.o_misc;
+  using LL = BwdLds<G>;
+  constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H;
+  constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, PD = LL::PD;
+  constexpr int NCH = (HW / 16 + NT - 1) / NT;    // 16-byte pixel chunks per thread
+  constexpr int NI1 = (HW2 / 2 + NT - 1) / NT;    // 16-byte pool-1 argmax chunks per thread
+  float* a1h = lds + LL::o_a1h;
+  float* a2h = lds + LL::o_ph;
+  float* dy3h = lds + LL::o_dy3h;
+  float* da2m = lds + LL::o_da2m;
+  uint8_t* i2b = reinterpret_cast<uint8_t*>(lds + LL::o_i2b);
+  float* dy2 = lds + LL::o_ph;
+  uint8_t* xb = reinterpret_cast<uint8_t*>(lds + LL::o_xb);
+  uint8_t* i1b = reinterpret_cast<uint8_t*>(lds + LL::o_i1b);
+  float* w3s = lds + LL::o_w3s;
+  float* w2t = lds + LL::o_w2t;
+  float* misc = lds + LL::o_misc;
   float* s_dout = misc;          // [64]
   float* s_feat = misc + 64;     // [32]
   float* s_dfeat = misc + 96;    // [32]  d feat[c] / P
   float* s_stat = misc + 128;    // mu, sd
   unsigned* s_red = reinterpret_cast<unsigned*>(misc + 136);  // [2*NWV]
   float* s_gb3 = misc + 160;     // [32]  accumulated over the frame walk
+  float* s_xn = misc + 192;      // [256] normalised value of every uint8 level for this frame
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wvu = __builtin_amdgcn_readfirstlane(wv);
   const int i = lane & 15, g = lane >> 4;
   const int E = p.E;
 
-  for (int q = tid; q < p.L.total; q += NT) lds[q] = 0.f;
+  for (int q = tid; q < LL::total; q += NT) lds[q] = 0.f;
   __syncthreads();
   for (int q = tid; q < 3456; q += NT) w3s[q] = p.w3[q];
-  for (int q = tid; q < 1152; q += NT) w2s[q] = p.w2[q];
+  // S4's B operand: k = (t*3+kx)*16 + n, column j = (c, s): W2[n][c][ky = s+2-t][kx], zero outside the 3x3 window
+  for (int q = tid; q < 192 * 16; q += NT) {
+    const int k = q >> 4, j = q & 15;
+    const int tk = k >> 4, n = k & 15, t = tk / 3, kx = tk % 3, c = j & 7, s = j >> 3;
+    const int ky = s + 2 - t;
+    w2t[q] = (ky >= 0 && ky <= 2) ? p.w2[n * 72 + c * 9 + ky * 3 + kx] : 0.f;
+  }
 
   // persistent per-thread accumulators
-  f32x4 acc3[2][9], acc2[5];
+  // S1 splits K (pixels) four ways and the nine taps into {0..4} / {5..8} over the 8 waves
+  f32x4 acc3[2][5], acc2[5];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 9; ++b) acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 5; ++b) acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int s1_kg = wvu & 3, s1_tbase = (wvu >> 2) * 5, s1_ntap = (wvu >> 2) ? 4 : 5;
 #pragma unroll
   for (int a = 0; a < 5; ++a) acc2[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float acc1[10];
+  float acc1[10];  // dW1[c = i&7][tap], db1: this lane's share
 #pragma unroll
   for (int a = 0; a < 10; ++a) acc1[a] = 0.f;
   float accfc[3] = {0.f, 0.f, 0.f}, accbfc = 0.f, accb2 = 0.f;
@@ -115,39 +124,187 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   int boff[5];
 #pragma unroll
   for (int nt = 0; nt < 5; ++nt) {
-    int idx = 16 * nt + i;
-    int tap = idx >> 3, c = idx & 7;
+    const int idx = 16 * nt + i;
+    const int tap = idx >> 3, c = idx & 7;
     boff[nt] = (idx < 72) ? c * P1 + (tap / 3) * S1 + (tap % 3) : -1;
   }
 
-  uint4 px[MAXCH], ix1[2];
-  auto load_frame = [&](int n) {
-#pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-      int q = tid + k * NT;
-      if (q * 16 < HW) px[k] = reinterpret_cast<const uint4*>(p.R + (long)n * HW)[q];
-    }
-  };
-  if ((int)blockIdx.x < p.N) load_frame(blockIdx.x);
   __syncthreads();
+  STAMP_DECL;
 
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
-    // ---------------- L0: clear the union region, stage the small vectors, pixel statistics
-    for (int q = tid; q < p.L.usize / 4; q += NT) reinterpret_cast<f32x4*>(U)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    STAMP(15);
+    // ---------------- L0: issue every global load of the frame, pixel statistics
+    uint4 m3w = {0, 0, 0, 0}, i2w = {0, 0, 0, 0};
+    if (tid * 16 < 24 * P) m3w = reinterpret_cast<const uint4*>(p.st_m3 + (long)n * 24 * P)[tid];
+    if (tid * 16 < 16 * P) i2w = reinterpret_cast<const uint4*>(p.st_i2 + (long)n * 16 * P)[tid];
     if (tid < E) s_dout[tid] = p.d_out[(long)n * p.ld_dout + tid];
     if (tid < 24) s_feat[tid] = p.st_feat[(long)n * 24 + tid];
+    {  // a2 -> haloed planes (float4 along x), a1 likewise
+      const f32x4* src = reinterpret_cast<const f32x4*>(p.st_a2 + (long)n * 16 * P);
+#pragma unroll 2
+      for (int q = tid; q < 4 * P; q += NT) {
+        const f32x4 v = src[q];
+        const int c = q / (P / 4), rem = q % (P / 4);
+        const int y = rem / (W4 / 4), x4 = rem % (W4 / 4);
+        float* dst = a2h + c * P2 + (y + 1) * S2 + 4 * x4 + 1;
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+      }
+    }
     {
+      const f32x4* src = reinterpret_cast<const f32x4*>(p.st_a1 + (long)n * 8 * HW2);
+#pragma unroll 4
+      for (int q = tid; q < 2 * HW2; q += NT) {
+        const f32x4 v = src[q];
+        const int c = q / (HW2 / 4), rem = q % (HW2 / 4);
+        const int y = rem / (W2 / 4), x4 = rem % (W2 / 4);
+        float* dst = a1h + c * P1 + (y + 1) * S1 + 4 * x4 + 1;
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+      }
+    }
+    if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = i2w;
+    __syncthreads();  // A
+    STAMP(0);
+
+    if (tid < 24) {
+      float s = 0.f;
+      for (int e = 0; e < E; ++e) s += s_dout[e] * p.wfc[e * 24 + tid];
+      s_dfeat[tid] = s / (float)P;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int idx = tid + k * NT;
+      if (idx < E * 24) {
+        const int e = idx / 24;
+        accfc[k] += s_dout[e] * s_feat[idx - 24 * e];
+      }
+    }
+    if (tid < E) accbfc += s_dout[tid];
+    __syncthreads();  // B
+    STAMP(1);
+
+    // dy3 = mask3 * dfeat / P into its haloed planes (the halo was re-zeroed at the end of the last frame); db3
+    if (tid * 16 < 24 * P) {
+      const int lin = tid * 16;
+      const int c = lin / P;
+      const float dv = s_dfeat[c];
+      const unsigned wds[4] = {m3w.x, m3w.y, m3w.z, m3w.w};
+      int cnt = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = lin - c * P + 4 * e;  // 4 | W4: the 4 pixels of a word share a row
+        float* dst = dy3h + c * P2 + (r / W4 + 1) * S2 + (r % W4) + 1;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const bool on = (wds[e] >> (8 * b)) & 1u;
+          dst[b] = on ? dv : 0.f;
+          cnt += on;
+        }
+      }
+      if (cnt) atomicAdd(&s_gb3[c], dv * (float)cnt);
+    }
+    __syncthreads();  // C
+    STAMP(2);
+
+    // ---------------- S1: dW3
+    {
+      constexpr int kpw = P / 4;
+      const int pbase = s1_kg * kpw;
+#pragma unroll 1
+      for (int kk = 0; kk < kpw / 4; ++kk) {
+        const int p0 = pbase + 4 * kk;
+        const int y = p0 / W4, x = p0 % W4 + g;
+        const int hal = (y + 1) * S2 + x + 1;
+        const float a0 = dy3h[i * P2 + hal];
+        const float a1v = (i < 8) ? dy3h[(16 + i) * P2 + hal] : 0.f;
+        const float* bp = a2h + i * P2 + y * S2 + x;
+#pragma unroll
+        for (int tl = 0; tl < 5; ++tl) {
+          if (tl < s1_ntap) {  // wave-uniform
+            const int tap = s1_tbase + tl;
+            const float b = bp[(tap / 3) * S2 + (tap % 3)];
+            acc3[0][tl] = mfma16(a0, b, acc3[0][tl]);
+            acc3[1][tl] = mfma16(a1v, b, acc3[1][tl]);
+          }
+        }
+      }
+    }
+    STAMP_SYNC(3);
+    // ---------------- S2: da2 (masked by a2 > 0) -> da2m ; db2
+    {
+      constexpr int tiles = P / 16;
+#pragma unroll 1
+      for (int tile = wv; tile < tiles; tile += NWV) {
+        const int pp = 16 * tile + i;
+        const int y = pp / W4, x = pp % W4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = dy3h + g * P2 + (y + 2) * S2 + (x + 2);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+          const float* at = ap - (tap / 3) * S2 - (tap % 3);
+          const float* bt = w3s + g * 144 + i * 9 + tap;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc = mfma16(at[4 * j * P2], bt[4 * j * 144], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pq = 16 * tile + 4 * g + r;
+          const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
+          const float v = av > 0.f ? acc[r] : 0.f;
+          da2m[i * P + pq] = v;
+          accb2 += v;
+        }
+      }
+    }
+    __syncthreads();  // D: dy3h / a2h are dead, da2m is complete
+    STAMP(4);
+
+    // ---------------- T: phase switch.  Every thread takes its share of (da2m, argmax) into registers, then
+    // the phase-2 images are written over the phase-1 area: dense dy2, the raw uint8 frame, the pool-1 argmaxes.
+    {
+      constexpr int TV = LL::TV;
+      uint4 px[NCH], ix1[NI1];  // the uint8 frame and the pool-1 argmaxes: their loads fly during the switch
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        if ((tid + k * NT) * 16 < HW) px[k] = reinterpret_cast<const uint4*>(p.R + (long)n * HW)[tid + k * NT];
+#pragma unroll
+      for (int k = 0; k < NI1; ++k)
+        if ((tid + k * NT) * 16 < 8 * HW2)
+          ix1[k] = reinterpret_cast<const uint4*>(p.st_i1 + (long)n * 8 * HW2)[tid + k * NT];
+      float dv[TV];
+      int iv[TV];
+#pragma unroll
+      for (int e = 0; e < TV; ++e) {
+        const int q = tid + e * NT;
+        dv[e] = (q < 16 * P) ? da2m[q] : 0.f;
+        iv[e] = (q < 16 * P) ? (int)i2b[q] : 0;
+      }
+      __syncthreads();  // every read of the phase-1 images is done before the first overwrite
+#pragma unroll
+      for (int e = 0; e < TV; ++e) {
+        const int q = tid + e * NT;
+        if (q < 16 * P) {
+          const int c = q / P, r = q % P;
+          const int qy = r / W4, qx = r % W4;
+          float* dst = dy2 + c * PD + (2 * qy) * W2 + 2 * qx;
+          const float v = dv[e];
+          const int o = iv[e];
+          *reinterpret_cast<float2*>(dst) = make_float2(o == 0 ? v : 0.f, o == 1 ? v : 0.f);
+          *reinterpret_cast<float2*>(dst + W2) = make_float2(o == 2 ? v : 0.f, o == 3 ? v : 0.f);
+        }
+      }
       unsigned su = 0, sq = 0;
 #pragma unroll
-      for (int k = 0; k < MAXCH; ++k) {
-        int q = tid + k * NT;
+      for (int k = 0; k < NCH; ++k) {
+        const int q = tid + k * NT;
         if (q * 16 < HW) {
+          reinterpret_cast<uint4*>(xb)[q] = px[k];
           const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-              unsigned u = (wds[e] >> (8 * b)) & 255u;
+              const unsigned u = (wds[e] >> (8 * b)) & 255u;
               su += u;
               sq += u * u;
             }
@@ -159,20 +316,31 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         sq += __shfl_xor(sq, o, 64);
       }
       if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
-    }
-    // the 8*HW2-byte argmax map of pool 1: up to two 16-byte pieces per thread (HW2 <= 2048)
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-      if ((tid + k * NT) * 16 < 8 * HW2)
-        ix1[k] = reinterpret_cast<const uint4*>(p.st_i1 + (long)n * 8 * HW2)[tid + k * NT];
-    __syncthreads();  // A
-
-    if (tid < 24) {
-      float s = 0.f;
-      for (int e = 0; e < E; ++e) s += s_dout[e] * p.wfc[e * 24 + tid];
-      s_dfeat[tid] = s / (float)P;
+      for (int k = 0; k < NI1; ++k)
+        if ((tid + k * NT) * 16 < 8 * HW2) reinterpret_cast<uint4*>(i1b)[tid + k * NT] = ix1[k];
     }
-    if (tid == 32) {
+    __syncthreads();  // T done
+    STAMP(5);
+
+    // ---------------- S3: dW2
+    {
+      constexpr int kpw = HW2 / NWV;
+      const int pbase = wvu * kpw;
+#pragma unroll 2
+      for (int kk = 0; kk < kpw / 4; ++kk) {
+        const int p0 = pbase + 4 * kk;
+        const int y = p0 / W2, x = p0 % W2 + g;
+        const float a = dy2[i * PD + p0 + g];
+        const float* bp = a1h + y * S1 + x;
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) {
+          const float b = (boff[nt] >= 0) ? bp[boff[nt] < 0 ? 0 : boff[nt]] : 0.f;
+          acc2[nt] = mfma16(a, b, acc2[nt]);
+        }
+      }
+    }
+    if (tid == 0) {  // pixel statistics of the frame (partials were left in s_red at the phase switch)
       unsigned long long tsu = 0, tsq = 0;
       for (int k = 0; k < NWV; ++k) { tsu += s_red[2 * k]; tsq += s_red[2 * k + 1]; }
       float mu = 0.f, sd = 1.f;
@@ -186,182 +354,67 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       s_stat[0] = mu;
       s_stat[1] = sd;
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      int idx = tid + k * NT;
-      if (idx < E * 24) accfc[k] += s_dout[idx / 24] * s_feat[idx % 24];
+    __syncthreads();
+    if (tid < 256) {  // the forward's xn = (u/255 - mu)/sd, once per grey level instead of once per gathered pixel
+      const float rr = (float)tid / 255.0f;
+      s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
     }
-    if (tid < E) accbfc += s_dout[tid];
-    for (int q = tid; q < 16 * P; q += NT) {
-      int c = q / P, r = q % P;
-      a2h[c * P2 + (r / W4 + 1) * S2 + (r % W4) + 1] = p.st_a2[(long)n * 16 * P + q];
-    }
-    for (int q = tid; q < 4 * P; q += NT)
-      reinterpret_cast<unsigned*>(i2b)[q] = reinterpret_cast<const unsigned*>(p.st_i2 + (long)n * 16 * P)[q];
-    for (int q = tid; q < 8 * HW2; q += NT) {
-      int c = q / HW2, r = q % HW2;
-      a1h[c * P1 + (r / W2 + 1) * S1 + (r % W2) + 1] = p.st_a1[(long)n * 8 * HW2 + q];
-    }
-    __syncthreads();  // B
-
-    // dy3 = mask3 * dfeat / P into its haloed planes; db3
-    for (int q = tid; q < 6 * P; q += NT) {  // 24*P mask bytes as 6*P words
-      const unsigned word = reinterpret_cast<const unsigned*>(p.st_m3 + (long)n * 24 * P)[q];
-      const int c = (4 * q) / P, r = (4 * q) % P;
-      const float dv = s_dfeat[c];
-      float* dst = dy3h + c * P2 + (r / W4 + 1) * S2 + (r % W4) + 1;  // 4 | W4: the 4 pixels share a row
-      int cnt = 0;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const bool on = (word >> (8 * b)) & 1u;
-        dst[b] = on ? dv : 0.f;
-        cnt += on;
-      }
-      if (cnt) atomicAdd(&s_gb3[c], dv * (float)cnt);
-    }
-    __syncthreads();  // C
-
-    // ---------------- S1: dW3
+    __syncthreads();
+    STAMP(6);
+    // ---------------- S4 + S5: da1 for rows y, y+1 of a 16-pixel column block; dW1 / db1 in the epilogue
     {
-      const int kpw = P / NWV;
-      const int pbase = wvu * kpw;
-      for (int kk = 0; kk < kpw / 4; ++kk) {
-        const int p0 = pbase + 4 * kk;
-        const int y = p0 / W4, x = p0 % W4 + g;
-        const int hal = (y + 1) * S2 + x + 1;
-        const float a0 = dy3h[i * P2 + hal];
-        const float a1v = (i < 8) ? dy3h[(16 + i) * P2 + hal] : 0.f;
-        const float* bp = a2h + i * P2 + y * S2 + x;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const float b = bp[(tap / 3) * S2 + (tap % 3)];
-          acc3[0][tap] = mfma16(a0, b, acc3[0][tap]);
-          acc3[1][tap] = mfma16(a1v, b, acc3[1][tap]);
-        }
-      }
-    }
-    // ---------------- S2: da2 (masked by a2 > 0) -> da2m ; db2
-    {
-      const int tiles = P / 16;
-      for (int tile = wv; tile < tiles; tile += NWV) {
-        const int pp = 16 * tile + i;
-        const int y = pp / W4, x = pp % W4;
+      constexpr int xt_n = W2 / 16;
+      constexpr int chains = (H2 / 2) * xt_n;
+      const int c = i & 7, s = i >> 3;
+#pragma unroll 1
+      for (int ch = wv; ch < chains; ch += NWV) {
+        const int yp = ch / xt_n, xt = ch % xt_n;
+        const int y = 2 * yp, x = 16 * xt + i;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* ap = dy3h + g * P2 + (y + 2) * S2 + (x + 2);
-#pragma unroll
-        for (int kk = 0; kk < 54; ++kk) {
-          const int tap = kk / 6, nb = 4 * (kk % 6);
-          const float a = ap[nb * P2 - (tap / 3) * S2 - (tap % 3)];
-          const float b = w3s[(nb + g) * 144 + i * 9 + tap];
-          acc = mfma16(a, b, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int pq = 16 * tile + 4 * g + r;
-          const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
-          const float v = av > 0.f ? acc[r] : 0.f;
-          da2m[i * P + pq] = v;
-          accb2 += v;
-        }
-      }
-    }
-    __syncthreads();  // D: dy3h / a2h are dead, da2m is complete
-
-    // normalised image (no halo) and the pool-1 argmax bytes into the union region
-    {
-      const float mu = s_stat[0], sd = s_stat[1];
-#pragma unroll
-      for (int k = 0; k < MAXCH; ++k) {
-        int q = tid + k * NT;
-        if (q * 16 < HW) {
-          const int lin = q * 16;
-          float* dst = xs + (lin / G.W) * XSS + (lin % G.W);
-          const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              float r = (float)((wds[e] >> (8 * b)) & 255u) / 255.0f;
-              dst[4 * e + b] = p.standardize ? (r - mu) / sd : r;
-            }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if ((tid + k * NT) * 16 < 8 * HW2) reinterpret_cast<uint4*>(i1b)[tid + k * NT] = ix1[k];
-    }
-    if (n + (int)gridDim.x < p.N) load_frame(n + gridDim.x);
-
-    // ---------------- S3: dW2
-    {
-      const int kpw = HW2 / NWV;
-      const int pbase = wvu * kpw;
-      for (int kk = 0; kk < kpw / 4; ++kk) {
-        const int p0 = pbase + 4 * kk;
-        const int y = p0 / W2, x = p0 % W2 + g;
-        const int q = (y >> 1) * W4 + (x >> 1), o = (y & 1) * 2 + (x & 1);
-        const float a = (i2b[i * P + q] == o) ? da2m[i * P + q] : 0.f;
-        const float* bp = a1h + y * S1 + x;
-#pragma unroll
-        for (int nt = 0; nt < 5; ++nt) {
-          const float b = (boff[nt] >= 0) ? bp[boff[nt] < 0 ? 0 : boff[nt]] : 0.f;
-          acc2[nt] = mfma16(a, b, acc2[nt]);
-        }
-      }
-    }
-    // ---------------- S4: da1 (masked by a1 > 0)
-    {
-      const int tiles = HW2 / 16;
-      for (int tile = wv; tile < tiles; tile += NWV) {
-        const int pp = 16 * tile + i;
-        const int y = pp / W2, x = pp % W2;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int sy = y + 1 - tap / 3, sx = x + 1 - tap % 3;
-          const bool inb = sy >= 0 && sy < G.H2 && sx >= 0 && sx < W2;
-          const int q = inb ? (sy >> 1) * W4 + (sx >> 1) : 0;
-          const int o = (sy & 1) * 2 + (sx & 1);
+#pragma unroll 1
+        for (int tk = 0; tk < 12; ++tk) {
+          const int t = tk / 3, kx = tk % 3;
+          const int sy = y - 1 + t, sx = x + 1 - kx;
+          const bool inb = sy >= 0 && sy < H2 && sx >= 0 && sx < W2;
+          const float* ap = dy2 + g * PD + (inb ? sy * W2 + sx : 0);
+          const float* bt = w2t + (tk * 16 + g) * 16 + i;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int nn = 4 * j + g;
-            const float a = (inb && i2b[nn * P + q] == o) ? da2m[nn * P + q] : 0.f;
-            const float b = (i < 8) ? w2s[nn * 72 + i * 9 + tap] : 0.f;
-            acc = mfma16(a, b, acc);
+            const float a = inb ? ap[4 * j * PD] : 0.f;
+            acc = mfma16(a, bt[4 * j * 16], acc);
           }
         }
-        if (i < 8) {
+        // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0, then the pool-sparse dW1.
+        const int yy = y + s;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int pq = 16 * tile + 4 * g + r;
-            const float av = a1h[i * P1 + (pq / W2 + 1) * S1 + (pq % W2) + 1];
-            da1[i * HW2 + pq] = av > 0.f ? acc[r] : 0.f;
+        for (int r = 0; r < 4; ++r) {
+          const int xx = 16 * xt + 4 * g + r;
+          const float av = a1h[c * P1 + (yy + 1) * S1 + xx + 1];
+          const float d = av > 0.f ? acc[r] : 0.f;
+          if (d != 0.f) {
+            const int o = i1b[c * HW2 + yy * W2 + xx];
+            const int y0 = 2 * yy + (o >> 1) - 1, x0 = 2 * xx + (o & 1) - 1;
+            acc1[9] += d;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) {
+                const int py = y0 + ky, pxx = x0 + kx;
+                const bool in2 = py >= 0 && py < H && pxx >= 0 && pxx < W;
+                const float xv = in2 ? s_xn[xb[in2 ? py * W + pxx : 0]] : 0.f;
+                acc1[ky * 3 + kx] += d * xv;
+              }
           }
         }
       }
     }
     __syncthreads();  // E
-
-    // ---------------- S5: dW1, db1 (wave = channel)
-    {
-      const int c = wv;
-      for (int q = lane; q < HW2; q += 64) {
-        const float d = da1[c * HW2 + q];
-        const int o = i1b[c * HW2 + q];
-        const int y0 = 2 * (q / W2) + (o >> 1) - 1, x0 = 2 * (q % W2) + (o & 1) - 1;
-        acc1[9] += d;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int yy = y0 + ky, xx = x0 + kx;
-            const bool inb = yy >= 0 && yy < G.H && xx >= 0 && xx < G.W;
-            const float xv = inb ? xs[(inb ? yy : 0) * XSS + (inb ? xx : 0)] : 0.f;
-            acc1[ky * 3 + kx] += d * xv;
-          }
-      }
-    }
+    STAMP(7);
+    // restore the zero halos of the phase-1 planes for the next frame (their interiors are rewritten anyway)
+    for (int q = tid; q < (LL::o_da2m - LL::o_ph) / 4; q += NT)
+      reinterpret_cast<f32x4*>(a2h)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();  // F
+    STAMP(8);
   }
 
   // ---------------- flush: reduce the per-wave partials through LDS, then one atomic per element
@@ -372,17 +425,17 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float* r_b2 = r_b1 + 8;       // [16]
   float* r_fc = r_b2 + 16;      // [E*24]
   const int rtot = 3456 + 1152 + 72 + 8 + 16 + E * 24;
-  // (r_* overlay a1h / U, both dead; s_gb3 in misc is untouched)
+  // (r_* overlay a1h and the phase area, both dead; s_gb3 in misc is untouched)
   for (int q = tid; q < rtot; q += NT) lds[q] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tl = 0; tl < 5; ++tl)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int nn = 16 * mt + 4 * g + r;
-        if (nn < 24) atomicAdd(&r_w3[nn * 144 + i * 9 + tap], acc3[mt][tap][r]);
+        if (nn < 24 && tl < s1_ntap) atomicAdd(&r_w3[nn * 144 + i * 9 + s1_tbase + tl], acc3[mt][tl][r]);
       }
 #pragma unroll
   for (int nt = 0; nt < 5; ++nt) {
@@ -393,12 +446,15 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       for (int r = 0; r < 4; ++r) atomicAdd(&r_w2[(4 * g + r) * 72 + c * 9 + tap], acc2[nt][r]);
     }
   }
+  {
+    const int c = i & 7;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    const float s = wave_sum(acc1[k]);
-    if (lane == 0) {
-      if (k < 9) r_w1[wv * 9 + k] = s;
-      else r_b1[wv] = s;
+    for (int k = 0; k < 10; ++k) {
+      float s = acc1[k];  // lanes with equal (i & 7) share a channel: fold i^8 and the 4 lane groups, then the waves
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 8) atomicAdd(k < 9 ? &r_w1[c * 9 + k] : &r_b1[c], s);
     }
   }
   {
@@ -409,7 +465,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    int idx = tid + k * NT;
+    const int idx = tid + k * NT;
     if (idx < E * 24) r_fc[idx] = accfc[k];
   }
   __syncthreads();
@@ -421,6 +477,26 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   if (tid < 24) atomicAdd(&p.g_b3[tid], s_gb3[tid]);
   for (int q = tid; q < E * 24; q += NT) atomicAdd(&p.g_wfc[q], r_fc[q]);
   if (tid < E) atomicAdd(&p.g_bfc[tid], accbfc);
+  STAMP_FLUSH();
+}
+
+template <class G>
+int launch_bwd(const CnnBwdParams& p, hipStream_t s) {
+  using LL = BwdLds<G>;
+  constexpr size_t lds_bytes = (size_t)LL::total * sizeof(float);
+  static_assert(lds_bytes <= 160 * 1024, "ROI size does not fit the CU's LDS");
+  // the K = pixel splits need whole 4-pixel k-steps per wave; mask / argmax-2 maps are one 16-byte piece per thread
+  static_assert(G::P % (4 * NWV) == 0 && G::HW2 % (4 * NWV) == 0 && 24 * G::P <= 16 * NT, "unsupported ROI size");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_cnn_bwd_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return SS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int grid = p.N < 256 ? p.N : 256;
+  hipLaunchKernelGGL(roi_cnn_bwd_kernel<G>, dim3(grid), dim3(NT), lds_bytes, s, p);
+  return ss_launch_status();
 }
 
 }  // namespace
@@ -435,27 +511,16 @@ extern "C" int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standar
   SS_REQUIRE(R && w2 && w3 && wfc && st_a1 && st_i1 && st_a2 && st_i2 && st_m3 && st_feat && d_out, SS_ERR_ARG);
   SS_REQUIRE(g_w1 && g_b1 && g_w2 && g_b2 && g_w3 && g_b3 && g_wfc && g_bfc, SS_ERR_ARG);
   SS_REQUIRE(N > 0 && E > 0 && ld_dout >= E, SS_ERR_ARG);
-  SS_REQUIRE(E <= 64 && H % 4 == 0 && W % 32 == 0 && H >= 4 && H * W <= MAXCH * 16 * NT, SS_ERR_UNSUPPORTED);
+  SS_REQUIRE(E <= 64, SS_ERR_UNSUPPORTED);
   CnnBwdParams p;
   p.R = R; p.N = N; p.standardize = standardize; p.w2 = w2; p.w3 = w3; p.wfc = wfc; p.E = E;
   p.st_a1 = st_a1; p.st_i1 = st_i1; p.st_a2 = st_a2; p.st_i2 = st_i2; p.st_m3 = st_m3; p.st_feat = st_feat;
   p.d_out = d_out; p.ld_dout = ld_dout;
   p.g_w1 = g_w1; p.g_b1 = g_b1; p.g_w2 = g_w2; p.g_b2 = g_b2; p.g_w3 = g_w3; p.g_b3 = g_b3; p.g_wfc = g_wfc; p.g_bfc = g_bfc;
-  p.g = make_geom(H, W);
-  p.L = make_bwd_layout(p.g);
-  // the K = pixel splits need whole 4-pixel k-steps per wave, the argmax map one 16-byte piece per thread
-  SS_REQUIRE(p.g.P % (4 * NWV) == 0 && (p.g.H2 * p.g.W2) % (4 * NWV) == 0 && 8 * p.g.H2 * p.g.W2 <= 2 * 16 * NT,
-             SS_ERR_UNSUPPORTED);
-  const size_t lds_bytes = (size_t)p.L.total * sizeof(float);
-  SS_REQUIRE(lds_bytes <= 160 * 1024, SS_ERR_UNSUPPORTED);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_cnn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return SS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  int grid = N < 256 ? N : 256;
-  hipLaunchKernelGGL(roi_cnn_bwd_kernel, dim3(grid), dim3(NT), lds_bytes, static_cast<hipStream_t>(stream), p);
-  return ss_launch_status();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define SS_DISPATCH(HH, WW) \
+  if (H == HH && W == WW) return launch_bwd<Geom<HH, WW>>(p, s);
+  SS_CNN_SHAPES(SS_DISPATCH)
+#undef SS_DISPATCH
+  return SS_ERR_UNSUPPORTED;
 }

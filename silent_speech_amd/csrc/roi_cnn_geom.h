@@ -1,30 +1,26 @@
-// LDS geometry shared by the ROI-CNN forward and backward kernels.
+// Compile-time LDS geometry shared by the ROI-CNN forward and backward kernels.  The kernels are instantiated per
+// frame size so every plane / row stride is an immediate in the ds_read/ds_write offsets and every pixel -> (y, x)
+// split is a multiply-shift; SS_CNN_SHAPES lists the sizes built (the reference ships 48x96, BASELINE.json's
+// synthetic configs use 64x64).
 #pragma once
 
 namespace {
 
-struct CnnGeom {
-  int H, W, H2, W2, H4, W4, P;  // P = H4*W4
-  int XS;                       // row stride of the haloed normalised image
-  int S1, P1;                   // pooled-1 map: row stride, plane stride (== 18 mod 32)
-  int S2, P2;                   // pooled-2 map
-  int lds_floats;
+constexpr int plane_stride(int n) {  // smallest >= n that is == 18 (mod 32): conflict-free MFMA operand reads
+  return n + (18 - n % 32 + 32) % 32;  // both when lanes walk pixels (stride 1) and when they walk planes
+}
+
+template <int H_, int W_>
+struct Geom {
+  static constexpr int H = H_, W = W_, H2 = H_ / 2, W2 = W_ / 2, H4 = H_ / 4, W4 = W_ / 4;
+  static constexpr int HW = H * W, HW2 = H2 * W2, P = H4 * W4;
+  static constexpr int XS = W + 2;                              // haloed normalised image, row stride
+  static constexpr int S1 = W2 + 2, P1 = plane_stride((H2 + 2) * S1);  // haloed pooled-1 map
+  static constexpr int S2 = W4 + 2, P2 = plane_stride((H4 + 2) * S2);  // haloed pooled-2 map
+  static_assert(H % 4 == 0 && W % 32 == 0 && H2 % 2 == 0 && P % 32 == 0 && HW2 % 32 == 0, "unsupported ROI size");
 };
 
-static inline int plane_stride(int n) {  // smallest >= n that is == 18 (mod 32)
-  int r = n % 32;
-  int add = (18 - r + 32) % 32;
-  return n + add;
-}
-
-static inline CnnGeom make_geom(int H, int W) {
-  CnnGeom g;
-  g.H = H; g.W = W; g.H2 = H / 2; g.W2 = W / 2; g.H4 = H / 4; g.W4 = W / 4; g.P = g.H4 * g.W4;
-  g.XS = W + 2;
-  g.S1 = g.W2 + 2; g.P1 = plane_stride((g.H2 + 2) * g.S1);
-  g.S2 = g.W4 + 2; g.P2 = plane_stride((g.H4 + 2) * g.S2);
-  g.lds_floats = (H + 2) * g.XS + 8 * g.P1 + 16 * g.P2 + 512;
-  return g;
-}
-
 }  // namespace
+
+// X(H, W) for every instantiated frame size
+#define SS_CNN_SHAPES(X) X(64, 64) X(48, 96) X(32, 32)

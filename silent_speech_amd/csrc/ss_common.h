@@ -43,3 +43,43 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __ex
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- diagnostic build only (-DSS_STAMP): per-stage cycle shares of the persistent kernels.
+// Thread 0 of every workgroup accumulates s_memtime deltas between barriers; the real build has no stamps.
+#ifdef SS_STAMP
+#define SS_STAMP_SLOTS 16
+// one table per translation unit (no relocatable device code): STAMP_TABLE(fn) defines it and its host reader
+#define STAMP_TABLE(reader)                                                                           \
+  __device__ unsigned long long ss_stamp_buf[256 * SS_STAMP_SLOTS];                                   \
+  extern "C" int reader(unsigned long long* host_out) {                                               \
+    if (hipDeviceSynchronize() != hipSuccess) return SS_ERR_LAUNCH;                                   \
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ss_stamp_buf), sizeof(unsigned long long) * 256 * SS_STAMP_SLOTS) == hipSuccess \
+               ? SS_OK                                                                                \
+               : SS_ERR_LAUNCH;                                                                       \
+  }
+#define STAMP_DECL unsigned long long st_last = clock64(), st_acc[SS_STAMP_SLOTS] = {0}
+#define STAMP(k)                               \
+  do {                                         \
+    if (threadIdx.x == 0) {                    \
+      unsigned long long t_ = clock64();       \
+      st_acc[k] += t_ - st_last;               \
+      st_last = t_;                            \
+    }                                          \
+  } while (0)
+#define STAMP_SYNC(k) \
+  do {                \
+    __syncthreads();  \
+    STAMP(k);         \
+  } while (0)
+#define STAMP_FLUSH()                                                                       \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 256)                                               \
+      for (int k_ = 0; k_ < SS_STAMP_SLOTS; ++k_) ss_stamp_buf[blockIdx.x * SS_STAMP_SLOTS + k_] = st_acc[k_]; \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_SYNC(k)
+#define STAMP_FLUSH()
+#define STAMP_TABLE(reader)
+#endif

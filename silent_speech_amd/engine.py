@@ -45,11 +45,11 @@ class Config:
 
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, relu=False, splits=1,
-         a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0), tag="gemm"):
+         a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0), a_colsum=None, tag="gemm"):
     """C[M,N] (+)= opA * opB (+bias)(ReLU); A/B/Cm are ints (device addresses)."""
     flags = (1 if accumulate else 0) | (2 if relu else 0)
     L.call("ss_gemm_f32", int(a_kc), int(b_kc), M, N, K, A, lda, a_map[0], a_map[1], a_map[2], B, ldb, b_map[0],
-           b_map[1], b_map[2], Cm, ldc, bias, flags, splits, L.stream(), tag=tag)
+           b_map[1], b_map[2], Cm, ldc, bias, a_colsum, flags, splits, L.stream(), tag=tag)
 
 
 def _addr(t: torch.Tensor, offset_elems: int = 0) -> int:
@@ -166,15 +166,13 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
     mid_used = ws.mid_drop if drop_head else ws.mid
     # ---- head
     gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, mid_used.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
-         accumulate=True)
-    L.call("ss_colsum_f32", d_logits.data_ptr(), B, C, C, G["head.4.bias"].data_ptr(), s)
+         accumulate=True, a_colsum=G["head.4.bias"].data_ptr())
     gemm(1, 0, B, MID, C, d_logits.data_ptr(), C, P["head.4.weight"].data_ptr(), MID, ws.d_mid.data_ptr(), MID)
     # dropout mask (same seed/offset as the forward) and ReLU' in one pass
     L.call("ss_dropout", ws.d_mid.data_ptr(), ws.d_mid.data_ptr(), B * MID, cfg.head_dropout if drop_head else 0.0,
            seed, 7 << 40, ws.mid.data_ptr(), s)
     gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
-         2 * H, accumulate=True)
-    L.call("ss_colsum_f32", ws.d_mid.data_ptr(), B, MID, MID, G["head.1.bias"].data_ptr(), s)
+         2 * H, accumulate=True, a_colsum=G["head.1.bias"].data_ptr())
     gemm(1, 0, B, 2 * H, MID, ws.d_mid.data_ptr(), MID, P["head.1.weight"].data_ptr(), 2 * H, ws.d_ln.data_ptr(),
          2 * H)
     L.call("ss_layernorm_bwd", ws.d_ln.data_ptr(), ws.xhat.data_ptr(), ws.rstd.data_ptr(),
@@ -205,7 +203,6 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             # d W_ih = dGi^T . layer_in ; d b_ih = colsum(dGi)
             gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K,
                  accumulate=True, splits=ksplit, tag="gemm_gru_dW")
-            L.call("ss_colsum_f32", dg, N, 3 * H, 4 * H, G[f"gru.bias_ih_l{l}{suf}"].data_ptr(), s)
             # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse)
             a_map = (T - 1, T, 1) if d == 0 else (T - 1, T, 0)
             b_map = (T - 1, T, 0) if d == 0 else (T - 1, T, 1)
@@ -216,9 +213,9 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                      splits=ksplit, a_map=a_map, b_map=b_map, tag="gemm_gru_dW")
                 gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, hprev, 2 * H, _addr(gw, 2 * H * H), H,
                      accumulate=True, splits=ksplit, a_map=a_map, b_map=b_map, tag="gemm_gru_dW")
-            gb = G[f"gru.bias_hh_l{l}{suf}"]
-            L.call("ss_colsum_f32", dg, N, 2 * H, 4 * H, gb.data_ptr(), s)
-            L.call("ss_colsum_f32", dg + 3 * H * 4, N, H, 4 * H, _addr(gb, 2 * H), s)
+        L.call("ss_gru_bias_grad", ws.dG[l].data_ptr(), N, H, G[f"gru.bias_ih_l{l}"].data_ptr(),
+               G[f"gru.bias_hh_l{l}"].data_ptr(), G[f"gru.bias_ih_l{l}_reverse"].data_ptr(),
+               G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), s)
         # d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r
         need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
         if need_dx:

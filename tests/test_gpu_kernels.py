@@ -80,7 +80,7 @@ def test_gemm_layouts(L, a_kc, b_kc, M, N, K, pad):
     a_d, b_d, bias_d = dev(a_buf), dev(b_buf), dev(bias)
     c_d = torch.full((M, ldc), 7.0, device="cuda")
     L.call("ss_gemm_f32", a_kc, b_kc, M, N, K, a_d.data_ptr(), lda, INT_MAX, 0, 0, b_d.data_ptr(), ldb, INT_MAX, 0, 0,
-           c_d.data_ptr(), ldc, bias_d.data_ptr(), 0, 1, L.stream())
+           c_d.data_ptr(), ldc, bias_d.data_ptr(), None, 0, 1, L.stream())
     sync()
     assert_close("gemm", c_d[:, :N], ref, atol=2e-5 * K ** 0.5, rtol=1e-5)
     if pad:
@@ -94,7 +94,7 @@ def test_gemm_accumulate_relu_splitk_rowmap(L):
     A, Bm, C0 = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
     a_d, b_d, c_d = dev(A), dev(Bm), dev(C0)
     L.call("ss_gemm_f32", 1, 1, M, N, K, a_d.data_ptr(), K, INT_MAX, 0, 0, b_d.data_ptr(), K, INT_MAX, 0, 0,
-           c_d.data_ptr(), N, None, 3, 1, L.stream())
+           c_d.data_ptr(), N, None, None, 3, 1, L.stream())
     sync()
     assert_close("acc+relu", c_d, F.relu(C0.double() + A.double() @ Bm.double().t()).float(), atol=2e-4)
     # split-K with atomics, [K][M] x [K][N] operands and the (b,t)->(b,t-1) row pairing
@@ -107,10 +107,13 @@ def test_gemm_accumulate_relu_splitk_rowmap(L):
             ref += torch.outer(dG[b * T + t].double(), Hh[b * T + t - 1].double())
     dg_d, h_d = dev(dG), dev(Hh)
     c_d = torch.zeros(Mm, Nn, device="cuda")
+    cs_d = torch.zeros(Mm, device="cuda")
     L.call("ss_gemm_f32", 0, 0, Mm, Nn, Bc * (T - 1), dg_d.data_ptr(), Mm, T - 1, T, 1, h_d.data_ptr(), Nn, T - 1, T, 0,
-           c_d.data_ptr(), Nn, None, 1, 3, L.stream())
+           c_d.data_ptr(), Nn, None, cs_d.data_ptr(), 1, 3, L.stream())
     sync()
     assert_close("splitk+rowmap", c_d, ref.float(), atol=3e-4)
+    cs_ref = dG.view(Bc, T, Mm)[:, 1:].double().sum((0, 1)).float()
+    assert_close("a_colsum", cs_d, cs_ref, atol=1e-4)
 
 
 # ------------------------------------------------------------------------------------- GRU
@@ -335,7 +338,9 @@ def _cnn_frames(N, H, W, seed):
     ramp = (torch.arange(W).view(1, 1, W) * 255 // (W - 1)).to(torch.int32)
     R = ((R.to(torch.int32) + ramp) // 2).to(torch.uint8)
     R[0] = 0
-    if N > 1:
+    # a constant non-zero frame normalises to exactly 0 here; torch's float mean of 1024 equal values is one ulp off and
+    # the 1e-6 clamp turns that ulp into 0.06, so that frame is only compared at the sizes where torch is exact too
+    if N > 1 and H * W != 1024:
         R[1] = 200
     if N > 2:
         R[2] = 17
@@ -343,7 +348,7 @@ def _cnn_frames(N, H, W, seed):
     return R
 
 
-@pytest.mark.parametrize("H,W", [(64, 64), (48, 96)])
+@pytest.mark.parametrize("H,W", [(64, 64), (48, 96), (32, 32)])
 @pytest.mark.parametrize("standardize", [1, 0])
 def test_roi_cnn_fwd(L, H, W, standardize):
     N = 300 if (H, W) == (64, 64) else 19  # 300 > 256 workgroups: exercises the persistent frame walk
@@ -360,7 +365,7 @@ def test_roi_cnn_fwd(L, H, W, standardize):
     assert torch.all(out[:, :8] == -3.0)
 
 
-@pytest.mark.parametrize("H,W", [(64, 64), (48, 96)])
+@pytest.mark.parametrize("H,W", [(64, 64), (48, 96), (32, 32)])
 def test_roi_cnn_stash_and_bwd(L, H, W):
     N = 270 if (H, W) == (64, 64) else 11
     sd = _cnn_sd(22)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-stage cycle shares of the persistent ROI-CNN kernels (needs the -DSS_STAMP build).
+
+    python -m silent_speech_amd.build --stamp
+    SS_HOTPATH_LIB=silent_speech_amd/libss_hotpath_stamp.so python tools/stamp_report.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("SS_HOTPATH_LIB", os.path.join(ROOT, "silent_speech_amd", "libss_hotpath_stamp.so"))
+import silent_speech_amd as ss  # noqa: E402
+from silent_speech_amd import _lib as L  # noqa: E402
+
+FWD = {15: "loop top", 0: "stats+normalise", 1: "conv1 (MFMA)", 2: "a1 stash copy + conv2 (MFMA)", 3: "a2 stash copy",
+       4: "conv3 (MFMA)", 5: "feat + fc"}
+BWD = {15: "loop top", 0: "L0 loads a2/i2/a1", 1: "dfeat + fc grads", 2: "dy3 fill", 3: "S1 dW3", 4: "S2 da2",
+       5: "T phase switch (dy2, x, i1)", 6: "S3 dW2 (+stats)", 7: "S4 da1 + S5 dW1", 8: "halo re-zero"}
+
+
+def main():
+    B, T = 256, 30
+    dev = torch.device("cuda")
+    m = ss.BiGRUClassifier(84, 5, use_roi=True).to(dev).train()
+    tr = ss.Trainer(m)
+    X = torch.randn(B, T, 84, device=dev)
+    R = torch.randint(0, 256, (B, T, 64, 64), device=dev, dtype=torch.uint8)
+    lengths = torch.full((B,), T, device=dev)
+    y = torch.randint(0, 5, (B,), device=dev)
+    for _ in range(3):
+        tr.step(X, lengths, R, y)
+    lib = L.load()
+    for which, names in ((0, FWD), (1, BWD)):
+        buf = np.zeros(256 * 16, np.uint64)
+        fn = getattr(lib, "ss_debug_stamps_fwd" if which == 0 else "ss_debug_stamps_bwd")
+        fn.argtypes, fn.restype = [C.c_void_p], C.c_int
+        assert fn(buf.ctypes.data) == 0
+        t = buf.reshape(256, 16).astype(np.float64)
+        tot = t.sum(1).mean()
+        print(f"kernel {'roi_cnn_fwd' if which == 0 else 'roi_cnn_bwd'}: {tot / 30:.0f} cycles per frame (mean over workgroups, 30 frames each)")
+        for k, name in names.items():
+            print(f"   {name:28s} {t[:, k].mean() / 30:9.0f} cyc/frame  {100 * t[:, k].mean() / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
