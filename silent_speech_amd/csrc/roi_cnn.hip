@@ -195,9 +195,13 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       for (int ch = wv; ch < chains; ch += NWV) {
         const int yp = ch / XT, xt = ch % XT;
         const float* ap = xh + (2 * yp) * XS + 16 * xt + i;
+        float av[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) av[kk] = ap[aoff1[kk]];
+        SS_SCHED_FENCE();
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) acc = mfma16(ap[aoff1[kk]], bw1[kk], acc);
+        for (int kk = 0; kk < 3; ++kk) acc = mfma16(av[kk], bw1[kk], acc);
         // lane holds 4 pixels x0+4g+r of row 2yp+s for channel c
         float m[2];
         int cb[2];
@@ -246,11 +250,22 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         const float* base = a1 + g * P1 + (2 * yp) * S1 + 16 * xt + i;
 #pragma unroll
-        for (int kk = 0; kk < 18; ++kk) {
-          const int tap = kk >> 1, ky = tap / 3, kx = tap % 3;
-          const float* ap = base + 4 * (kk & 1) * P1 + ky * S1 + kx;
-          acc0 = mfma16(ap[0], bw2[kk], acc0);
-          acc1 = mfma16(ap[S1], bw2[kk], acc1);
+        for (int kb = 0; kb < 18; kb += 6) {
+          float a0[6], a1v[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int kk = kb + u, tap = kk >> 1, ky = tap / 3, kx = tap % 3;
+            const float* ap = base + 4 * (kk & 1) * P1 + ky * S1 + kx;
+            a0[u] = ap[0];
+            a1v[u] = ap[S1];
+          }
+          SS_SCHED_FENCE();
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            acc0 = mfma16(a0[u], bw2[kb + u], acc0);
+            acc1 = mfma16(a1v[u], bw2[kb + u], acc1);
+          }
+          SS_SCHED_FENCE();
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -291,11 +306,20 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
         const float* base = a2 + g * P2 + (pa / W4) * S2 + (pa % W4);
         f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = acca;
 #pragma unroll
-        for (int kk = 0; kk < 36; ++kk) {
-          const int tap = kk >> 2, ky = tap / 3, kx = tap % 3;
-          const float a = base[4 * (kk & 3) * P2 + ky * S2 + kx];
-          acca = mfma16(a, bw3a[kk], acca);
-          accb = mfma16(a, bw3b[kk], accb);
+        for (int kb = 0; kb < 36; kb += 9) {
+          float av[9];
+#pragma unroll
+          for (int u = 0; u < 9; ++u) {
+            const int kk = kb + u, tap = kk >> 2, ky = tap / 3, kx = tap % 3;
+            av[u] = base[4 * (kk & 3) * P2 + ky * S2 + kx];
+          }
+          SS_SCHED_FENCE();
+#pragma unroll
+          for (int u = 0; u < 9; ++u) {
+            acca = mfma16(av[u], bw3a[kb + u], acca);
+            accb = mfma16(av[u], bw3b[kb + u], accb);
+          }
+          SS_SCHED_FENCE();
         }
         unsigned ma = 0, mb = 0;
 #pragma unroll

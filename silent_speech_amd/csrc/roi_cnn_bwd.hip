@@ -12,7 +12,9 @@
 //   S3  dW2[n][c][tap] += sum_x dy2[n][x] * a1[c][x+tap]       M=n(16) N=(tap,c)=72->80 K=pixels
 //   S4  da1[c][y..y+1][x] = sum dy2[n][.] * W2[n][c][.]        M=16 pixels of row y, N=(c, row y|y+1)=16,
 //                                                              K=(4 source rows x 3 cols, n)=192: no N padding
-//   S5  dW1[c][tap] += da1[c][q] * x[2q+argmax+tap]            in S4's epilogue (pool sparsity: 1 of 4 live)
+//   S5  dW1[c][tap] += da1[c][q] * x[2q+argmax+tap]            in S4's epilogue (pool sparsity: 1 of 4 live),
+//                                                              x = the normalised frame, rebuilt in LDS from a
+//                                                              256-entry grey-level table (no per-pixel divides)
 //
 // Weight-gradient partial sums stay in registers for the whole frame walk (K = pixels split over the
 // 8 waves) and are reduced through LDS, then one float atomic per element per workgroup, at the end.
@@ -29,18 +31,19 @@ constexpr int NWV = NT / 64;
 template <class G>
 struct BwdLds {
   static constexpr int o_a1h = 0;                         // [8][P1]   haloed pooled-1 map (persistent halo)
-  // phase area: phase 1 = a2h | dy3h | da2m | i2 ; phase 2 = dy2 | x (u8) | i1
+  // phase area.  phase 1: a2h | dy3h | da2m | i2 | w3 ;  phase 2: dy2 | xh (normalised frame, haloed) | i1
   static constexpr int o_ph = 8 * G::P1;
   static constexpr int o_dy3h = o_ph + 16 * G::P2;
   static constexpr int o_da2m = o_dy3h + 24 * G::P2;
   static constexpr int o_i2b = o_da2m + 16 * G::P;
-  static constexpr int end1 = o_i2b + 4 * G::P;
+  static constexpr int o_w3s = (o_i2b + 4 * G::P + 3) & ~3;
+  static constexpr int end1 = o_w3s + 3456;
   static constexpr int PD = plane_stride(G::HW2);         // dy2 plane stride
-  static constexpr int o_xb = o_ph + 16 * PD;
-  static constexpr int o_i1b = o_xb + (G::HW + 3) / 4;
+  static constexpr int o_xh = o_ph + 16 * PD;
+  static constexpr int XHN = (G::H + 2) * G::XS;
+  static constexpr int o_i1b = (o_xh + XHN + 3) & ~3;
   static constexpr int end2 = o_i1b + 2 * G::HW2;
-  static constexpr int o_w3s = ((end1 > end2 ? end1 : end2) + 3) & ~3;
-  static constexpr int o_w2t = o_w3s + 3456;
+  static constexpr int o_w2t = ((end1 > end2 ? end1 : end2) + 3) & ~3;
   static constexpr int o_misc = o_w2t + 192 * 16;
   static constexpr int total = o_misc + 512;
   static constexpr int TV = (16 * G::P + NT - 1) / NT;    // (da2m, argmax) pairs per thread at the phase switch
@@ -66,7 +69,7 @@ template <class G>
 __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = BwdLds<G>;
-  constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H;
+  constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H, XS = G::XS;
   constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, PD = LL::PD;
   constexpr int NCH = (HW / 16 + NT - 1) / NT;    // 16-byte pixel chunks per thread
   constexpr int NI1 = (HW2 / 2 + NT - 1) / NT;    // 16-byte pool-1 argmax chunks per thread
@@ -75,10 +78,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float* dy3h = lds + LL::o_dy3h;
   float* da2m = lds + LL::o_da2m;
   uint8_t* i2b = reinterpret_cast<uint8_t*>(lds + LL::o_i2b);
-  float* dy2 = lds + LL::o_ph;
-  uint8_t* xb = reinterpret_cast<uint8_t*>(lds + LL::o_xb);
-  uint8_t* i1b = reinterpret_cast<uint8_t*>(lds + LL::o_i1b);
   float* w3s = lds + LL::o_w3s;
+  float* dy2 = lds + LL::o_ph;
+  float* xh = lds + LL::o_xh;
+  uint8_t* i1b = reinterpret_cast<uint8_t*>(lds + LL::o_i1b);
   float* w2t = lds + LL::o_w2t;
   float* misc = lds + LL::o_misc;
   float* s_dout = misc;          // [64]
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   unsigned* s_red = reinterpret_cast<unsigned*>(misc + 136);  // [2*NWV]
   float* s_gb3 = misc + 160;     // [32]  accumulated over the frame walk
   float* s_xn = misc + 192;      // [256] normalised value of every uint8 level for this frame
+  float* s_wfc = da2m;           // [E*24] staged per frame; da2m itself is first written in S2
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wvu = __builtin_amdgcn_readfirstlane(wv);
@@ -96,7 +100,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
 
   for (int q = tid; q < LL::total; q += NT) lds[q] = 0.f;
   __syncthreads();
-  for (int q = tid; q < 3456; q += NT) w3s[q] = p.w3[q];
   // S4's B operand: k = (t*3+kx)*16 + n, column j = (c, s): W2[n][c][ky = s+2-t][kx], zero outside the 3x3 window
   for (int q = tid; q < 192 * 16; q += NT) {
     const int k = q >> 4, j = q & 15;
@@ -134,12 +137,18 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
 
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     STAMP(15);
-    // ---------------- L0: issue every global load of the frame, pixel statistics
-    uint4 m3w = {0, 0, 0, 0}, i2w = {0, 0, 0, 0};
+    // ---------------- L0: issue every global load of the frame; pixel statistics
+    uint4 px[NCH], m3w = {0, 0, 0, 0}, i2w = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+      if ((tid + k * NT) * 16 < HW) px[k] = reinterpret_cast<const uint4*>(p.R + (long)n * HW)[tid + k * NT];
     if (tid * 16 < 24 * P) m3w = reinterpret_cast<const uint4*>(p.st_m3 + (long)n * 24 * P)[tid];
     if (tid * 16 < 16 * P) i2w = reinterpret_cast<const uint4*>(p.st_i2 + (long)n * 16 * P)[tid];
     if (tid < E) s_dout[tid] = p.d_out[(long)n * p.ld_dout + tid];
     if (tid < 24) s_feat[tid] = p.st_feat[(long)n * 24 + tid];
+    for (int q = tid; q < E * 24; q += NT) s_wfc[q] = p.wfc[q];
+    for (int q = tid; q < 3456 / 4; q += NT)
+      reinterpret_cast<f32x4*>(w3s)[q] = reinterpret_cast<const f32x4*>(p.w3)[q];
     {  // a2 -> haloed planes (float4 along x), a1 likewise
       const f32x4* src = reinterpret_cast<const f32x4*>(p.st_a2 + (long)n * 16 * P);
 #pragma unroll 2
@@ -163,13 +172,50 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
     }
     if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = i2w;
+    {
+      unsigned su = 0, sq = 0;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        if ((tid + k * NT) * 16 < HW) {
+          const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const unsigned u = (wds[e] >> (8 * b)) & 255u;
+              su += u;
+              sq += u * u;
+            }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        su += __shfl_xor(su, o, 64);
+        sq += __shfl_xor(sq, o, 64);
+      }
+      if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
+    }
     __syncthreads();  // A
     STAMP(0);
 
     if (tid < 24) {
       float s = 0.f;
-      for (int e = 0; e < E; ++e) s += s_dout[e] * p.wfc[e * 24 + tid];
+      for (int e = 0; e < E; ++e) s += s_dout[e] * s_wfc[e * 24 + tid];
       s_dfeat[tid] = s / (float)P;
+    }
+    if (tid == 32) {
+      unsigned long long tsu = 0, tsq = 0;
+      for (int k = 0; k < NWV; ++k) { tsu += s_red[2 * k]; tsq += s_red[2 * k + 1]; }
+      float mu = 0.f, sd = 1.f;
+      if (p.standardize) {
+        const double nn = (double)HW;
+        mu = (float)((double)tsu / nn) / 255.0f;
+        double var = ((double)tsq - (double)tsu * (double)tsu / nn) / (nn - 1.0);
+        sd = (float)(sqrt(var > 0.0 ? var : 0.0) / 255.0);
+        sd = fmaxf(sd, 1e-6f);
+      }
+      s_stat[0] = mu;
+      s_stat[1] = sd;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -203,6 +249,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
       if (cnt) atomicAdd(&s_gb3[c], dv * (float)cnt);
     }
+    if (tid < 256) {  // the forward's xn = (u/255 - mu)/sd, once per grey level instead of once per pixel
+      const float rr = (float)tid / 255.0f;
+      s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
+    }
     __syncthreads();  // C
     STAMP(2);
 
@@ -218,55 +268,82 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         const float a0 = dy3h[i * P2 + hal];
         const float a1v = (i < 8) ? dy3h[(16 + i) * P2 + hal] : 0.f;
         const float* bp = a2h + i * P2 + y * S2 + x;
+        float b[5];
+#pragma unroll
+        for (int tl = 0; tl < 5; ++tl) {
+          const int tap = s1_tbase + (tl < s1_ntap ? tl : 0);
+          b[tl] = bp[(tap / 3) * S2 + (tap % 3)];
+        }
+        SS_SCHED_FENCE();
 #pragma unroll
         for (int tl = 0; tl < 5; ++tl) {
           if (tl < s1_ntap) {  // wave-uniform
-            const int tap = s1_tbase + tl;
-            const float b = bp[(tap / 3) * S2 + (tap % 3)];
-            acc3[0][tl] = mfma16(a0, b, acc3[0][tl]);
-            acc3[1][tl] = mfma16(a1v, b, acc3[1][tl]);
+            acc3[0][tl] = mfma16(a0, b[tl], acc3[0][tl]);
+            acc3[1][tl] = mfma16(a1v, b[tl], acc3[1][tl]);
           }
         }
+        SS_SCHED_FENCE();
       }
     }
     STAMP_SYNC(3);
-    // ---------------- S2: da2 (masked by a2 > 0) -> da2m ; db2
+    // ---------------- S2: da2 (masked by a2 > 0) -> da2m ; db2.  Two pixel tiles per pass share the W3 reads.
     {
       constexpr int tiles = P / 16;
 #pragma unroll 1
-      for (int tile = wv; tile < tiles; tile += NWV) {
-        const int pp = 16 * tile + i;
-        const int y = pp / W4, x = pp % W4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* ap = dy3h + g * P2 + (y + 2) * S2 + (x + 2);
+      for (int tile = wv; tile < tiles; tile += 2 * NWV) {
+        const int tile2 = tile + NWV;
+        const bool two = tile2 < tiles;
+        const int pp0 = 16 * tile + i, pp1 = 16 * (two ? tile2 : tile) + i;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0;
+        const float* ap0 = dy3h + g * P2 + (pp0 / W4 + 2) * S2 + (pp0 % W4 + 2);
+        const float* ap1 = dy3h + g * P2 + (pp1 / W4 + 2) * S2 + (pp1 % W4 + 2);
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-          const float* at = ap - (tap / 3) * S2 - (tap % 3);
+          const int back = (tap / 3) * S2 + (tap % 3);
           const float* bt = w3s + g * 144 + i * 9 + tap;
+          float b[6], a0[6], a1[6];
 #pragma unroll
-          for (int j = 0; j < 6; ++j) acc = mfma16(at[4 * j * P2], bt[4 * j * 144], acc);
+          for (int j = 0; j < 6; ++j) {
+            b[j] = bt[4 * j * 144];
+            a0[j] = ap0[4 * j * P2 - back];
+            a1[j] = ap1[4 * j * P2 - back];
+          }
+          SS_SCHED_FENCE();
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            acc0 = mfma16(a0[j], b[j], acc0);
+            acc1x = mfma16(a1[j], b[j], acc1x);
+          }
+          SS_SCHED_FENCE();
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pq = 16 * tile + 4 * g + r;
           const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
-          const float v = av > 0.f ? acc[r] : 0.f;
+          const float v = av > 0.f ? acc0[r] : 0.f;
           da2m[i * P + pq] = v;
           accb2 += v;
         }
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pq = 16 * tile2 + 4 * g + r;
+            const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
+            const float v = av > 0.f ? acc1x[r] : 0.f;
+            da2m[i * P + pq] = v;
+            accb2 += v;
+          }
+        }
       }
     }
-    __syncthreads();  // D: dy3h / a2h are dead, da2m is complete
+    __syncthreads();  // D: dy3h / a2h / w3 are dead, da2m is complete
     STAMP(4);
 
-    // ---------------- T: phase switch.  Every thread takes its share of (da2m, argmax) into registers, then
-    // the phase-2 images are written over the phase-1 area: dense dy2, the raw uint8 frame, the pool-1 argmaxes.
+    // ---------------- T: phase switch.  Every thread takes its share of (da2m, argmax) into registers, then the
+    // phase-2 images are written over the phase-1 area: dense dy2, the normalised frame (haloed), pool-1 argmaxes.
     {
       constexpr int TV = LL::TV;
-      uint4 px[NCH], ix1[NI1];  // the uint8 frame and the pool-1 argmaxes: their loads fly during the switch
-#pragma unroll
-      for (int k = 0; k < NCH; ++k)
-        if ((tid + k * NT) * 16 < HW) px[k] = reinterpret_cast<const uint4*>(p.R + (long)n * HW)[tid + k * NT];
+      uint4 ix1[NI1];
 #pragma unroll
       for (int k = 0; k < NI1; ++k)
         if ((tid + k * NT) * 16 < 8 * HW2)
@@ -293,29 +370,28 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           *reinterpret_cast<float2*>(dst + W2) = make_float2(o == 2 ? v : 0.f, o == 3 ? v : 0.f);
         }
       }
-      unsigned su = 0, sq = 0;
+      // normalised frame: interior by table lookup, halo cells zeroed (the area held phase-1 data)
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
         const int q = tid + k * NT;
         if (q * 16 < HW) {
-          reinterpret_cast<uint4*>(xb)[q] = px[k];
+          const int lin = q * 16;
+          float* dst = xh + (lin / W + 1) * XS + (lin % W + 1);
           const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const unsigned u = (wds[e] >> (8 * b)) & 255u;
-              su += u;
-              sq += u * u;
-            }
+            for (int b = 0; b < 4; ++b) dst[4 * e + b] = s_xn[(wds[e] >> (8 * b)) & 255u];
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        su += __shfl_xor(su, o, 64);
-        sq += __shfl_xor(sq, o, 64);
+      for (int q = tid; q < 2 * XS + 2 * H; q += NT) {
+        int cell;
+        if (q < XS) cell = q;                                   // top row
+        else if (q < 2 * XS) cell = (H + 1) * XS + (q - XS);    // bottom row
+        else if (q < 2 * XS + H) cell = (q - 2 * XS + 1) * XS;  // left column
+        else cell = (q - 2 * XS - H + 1) * XS + XS - 1;         // right column
+        xh[cell] = 0.f;
       }
-      if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
 #pragma unroll
       for (int k = 0; k < NI1; ++k)
         if ((tid + k * NT) * 16 < 8 * HW2) reinterpret_cast<uint4*>(i1b)[tid + k * NT] = ix1[k];
@@ -327,83 +403,84 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     {
       constexpr int kpw = HW2 / NWV;
       const int pbase = wvu * kpw;
-#pragma unroll 2
-      for (int kk = 0; kk < kpw / 4; ++kk) {
-        const int p0 = pbase + 4 * kk;
-        const int y = p0 / W2, x = p0 % W2 + g;
-        const float a = dy2[i * PD + p0 + g];
-        const float* bp = a1h + y * S1 + x;
+#pragma unroll 1
+      for (int kk = 0; kk < kpw / 4; kk += 2) {  // two k-steps per pass: 12 LDS reads in flight, then 10 MFMAs
+        float a[2], b[2][5];
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) {
-          const float b = (boff[nt] >= 0) ? bp[boff[nt] < 0 ? 0 : boff[nt]] : 0.f;
-          acc2[nt] = mfma16(a, b, acc2[nt]);
+        for (int u = 0; u < 2; ++u) {
+          const int p0 = pbase + 4 * (kk + u);
+          const int y = p0 / W2, x = p0 % W2 + g;
+          a[u] = dy2[i * PD + p0 + g];
+          const float* bp = a1h + y * S1 + x;
+#pragma unroll
+          for (int nt = 0; nt < 5; ++nt) b[u][nt] = bp[boff[nt] < 0 ? 0 : boff[nt]];
         }
+        SS_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int nt = 0; nt < 5; ++nt) acc2[nt] = mfma16(a[u], boff[nt] >= 0 ? b[u][nt] : 0.f, acc2[nt]);
+        SS_SCHED_FENCE();
       }
     }
-    if (tid == 0) {  // pixel statistics of the frame (partials were left in s_red at the phase switch)
-      unsigned long long tsu = 0, tsq = 0;
-      for (int k = 0; k < NWV; ++k) { tsu += s_red[2 * k]; tsq += s_red[2 * k + 1]; }
-      float mu = 0.f, sd = 1.f;
-      if (p.standardize) {
-        const double nn = (double)HW;
-        mu = (float)((double)tsu / nn) / 255.0f;
-        double var = ((double)tsq - (double)tsu * (double)tsu / nn) / (nn - 1.0);
-        sd = (float)(sqrt(var > 0.0 ? var : 0.0) / 255.0);
-        sd = fmaxf(sd, 1e-6f);
-      }
-      s_stat[0] = mu;
-      s_stat[1] = sd;
-    }
-    __syncthreads();
-    if (tid < 256) {  // the forward's xn = (u/255 - mu)/sd, once per grey level instead of once per gathered pixel
-      const float rr = (float)tid / 255.0f;
-      s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
-    }
-    __syncthreads();
-    STAMP(6);
-    // ---------------- S4 + S5: da1 for rows y, y+1 of a 16-pixel column block; dW1 / db1 in the epilogue
+    STAMP_SYNC(6);
+    // ---------------- S4 + S5: da1 for rows y, y+1 of a 16-pixel column block (two blocks per pass share the W2
+    // table reads); dW1 / db1 in the epilogue
     {
       constexpr int xt_n = W2 / 16;
       constexpr int chains = (H2 / 2) * xt_n;
       const int c = i & 7, s = i >> 3;
 #pragma unroll 1
-      for (int ch = wv; ch < chains; ch += NWV) {
-        const int yp = ch / xt_n, xt = ch % xt_n;
-        const int y = 2 * yp, x = 16 * xt + i;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ch = wv; ch < chains; ch += 2 * NWV) {
+        const int ch2 = ch + NWV;
+        const bool two = ch2 < chains;
+        const int chb = two ? ch2 : ch;
+        const int y0_ = 2 * (ch / xt_n), x0_ = 16 * (ch % xt_n) + i;
+        const int y1_ = 2 * (chb / xt_n), x1_ = 16 * (chb % xt_n) + i;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0;
 #pragma unroll 1
         for (int tk = 0; tk < 12; ++tk) {
           const int t = tk / 3, kx = tk % 3;
-          const int sy = y - 1 + t, sx = x + 1 - kx;
-          const bool inb = sy >= 0 && sy < H2 && sx >= 0 && sx < W2;
-          const float* ap = dy2 + g * PD + (inb ? sy * W2 + sx : 0);
+          const int sy0 = y0_ - 1 + t, sx0 = x0_ + 1 - kx, sy1 = y1_ - 1 + t, sx1 = x1_ + 1 - kx;
+          const bool in0 = sy0 >= 0 && sy0 < H2 && sx0 >= 0 && sx0 < W2;
+          const bool in1 = sy1 >= 0 && sy1 < H2 && sx1 >= 0 && sx1 < W2;
+          const float* ap0 = dy2 + g * PD + (in0 ? sy0 * W2 + sx0 : 0);
+          const float* ap1 = dy2 + g * PD + (in1 ? sy1 * W2 + sx1 : 0);
           const float* bt = w2t + (tk * 16 + g) * 16 + i;
+          float b[4], a0[4], a1[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float a = inb ? ap[4 * j * PD] : 0.f;
-            acc = mfma16(a, bt[4 * j * 16], acc);
+            b[j] = bt[4 * j * 16];
+            a0[j] = ap0[4 * j * PD];
+            a1[j] = ap1[4 * j * PD];
           }
-        }
-        // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0, then the pool-sparse dW1.
-        const int yy = y + s;
+          SS_SCHED_FENCE();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int xx = 16 * xt + 4 * g + r;
-          const float av = a1h[c * P1 + (yy + 1) * S1 + xx + 1];
-          const float d = av > 0.f ? acc[r] : 0.f;
-          if (d != 0.f) {
+          for (int j = 0; j < 4; ++j) {
+            acc0 = mfma16(in0 ? a0[j] : 0.f, b[j], acc0);
+            acc1x = mfma16(in1 ? a1[j] : 0.f, b[j], acc1x);
+          }
+          SS_SCHED_FENCE();
+        }
+        // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0, then the pool-sparse dW1:
+        // the gradient lands on the window's argmax position, whose 3x3 input patch is read from the haloed frame.
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if (half == 1 && !two) break;
+          const int yy = (half ? y1_ : y0_) + s;
+          const int xb0 = (half ? x1_ : x0_) - i + 4 * g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int xx = xb0 + r;
+            const float av = a1h[c * P1 + (yy + 1) * S1 + xx + 1];
+            const float d = av > 0.f ? (half ? acc1x[r] : acc0[r]) : 0.f;
             const int o = i1b[c * HW2 + yy * W2 + xx];
-            const int y0 = 2 * yy + (o >> 1) - 1, x0 = 2 * xx + (o & 1) - 1;
+            const float* xp = xh + (2 * yy + (o >> 1)) * XS + 2 * xx + (o & 1);
             acc1[9] += d;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-              for (int kx = 0; kx < 3; ++kx) {
-                const int py = y0 + ky, pxx = x0 + kx;
-                const bool in2 = py >= 0 && py < H && pxx >= 0 && pxx < W;
-                const float xv = in2 ? s_xn[xb[in2 ? py * W + pxx : 0]] : 0.f;
-                acc1[ky * 3 + kx] += d * xv;
-              }
+              for (int kx = 0; kx < 3; ++kx) acc1[ky * 3 + kx] += d * xp[ky * XS + kx];
           }
         }
       }

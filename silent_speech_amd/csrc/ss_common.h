@@ -26,6 +26,10 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Fence for the instruction scheduler: keeps a batch of ds_reads issued ahead of the MFMAs that consume them
+// (left alone, hipcc sinks every read next to its MFMA and waits lgkmcnt(0) in between: one LDS latency per MFMA).
+#define SS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
