@@ -163,11 +163,15 @@ def main():
     # ---- per-kernel launch durations over K more steps, HIP events on the launch stream
     kernels, roof = {}, None
     if not args.no_kernel_times:
+        from silent_speech_amd import engine
+
+        engine.USE_SIDE_STREAM = False  # one stream, so each event pair brackets exactly one kernel
         L.PROFILE = {}
         for _ in range(args.steps):
             trainer.step(X, lengths, R, y)
         torch.cuda.synchronize()
         prof, L.PROFILE = L.PROFILE, None
+        engine.USE_SIDE_STREAM = True
         for tag, evs in prof.items():
             ms = [a.elapsed_time(b) for a, b in evs]
             kernels[tag] = {"launches_per_step": len(ms) / args.steps, "avg_ms": sum(ms) / len(ms),

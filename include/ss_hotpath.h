@@ -106,6 +106,14 @@ int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* 
                 int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
                 float* C, int ldc, const float* bias, float* a_colsum, int flags, int splits, ss_stream_t stream);
 
+/* `batch` independent problems of identical shape in one launch (the two GRU directions): problem b uses
+ * A + b*stride_a, B + b*stride_b, C + b*stride_c, bias + b*stride_bias, a_colsum + b*stride_colsum (element strides). */
+int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
+                        int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
+                        float* C, int ldc, const float* bias, float* a_colsum, int flags, int splits, int batch,
+                        long stride_a, long stride_b, long stride_c, long stride_bias, long stride_colsum,
+                        ss_stream_t stream);
+
 /* column sums: out[n] += sum_r A[r*lda + n]  (bias gradients) */
 int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_stream_t stream);
 

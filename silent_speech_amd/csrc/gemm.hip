@@ -34,6 +34,8 @@ struct GemmParams {
   RowMap ra, rb;
   float* asum; // optional: asum[m] += sum_k A[k][m] (A stored [k][m]); the bias gradient rides on the dW GEMM
   int ksplit;  // K elements per blockIdx.z slice (multiple of BK)
+  int nz;      // K slices per problem; blockIdx.z = batch * nz + slice
+  long sA, sB, sC, sBias, sAsum;  // element strides between the problems of a batch
   int flags;   // bit0: accumulate into C (plain RMW when gridDim.z==1, atomics otherwise); bit1: ReLU
 };
 
@@ -106,7 +108,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_SZ + B_SZ)];
 
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * p.ksplit;
+  const int bi = blockIdx.z / p.nz, zs = blockIdx.z - bi * p.nz;
+  p.A += bi * p.sA; p.B += bi * p.sB; p.C += bi * p.sC;
+  if (p.bias) p.bias += bi * p.sBias;
+  if (p.asum) p.asum += bi * p.sAsum;
+  const int kbeg = zs * p.ksplit;
   const int kend = min(p.K, kbeg + p.ksplit);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -191,14 +197,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   }
 
   const bool accumulate = p.flags & 1, relu = p.flags & 2;
-  const bool atomic = gridDim.z > 1;
+  const bool atomic = p.nz > 1;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       int col = n0 + wn * 32 + nt * 16 + i;
       if (col >= p.N) continue;
-      float bv = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.f;
+      float bv = (p.bias && zs == 0) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = m0 + wm * 64 + mt * 16 + 4 * g + r;
@@ -218,11 +224,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
 }  // namespace
 
-extern "C" int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
-                           int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
-                           float* C, int ldc, const float* bias, float* a_colsum, int flags, int splits,
-                           ss_stream_t stream) {
-  SS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, SS_ERR_ARG);
+extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda,
+                                   int a_group, int a_gstride, int a_off, const float* B, int ldb, int b_group,
+                                   int b_gstride, int b_off, float* C, int ldc, const float* bias, float* a_colsum,
+                                   int flags, int splits, int batch, long stride_a, long stride_b, long stride_c,
+                                   long stride_bias, long stride_colsum, ss_stream_t stream) {
+  SS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && batch >= 1, SS_ERR_ARG);
   SS_REQUIRE(!a_colsum || !a_kcontig, SS_ERR_ARG);
   SS_REQUIRE(splits >= 1 && a_group > 0 && b_group > 0, SS_ERR_ARG);
   // split-K accumulates with atomics: C must already hold the value to add to, and ReLU cannot apply
@@ -235,13 +242,23 @@ extern "C" int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, co
   p.rb = RowMap{b_group, b_gstride, b_off};
   int per = ceil_div(ceil_div(K, splits), BK) * BK;
   p.ksplit = per;
-  int nz = ceil_div(K, per);
+  p.nz = ceil_div(K, per);
+  p.sA = stride_a; p.sB = stride_b; p.sC = stride_c; p.sBias = stride_bias; p.sAsum = stride_colsum;
   p.flags = flags;
-  dim3 grid(ceil_div(N, BN), ceil_div(M, BM), nz), block(256);
+  dim3 grid(ceil_div(N, BN), ceil_div(M, BM), p.nz * batch), block(256);
+  SS_REQUIRE(grid.z <= 65535, SS_ERR_UNSUPPORTED);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p);
   else if (a_kcontig && !b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
   else if (!a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
   return ss_launch_status();
+}
+
+extern "C" int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
+                           int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
+                           float* C, int ldc, const float* bias, float* a_colsum, int flags, int splits,
+                           ss_stream_t stream) {
+  return ss_gemm_f32_batched(a_kcontig, b_kcontig, M, N, K, A, lda, a_group, a_gstride, a_off, B, ldb, b_group,
+                             b_gstride, b_off, C, ldc, bias, a_colsum, flags, splits, 1, 0, 0, 0, 0, 0, stream);
 }

@@ -23,6 +23,9 @@ import torch
 from . import _lib as L
 
 INT_MAX = 2**31 - 1
+# bench.py turns this off for its per-kernel timing pass: HIP-event pairs only bracket a kernel's own run time when
+# every launch sits on one stream
+USE_SIDE_STREAM = True
 
 
 @dataclass
@@ -45,11 +48,23 @@ class Config:
 
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, relu=False, splits=1,
-         a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0), a_colsum=None, tag="gemm"):
-    """C[M,N] (+)= opA * opB (+bias)(ReLU); A/B/Cm are ints (device addresses)."""
+         a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0), a_colsum=None, tag="gemm", batch=1, strides=(0, 0, 0, 0, 0)):
+    """C[M,N] (+)= opA * opB (+bias)(ReLU); A/B/Cm are ints (device addresses).  ``batch`` problems of one shape
+    share a launch; ``strides`` = element strides of (A, B, C, bias, a_colsum) between them."""
     flags = (1 if accumulate else 0) | (2 if relu else 0)
-    L.call("ss_gemm_f32", int(a_kc), int(b_kc), M, N, K, A, lda, a_map[0], a_map[1], a_map[2], B, ldb, b_map[0],
-           b_map[1], b_map[2], Cm, ldc, bias, a_colsum, flags, splits, L.stream(), tag=tag)
+    L.call("ss_gemm_f32_batched", int(a_kc), int(b_kc), M, N, K, A, lda, a_map[0], a_map[1], a_map[2], B, ldb,
+           b_map[0], b_map[1], b_map[2], Cm, ldc, bias, a_colsum, flags, splits, batch, *strides, L.stream(), tag=tag)
+
+
+def split_k(M, N, K, batch=1, target_wgs=768):
+    """K slices for a weight-gradient GEMM (tiny M x N, huge K): enough workgroups to fill the chip ~3x over."""
+    tiles = -(-M // 128) * -(-N // 64) * batch
+    return max(1, min(K // 128, target_wgs // tiles))
+
+
+def _pstride(P, a: str, b: str) -> int:
+    """Element stride between two tensors of the flat parameter (or gradient) bucket."""
+    return (P[b].data_ptr() - P[a].data_ptr()) // 4
 
 
 def _addr(t: torch.Tensor, offset_elems: int = 0) -> int:
@@ -65,6 +80,10 @@ class Workspace:
         f32 = dict(device=device, dtype=torch.float32)
         u8 = dict(device=device, dtype=torch.uint8)
         self.lengths = torch.empty(B, device=device, dtype=torch.int32)
+        # weight-gradient GEMMs run on a side stream next to the (32-CU) recurrence of the layer below
+        self.side = torch.cuda.Stream(device=device) if train else None
+        self.ev_fork = torch.cuda.Event() if train else None
+        self.ev_join = torch.cuda.Event() if train else None
         self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
         self.gi = [torch.empty(2, N, 3 * H, **f32) for _ in range(cfg.gru_layers)]
         self.out = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers)]
@@ -123,9 +142,10 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
     # ---- GRU layers
     for l in range(cfg.gru_layers):
         K = cfg.in_dim if l == 0 else 2 * H
-        for d, suf in enumerate(("", "_reverse")):
-            gemm(1, 1, N, 3 * H, K, layer_in, ld_in, P[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K,
-                 _addr(ws.gi[l], d * N * 3 * H), 3 * H, bias=P[f"gru.bias_ih_l{l}{suf}"].data_ptr(), tag="gemm_gru_ih")
+        wf, wr = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
+        gemm(1, 1, N, 3 * H, K, layer_in, ld_in, P[wf].data_ptr(), K, ws.gi[l].data_ptr(), 3 * H,
+             bias=P[f"gru.bias_ih_l{l}"].data_ptr(), tag="gemm_gru_ih", batch=2,
+             strides=(0, _pstride(P, wf, wr), N * 3 * H, _pstride(P, f"gru.bias_ih_l{l}", f"gru.bias_ih_l{l}_reverse"), 0))
         L.call("ss_gru_fwd", ws.gi[l].data_ptr(), P[f"gru.weight_hh_l{l}"].data_ptr(),
                P[f"gru.weight_hh_l{l}_reverse"].data_ptr(), P[f"gru.bias_hh_l{l}"].data_ptr(),
                P[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.lengths.data_ptr(), B, T, H, ws.out[l].data_ptr(),
@@ -184,7 +204,6 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
            ws.attn.data_ptr(), ws.d_pooled.data_ptr(), B, T, 2 * H, ws.d_out.data_ptr(),
            G["pool.score.weight"].data_ptr(), G["pool.score.bias"].data_ptr(), s)
     # ---- GRU layers, top down
-    ksplit = max(1, min(16, N // 512))
     for l in range(cfg.gru_layers - 1, -1, -1):
         K = cfg.in_dim if l == 0 else 2 * H
         L.call("ss_gru_bwd", ws.d_out.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(),
@@ -198,24 +217,34 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         else:
             use_drop = train and cfg.gru_dropout > 0.0
             lin, ld_in = (ws.out_drop[l - 1] if use_drop else ws.out[l - 1]).data_ptr(), 2 * H
-        for d, suf in enumerate(("", "_reverse")):
-            dg = _addr(ws.dG[l], d * N * 4 * H)
-            # d W_ih = dGi^T . layer_in ; d b_ih = colsum(dGi)
-            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K,
-                 accumulate=True, splits=ksplit, tag="gemm_gru_dW")
-            # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse)
-            a_map = (T - 1, T, 1) if d == 0 else (T - 1, T, 0)
-            b_map = (T - 1, T, 0) if d == 0 else (T - 1, T, 1)
-            hprev = _addr(ws.out[l], d * H)
-            gw = G[f"gru.weight_hh_l{l}{suf}"]
+        # fork: everything that only feeds the parameter gradients of this layer goes to the side stream
+        side = ws.side if USE_SIDE_STREAM else torch.cuda.current_stream()
+        ws.ev_fork.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ws.ev_fork)
+            dg = ws.dG[l].data_ptr()
+            wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
+            wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
+            # d W_ih = dGi^T . layer_in, both directions in one launch
+            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True,
+                 splits=split_k(3 * H, K, N, 2), tag="gemm_gru_dW", batch=2,
+                 strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0, 0))
+            # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse).
+            # With the row remap (group T-1 of stride T, A offset 1, B offset 0) the reverse direction is the same
+            # pairing seen from one row earlier in dG and one row later in out, i.e. two pointer shifts.
             if T > 1:
-                gemm(0, 0, 2 * H, H, B * (T - 1), dg, 4 * H, hprev, 2 * H, gw.data_ptr(), H, accumulate=True,
-                     splits=ksplit, a_map=a_map, b_map=b_map, tag="gemm_gru_dW")
-                gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, hprev, 2 * H, _addr(gw, 2 * H * H), H,
-                     accumulate=True, splits=ksplit, a_map=a_map, b_map=b_map, tag="gemm_gru_dW")
-        L.call("ss_gru_bias_grad", ws.dG[l].data_ptr(), N, H, G[f"gru.bias_ih_l{l}"].data_ptr(),
-               G[f"gru.bias_hh_l{l}"].data_ptr(), G[f"gru.bias_ih_l{l}_reverse"].data_ptr(),
-               G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), s)
+                maps = dict(a_map=(T - 1, T, 1), b_map=(T - 1, T, 0))
+                st = (N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr), 0, 0)
+                gw = G[wh]
+                gemm(0, 0, 2 * H, H, B * (T - 1), dg, 4 * H, ws.out[l].data_ptr(), 2 * H, gw.data_ptr(), H,
+                     accumulate=True, splits=split_k(2 * H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2, strides=st,
+                     **maps)
+                gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, ws.out[l].data_ptr(), 2 * H, _addr(gw, 2 * H * H), H,
+                     accumulate=True, splits=split_k(H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2, strides=st,
+                     **maps)
+            L.call("ss_gru_bias_grad", ws.dG[l].data_ptr(), N, H, G[f"gru.bias_ih_l{l}"].data_ptr(),
+                   G[f"gru.bias_hh_l{l}"].data_ptr(), G[f"gru.bias_ih_l{l}_reverse"].data_ptr(),
+                   G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.stream())
         # d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r
         need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
         if need_dx:
@@ -241,3 +270,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                cfg.roi_emb, ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
                ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
                *[G[k].data_ptr() for k in names], s)
+    # join the side stream: the caller's next kernels (all-reduce, clip, Adam) read every gradient
+    if USE_SIDE_STREAM:
+        ws.ev_join.record(ws.side)
+        torch.cuda.current_stream().wait_event(ws.ev_join)
