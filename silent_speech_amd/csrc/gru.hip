@@ -95,21 +95,32 @@ __global__ __launch_bounds__(H * 4) void gru_fwd_kernel(GruFwdParams p) {
     f32x4 az = *reinterpret_cast<const f32x4*>(&bias[H + j0]);
     f32x4 an = *reinterpret_cast<const f32x4*>(&bias[2 * H + j0]);
     const float* hb = hbuf + cur * H * SLICE;
+    // 4 k-steps per batch: their h values (and, past KREG_F, their LDS-resident weight fragments) are read
+    // together, then the 12 MFMAs run while the other two waves of the SIMD cover the LDS latency
 #pragma unroll
-    for (int kk = 0; kk < C::KS; ++kk) {
-      float b = hb[(4 * kk + g) * SLICE + i];
-      float w0, w1, w2;
-      if (kk < C::KREG_F) {
-        w0 = wf[0][kk]; w1 = wf[1][kk]; w2 = wf[2][kk];
-      } else {
-        const float* wl = wlds + ((kk - C::KREG_F) * C::NW + w) * 64 + lane;
-        w0 = wl[0];
-        w1 = wl[C::KLDS_F * C::NW * 64];
-        w2 = wl[2 * C::KLDS_F * C::NW * 64];
+    for (int kb = 0; kb < C::KS; kb += 4) {
+      float b[4], w0[4], w1[4], w2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = kb + u;
+        b[u] = hb[(4 * kk + g) * SLICE + i];
+        if (kk < C::KREG_F) {
+          w0[u] = wf[0][kk]; w1[u] = wf[1][kk]; w2[u] = wf[2][kk];
+        } else {
+          const float* wl = wlds + ((kk - C::KREG_F) * C::NW + w) * 64 + lane;
+          w0[u] = wl[0];
+          w1[u] = wl[C::KLDS_F * C::NW * 64];
+          w2[u] = wl[2 * C::KLDS_F * C::NW * 64];
+        }
       }
-      ar = mfma16(w0, b, ar);
-      az = mfma16(w1, b, az);
-      an = mfma16(w2, b, an);
+      SS_SCHED_FENCE();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ar = mfma16(w0[u], b[u], ar);
+        az = mfma16(w1[u], b[u], az);
+        an = mfma16(w2[u], b[u], an);
+      }
+      SS_SCHED_FENCE();
     }
     f32x4 r, z, n, hn;
 #pragma unroll
@@ -228,12 +239,22 @@ __global__ __launch_bounds__(H * 4) void gru_bwd_kernel(GruBwdParams p) {
     __syncthreads();
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
-    for (int ks = 0; ks < C::KS_B; ++ks) {
-      float a = (ks < C::KREG_B) ? wf[ks < C::KREG_B ? ks : 0] : wlds[((ks - C::KREG_B) * C::NW + w) * 64 + lane];
-      float b = db[(4 * ks + g) * SLICE + i];
-      if (ks % 3 == 0) a0 = mfma16(a, b, a0);
-      else if (ks % 3 == 1) a1 = mfma16(a, b, a1);
-      else a2 = mfma16(a, b, a2);
+    for (int kb = 0; kb < C::KS_B; kb += 6) {  // 6 k-steps per batch: reads first, then the MFMAs
+      float a[6], b[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int ks = kb + u;
+        a[u] = (ks < C::KREG_B) ? wf[ks < C::KREG_B ? ks : 0] : wlds[((ks - C::KREG_B) * C::NW + w) * 64 + lane];
+        b[u] = db[(4 * ks + g) * SLICE + i];
+      }
+      SS_SCHED_FENCE();
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        if (u % 3 == 0) a0 = mfma16(a[u], b[u], a0);
+        else if (u % 3 == 1) a1 = mfma16(a[u], b[u], a1);
+        else a2 = mfma16(a[u], b[u], a2);
+      }
+      SS_SCHED_FENCE();
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) dh[e] = dcarry[e] + (a0[e] + a1[e]) + a2[e];
