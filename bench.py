@@ -44,6 +44,20 @@ def algorithmic_gflop(tag, B, T, D, E, H, C, roi):
     }.get(tag)
 
 
+def pmc_traffic(kernel_tag):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (profiles/round1_pmc_traffic.json,
+    made by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
+    path = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
+    stem = {"ss_roi_cnn_bwd": "roi_cnn_bwd_kernel", "ss_roi_cnn_fwd_stash": "roi_cnn_fwd_kernel", "ss_gru_fwd": "gru_fwd_kernel",
+            "ss_gru_bwd": "gru_bwd_kernel"}.get(kernel_tag)
+    if not stem or not os.path.exists(path):
+        return None
+    for name, d in json.load(open(path))["kernels"].items():
+        if stem in name:
+            return int(d["hbm_bytes_per_launch"])
+    return None
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box gives one
     GPU's share of a large host; os.cpu_count() would oversubscribe it many times over)."""
@@ -181,7 +195,8 @@ def main():
         if gf is not None:
             achieved = gf / kernels[dom]["avg_ms"]  # GFLOP / ms = TFLOP/s
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": pmc_traffic(dom) if (B, T, roi) == (256, 30, 64) else None,
                     "algorithmic_gflop_per_launch": round(gf, 3), "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
 
     out = {
