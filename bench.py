@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
+    ap.add_argument("--micro-batches", type=int, default=1, help="slices of the per-GPU batch kept in flight on separate streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,7 +153,7 @@ def main():
     model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).train()
     if world > 1:
         dist.broadcast(model.flat_params, src=0)
-    trainer = ss.Trainer(model, world_size=world)
+    trainer = ss.Trainer(model, world_size=world, micro_batches=args.micro_batches)
 
     def barrier():
         if world > 1:
@@ -180,12 +181,14 @@ def main():
         from silent_speech_amd import engine
 
         engine.USE_SIDE_STREAM = False  # one stream, so each event pair brackets exactly one kernel
+        mb, trainer.micro_batches = trainer.micro_batches, 1
         L.PROFILE = {}
         for _ in range(args.steps):
             trainer.step(X, lengths, R, y)
         torch.cuda.synchronize()
         prof, L.PROFILE = L.PROFILE, None
         engine.USE_SIDE_STREAM = True
+        trainer.micro_batches = mb
         for tag, evs in prof.items():
             ms = [a.elapsed_time(b) for a, b in evs]
             kernels[tag] = {"launches_per_step": len(ms) / args.steps, "avg_ms": sum(ms) / len(ms),
@@ -205,7 +208,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE config 2: landmark (K={K}, D={D}) + {roi}x{roi} uint8 ROI CNN + 2-layer BiGRU(192), "
                                f"T={T}, C={C}, train step = fwd + CE(ls .05) + bwd + grad all-reduce + clip(1.0) + Adam, dropout on",
-                   "batch_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}"},
+                   "batch_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}",
+                   "micro_batches_in_flight": args.micro_batches},
         "final_loss": round(final_loss, 5),
     }
     if roof:

@@ -70,6 +70,10 @@ int ss_roi_cnn_fwd(const uint8_t* R, int N, int H, int W, int standardize, const
                    const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
                    const float* bfc, int E, float* out, int ld_out, ss_stream_t stream);
 
+/* Workgroups the two persistent ROI-CNN kernels launch (default 256 = one per CU; 0 restores the default).
+ * A caller that runs a second stream beside them (micro-batch pipelining) leaves CUs free this way. */
+int ss_roi_cnn_set_max_workgroups(int n);
+
 /* Same forward, additionally writing what the backward needs (the six st_* pointers are either
  * all NULL -- then this is ss_roi_cnn_fwd -- or all valid):
  * st_a1 (N,8,H/2,W/2) f32 and st_i1 u8: pooled conv1 map and its 2x2 argmax (0..3, row-major window);
@@ -100,8 +104,9 @@ int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const
  *   used to pair dG[b][t] with h[b][t-1] without materialising a shifted copy.
  * a_colsum (may be NULL; needs a_kcontig = 0): a_colsum[m] += sum_k A[k][m] -- the bias gradient of a
  *   Linear layer rides on its weight-gradient GEMM instead of a separate reduction pass.
- * flags bit0: accumulate into C; bit1: ReLU epilogue.  splits > 1 slices K over blockIdx.z and
- * adds with float atomics (requires bit0, C pre-initialised). */
+ * flags bit0: accumulate into C; bit1: ReLU epilogue; bit2: accumulate with float atomics even when K is not
+ * split (several streams add into one C).  splits > 1 slices K over blockIdx.z and adds with float atomics
+ * (atomics require bit0, C pre-initialised, no ReLU). */
 int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
                 int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
                 float* C, int ldc, const float* bias, float* a_colsum, int flags, int splits, ss_stream_t stream);

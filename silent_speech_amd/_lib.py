@@ -28,6 +28,7 @@ SIGNATURES = {
     "ss_roi_crop_idx": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ss_roi_cnn_fwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i, _vp],
     "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_vp],
+    "ss_roi_cnn_set_max_workgroups": [_i],
     "ss_roi_cnn_bwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_vp, _i] + [_vp] * 8 + [_vp],
     "ss_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
     "ss_gemm_f32_batched": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i,

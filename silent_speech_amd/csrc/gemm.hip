@@ -36,7 +36,7 @@ struct GemmParams {
   int ksplit;  // K elements per blockIdx.z slice (multiple of BK)
   int nz;      // K slices per problem; blockIdx.z = batch * nz + slice
   long sA, sB, sC, sBias, sAsum;  // element strides between the problems of a batch
-  int flags;   // bit0: accumulate into C (plain RMW when gridDim.z==1, atomics otherwise); bit1: ReLU
+  int flags;   // bit0: accumulate into C (plain RMW when nz==1, atomics otherwise); bit1: ReLU; bit2: always atomic
 };
 
 // One operand tile, staged global -> registers (fetch) -> LDS (store) so the loads of tile k+1 are in
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   }
 
   const bool accumulate = p.flags & 1, relu = p.flags & 2;
-  const bool atomic = p.nz > 1;
+  const bool atomic = p.nz > 1 || (p.flags & 4);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -233,7 +233,7 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
   SS_REQUIRE(!a_colsum || !a_kcontig, SS_ERR_ARG);
   SS_REQUIRE(splits >= 1 && a_group > 0 && b_group > 0, SS_ERR_ARG);
   // split-K accumulates with atomics: C must already hold the value to add to, and ReLU cannot apply
-  SS_REQUIRE(splits == 1 || ((flags & 1) && !(flags & 2)), SS_ERR_ARG);
+  SS_REQUIRE((splits == 1 && !(flags & 4)) || ((flags & 1) && !(flags & 2)), SS_ERR_ARG);
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.asum = a_colsum;
   p.M = M; p.N = N; p.K = K;

@@ -24,6 +24,13 @@
 
 STAMP_TABLE(ss_debug_stamps_fwd)
 
+int ss_cnn_max_wgs = 0;  // shared with roi_cnn_bwd.hip; set through ss_roi_cnn_set_max_workgroups
+extern "C" int ss_roi_cnn_set_max_workgroups(int n) {
+  if (n < 0 || n > 4096) return SS_ERR_ARG;
+  ss_cnn_max_wgs = n;
+  return SS_OK;
+}
+
 namespace {
 
 constexpr int NT = 512;  // threads per workgroup
@@ -371,7 +378,8 @@ int launch_fwd(const CnnFwdParams& p, hipStream_t s) {
       return SS_ERR_LAUNCH;
     attr_set = true;
   }
-  const int grid = p.N < 256 ? p.N : 256;
+  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256;
+  const int grid = p.N < cap ? p.N : cap;
   hipLaunchKernelGGL(roi_cnn_fwd_kernel<G>, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();
 }

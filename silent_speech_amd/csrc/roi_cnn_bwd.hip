@@ -23,6 +23,8 @@
 
 STAMP_TABLE(ss_debug_stamps_bwd)
 
+extern int ss_cnn_max_wgs;  // roi_cnn.hip
+
 namespace {
 
 constexpr int NT = 512;
@@ -571,7 +573,8 @@ int launch_bwd(const CnnBwdParams& p, hipStream_t s) {
       return SS_ERR_LAUNCH;
     attr_set = true;
   }
-  const int grid = p.N < 256 ? p.N : 256;
+  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256;
+  const int grid = p.N < cap ? p.N : cap;
   hipLaunchKernelGGL(roi_cnn_bwd_kernel<G>, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();
 }

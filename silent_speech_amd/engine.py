@@ -48,10 +48,11 @@ class Config:
 
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, relu=False, splits=1,
-         a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0), a_colsum=None, tag="gemm", batch=1, strides=(0, 0, 0, 0, 0)):
+         a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0), a_colsum=None, tag="gemm", batch=1, strides=(0, 0, 0, 0, 0),
+         atomic=False):
     """C[M,N] (+)= opA * opB (+bias)(ReLU); A/B/Cm are ints (device addresses).  ``batch`` problems of one shape
     share a launch; ``strides`` = element strides of (A, B, C, bias, a_colsum) between them."""
-    flags = (1 if accumulate else 0) | (2 if relu else 0)
+    flags = (1 if accumulate else 0) | (2 if relu else 0) | (4 if atomic else 0)
     L.call("ss_gemm_f32_batched", int(a_kc), int(b_kc), M, N, K, A, lda, a_map[0], a_map[1], a_map[2], B, ldb,
            b_map[0], b_map[1], b_map[2], Cm, ldc, bias, a_colsum, flags, splits, batch, *strides, L.stream(), tag=tag)
 
@@ -84,6 +85,7 @@ class Workspace:
         self.side = torch.cuda.Stream(device=device) if train else None
         self.ev_fork = torch.cuda.Event() if train else None
         self.ev_join = torch.cuda.Event() if train else None
+        self.ev_cnn_fwd = torch.cuda.Event() if train else None  # recorded after the ROI-CNN forward (micro-batch stagger)
         self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
         self.gi = [torch.empty(2, N, 3 * H, **f32) for _ in range(cfg.gru_layers)]
         self.out = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers)]
@@ -136,6 +138,8 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
                ws.st_m3.data_ptr(), ws.st_feat.data_ptr()] if stash else [None] * 6)
         L.call("ss_roi_cnn_fwd_stash", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
                _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, s)
+        if ws.train:
+            ws.ev_cnn_fwd.record()
         layer_in, ld_in = ws_Z.data_ptr(), cfg.in_dim
     else:
         layer_in, ld_in = X.data_ptr(), cfg.x_dim
@@ -186,13 +190,13 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
     mid_used = ws.mid_drop if drop_head else ws.mid
     # ---- head
     gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, mid_used.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
-         accumulate=True, a_colsum=G["head.4.bias"].data_ptr())
+         accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
     gemm(1, 0, B, MID, C, d_logits.data_ptr(), C, P["head.4.weight"].data_ptr(), MID, ws.d_mid.data_ptr(), MID)
     # dropout mask (same seed/offset as the forward) and ReLU' in one pass
     L.call("ss_dropout", ws.d_mid.data_ptr(), ws.d_mid.data_ptr(), B * MID, cfg.head_dropout if drop_head else 0.0,
            seed, 7 << 40, ws.mid.data_ptr(), s)
     gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
-         2 * H, accumulate=True, a_colsum=G["head.1.bias"].data_ptr())
+         2 * H, accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
     gemm(1, 0, B, 2 * H, MID, ws.d_mid.data_ptr(), MID, P["head.1.weight"].data_ptr(), 2 * H, ws.d_ln.data_ptr(),
          2 * H)
     L.call("ss_layernorm_bwd", ws.d_ln.data_ptr(), ws.xhat.data_ptr(), ws.rstd.data_ptr(),
@@ -226,7 +230,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
             wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
             # d W_ih = dGi^T . layer_in, both directions in one launch
-            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True,
+            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
                  splits=split_k(3 * H, K, N, 2), tag="gemm_gru_dW", batch=2,
                  strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0, 0))
             # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse).
@@ -237,10 +241,12 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                 st = (N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr), 0, 0)
                 gw = G[wh]
                 gemm(0, 0, 2 * H, H, B * (T - 1), dg, 4 * H, ws.out[l].data_ptr(), 2 * H, gw.data_ptr(), H,
-                     accumulate=True, splits=split_k(2 * H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2, strides=st,
+                     accumulate=True, atomic=True, splits=split_k(2 * H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2,
+                     strides=st,
                      **maps)
                 gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, ws.out[l].data_ptr(), 2 * H, _addr(gw, 2 * H * H), H,
-                     accumulate=True, splits=split_k(H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2, strides=st,
+                     accumulate=True, atomic=True, splits=split_k(H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2,
+                     strides=st,
                      **maps)
             L.call("ss_gru_bias_grad", ws.dG[l].data_ptr(), N, H, G[f"gru.bias_ih_l{l}"].data_ptr(),
                    G[f"gru.bias_hh_l{l}"].data_ptr(), G[f"gru.bias_ih_l{l}_reverse"].data_ptr(),

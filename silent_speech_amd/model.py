@@ -187,10 +187,11 @@ class BiGRUClassifier(nn.Module):
         return {k: p.data for k, p in self.named_parameters()}
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, X, R, train: bool) -> E.Workspace:
+    def _workspace(self, X, R, train: bool, slot: int = 0) -> E.Workspace:
+        """Buffers for one (B, T, H, W) shape; ``slot`` separates micro-batches that are in flight together."""
         B, T, _ = X.shape
         hw = tuple(R.shape[2:]) if R is not None else None
-        key = (B, T, hw, train, X.device)
+        key = (B, T, hw, train, X.device, slot)
         ws = self._ws_cache.get(key)
         if ws is None:
             ws = E.Workspace(self.cfg, B, T, hw, X.device, train)

@@ -153,6 +153,35 @@ def test_config2_shapes_vs_oracle(ss):
     assert float((after.cpu() - ref_after).abs().max()) < 2e-4
 
 
+def test_micro_batch_streams_match_oracle(ss):
+    """Two micro-batches on two HIP streams (Trainer(micro_batches=2)) add up to the same step as the oracle's."""
+    B, T = 32, 12
+    sd = W.make_state_dict(11, 84, 5, True)
+    X, Lh, R, y = W.make_inputs(11, B, T, 84, 5, (64, 64))
+    m = ss.BiGRUClassifier(84, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    tr = ss.Trainer(m, dropout=False, micro_batches=2)
+    Xd, Ld, Rd, yd = X.cuda(), Lh.cuda(), R.cuda(), y.cuda()
+    loss, correct = tr.step(Xd, Ld, Rd, yd)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    loss_ref, logits_ref, _, total = MR.train_step(sd2, {}, X, Lh, R, y, impl="aten")
+    assert abs(float(loss) - float(loss_ref)) < 2e-5
+    assert abs(float(tr.grad_norm()) - total) < 1e-3 * total
+    assert int(correct) == int((logits_ref.argmax(1) == y).sum())
+    with torch.no_grad():
+        after = m(Xd, Lh, Rd)
+    assert float((after.cpu() - MR.forward(sd2, X, Lh, R, impl="aten")).abs().max()) < 2e-4
+    # and it is the same step as the single-stream trainer takes
+    m1 = ss.BiGRUClassifier(84, 5, use_roi=True)
+    m1.load_state_dict(sd)
+    m1.cuda().eval()
+    ss.Trainer(m1, dropout=False, micro_batches=1).step(Xd, Ld, Rd, yd)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m1.state_dict().items()):
+        atol = 6.1e-4 if k == "pool.score.bias" else 2e-6
+        assert float((a - b).abs().max()) <= atol, k
+
+
 def test_full_size_properties(ss):
     """BASELINE config 2 at full size (B=256): properties that need no oracle run."""
     B, T = 256, 30
