@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="train = the headline metric; infer = BASELINE config 4 (T=60, B=4096 windows, forward-only, hipGraph)")
     ap.add_argument("--micro-batches", type=int, default=1, help="slices of the per-GPU batch kept in flight on separate streams")
     args = ap.parse_args()
 
@@ -132,6 +134,8 @@ def main():
     import silent_speech_amd as ss
     from silent_speech_amd import _lib as L
 
+    if args.mode == "infer" and args.batch == 256 and args.frames == 30:
+        args.batch, args.frames = 4096, 60
     B, T, K, C, roi = args.batch, args.frames, args.landmarks, args.classes, args.roi
     D, E, H = 2 * K + 4, 32, 192
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -150,6 +154,24 @@ def main():
     y = torch.randint(0, C, (B,), device=dev, generator=g)
 
     torch.manual_seed(0)
+    if args.mode == "infer":
+        model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).eval()
+        g_inf = ss.GraphedInference(model, B, T, (roi, roi))
+        g_inf(X, lengths, R)
+        for _ in range(args.warmup):
+            g_inf()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g_inf()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        print(json.dumps({"metric": "windows/sec (60-frame, forward-only, hipGraph)", "value": round(B * args.steps / el, 1),
+                          "unit": "windows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": f"BASELINE config 4: {B} sliding windows x T={T}, "
+                                                          f"landmark + {roi}x{roi} ROI CNN + BiGRU, forward-only, hipGraph replay"}}))
+        return
     model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).train()
     if world > 1:
         dist.broadcast(model.flat_params, src=0)

@@ -10,9 +10,10 @@ from . import checkpoint, data, features
 from .checkpoint import load_classifier, save_checkpoint, topk_from_logits
 from .engine import Config
 from .features import crop_boxes, extract_features
+from .infer import GraphedInference
 from .model import AttnPool, BiGRUClassifier, TinyROICNN
 from .train import Trainer, allreduce_flat_grads, shard_range
 
 __all__ = ["Config", "BiGRUClassifier", "TinyROICNN", "AttnPool", "Trainer", "allreduce_flat_grads", "shard_range",
-           "extract_features", "crop_boxes", "load_classifier", "save_checkpoint", "topk_from_logits", "features",
+           "extract_features", "crop_boxes", "GraphedInference", "load_classifier", "save_checkpoint", "topk_from_logits", "features",
            "data", "checkpoint"]

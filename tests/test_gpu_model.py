@@ -220,6 +220,30 @@ def test_train_mode_dropout_is_active_and_seeded(ss, golden_dir):
     assert float((a - c).abs().max()) < 1.0
 
 
+def test_hipgraph_inference_equals_eager(ss):
+    """BASELINE config 4 flavour (sliding T=60 windows, forward-only, hipGraph-captured) at a test-sized batch."""
+    B, T = 96, 60
+    sd = W.make_state_dict(13, 84, 5, True)
+    X, Lh, R, y = W.make_inputs(13, B, T, 84, 5, (64, 64), lengths=[T] * B)
+    m = ss.BiGRUClassifier(84, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    Xd, Rd = X.cuda(), R.cuda()
+    with torch.no_grad():
+        eager = m(Xd, Lh, Rd)
+    g = ss.GraphedInference(m, B, T, (64, 64))
+    out1 = g(Xd, Lh, Rd).clone()
+    assert torch.equal(out1, eager)
+    # replay on new window contents and ragged lengths without re-capturing
+    X2, L2, R2, _ = W.make_inputs(14, B, T, 84, 5, (64, 64))
+    with torch.no_grad():
+        eager2 = m(X2.cuda(), L2, R2.cuda())
+    out2 = g(X2.cuda(), L2, R2.cuda()).clone()
+    assert torch.equal(out2, eager2) and not torch.equal(out2, out1)
+    ref = MR.forward(sd, X2[:8], L2[:8], R2[:8], impl="aten")
+    assert float((out2[:8].cpu() - ref).abs().max()) < TIGHT
+
+
 def test_real_weights_kat_gru(ss, golden_dir):
     """inactive/word_model_5.pt (1-layer BiGRU 83->64): trained weights through the GEMM + recurrence kernels."""
     from silent_speech_amd import _lib as L
