@@ -74,11 +74,18 @@ int ss_roi_cnn_fwd(const uint8_t* R, int N, int H, int W, int standardize, const
  * A caller that runs a second stream beside them (micro-batch pipelining) leaves CUs free this way. */
 int ss_roi_cnn_set_max_workgroups(int n);
 
+/* per-frame sizes of the stashed pooled maps (floats) and of the pool-1 argmax map (bytes, padded planes) for an
+ * (H, W) the kernels are built for */
+int ss_roi_cnn_stash_size(int H, int W, int* a1_floats, int* a2_floats, int* i1_bytes);
+
 /* Same forward, additionally writing what the backward needs (the six st_* pointers are either
  * all NULL -- then this is ss_roi_cnn_fwd -- or all valid):
- * st_a1 (N,8,H/2,W/2) f32 and st_i1 u8: pooled conv1 map and its 2x2 argmax (0..3, row-major window);
- * st_a2 (N,16,H/4,W/4) f32 and st_i2 u8: the same for conv2; st_m3 (N,24,H/4*W/4) u8: conv3 output > 0;
- * st_feat (N,24): globally averaged conv3 features. */
+ * st_a1 (N, a1_floats) f32: the pooled conv1 map in the kernels' zero-haloed LDS layout (8 planes of
+ *   (H/2+2) rows x (W/2+2) floats, plane stride padded; sizes from ss_roi_cnn_stash_size) so that the backward
+ *   streams it back with linear 16-byte copies; st_i1 (N, i1_bytes) u8: its 2x2 argmax (0..3, row-major window),
+ *   8 planes of H/2*W/2 + 4 bytes;
+ * st_a2 (N, a2_floats) f32 and st_i2 (N,16,H/4,W/4) u8: the same for conv2;
+ * st_m3 (N,24,H/4*W/4) u8: conv3 output > 0; st_feat (N,24): globally averaged conv3 features. */
 int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
                          const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
                          const float* bfc, int E, float* out, int ld_out, float* st_a1, uint8_t* st_i1,

@@ -29,6 +29,7 @@ SIGNATURES = {
     "ss_roi_cnn_fwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i, _vp],
     "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_vp],
     "ss_roi_cnn_set_max_workgroups": [_i],
+    "ss_roi_cnn_stash_size": [_i, _i, _vp, _vp, _vp],
     "ss_roi_cnn_bwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_vp, _i] + [_vp] * 8 + [_vp],
     "ss_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
     "ss_gemm_f32_batched": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i,
@@ -68,6 +69,15 @@ def load():
         fn.restype = _RESTYPES.get(name, C.c_int)
     _lib = lib
     return lib
+
+
+def cnn_stash_sizes(H: int, W: int):
+    """(floats per frame of the stashed pooled-1 map, of the pooled-2 map, bytes of the pool-1 argmax map)."""
+    a1, a2, i1 = C.c_int(0), C.c_int(0), C.c_int(0)
+    st = load().ss_roi_cnn_stash_size(H, W, C.byref(a1), C.byref(a2), C.byref(i1))
+    if st != 0:
+        raise RuntimeError(f"ROI size {H}x{W} is not one the CNN kernels are built for")
+    return a1.value, a2.value, i1.value
 
 
 def ptr(t):

@@ -39,7 +39,8 @@ def build(force: bool = False, verbose: bool = True, stamp: bool = False) -> str
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         return out
-    hdrs = [os.path.join(CSRC, "ss_common.h"), os.path.join(HERE, "..", "include", "ss_hotpath.h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "ss_hotpath.h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = []
     procs = []

@@ -101,11 +101,14 @@ struct Stager {
   }
 };
 
+constexpr int KSUB = 1;  // 16-wide k tiles per barrier (2 measured slower: the doubled LDS halves the co-resident workgroups)
+
 template <bool A_KCONTIG, bool B_KCONTIG>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   constexpr int A_SZ = A_KCONTIG ? BM * LDK : BK * LDM_A;
   constexpr int B_SZ = B_KCONTIG ? BN * LDK : BK * LDM_B;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_SZ + B_SZ)];
+  constexpr int STAGE = KSUB * (A_SZ + B_SZ);
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int bi = blockIdx.z / p.nz, zs = blockIdx.z - bi * p.nz;
@@ -129,64 +132,79 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   float asum = 0.f;  // column sums of the [k][row] A tile (bias gradient), thread t < BM owns row m0 + t
   const bool want_asum = (!A_KCONTIG) && p.asum && blockIdx.x == 0;
 
-  Stager<BM, A_KCONTIG> sa;
-  Stager<BN, B_KCONTIG> sb;
-  sa.fetch(p.A, p.lda, p.ra, m0, p.M, kbeg, kend, a_vec);
-  sb.fetch(p.B, p.ldb, p.rb, n0, p.N, kbeg, kend, b_vec);
-  sa.store(lds);
-  sb.store(lds + A_SZ);
+  Stager<BM, A_KCONTIG> sa[KSUB];
+  Stager<BN, B_KCONTIG> sb[KSUB];
+#pragma unroll
+  for (int u = 0; u < KSUB; ++u) {
+    sa[u].fetch(p.A, p.lda, p.ra, m0, p.M, kbeg + u * BK, kend, a_vec);
+    sb[u].fetch(p.B, p.ldb, p.rb, n0, p.N, kbeg + u * BK, kend, b_vec);
+  }
+#pragma unroll
+  for (int u = 0; u < KSUB; ++u) {
+    sa[u].store(lds + u * (A_SZ + B_SZ));
+    sb[u].store(lds + u * (A_SZ + B_SZ) + A_SZ);
+  }
   __syncthreads();
 
   int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const float* As = lds + cur * (A_SZ + B_SZ);
-    const float* Bs = As + A_SZ;
-    const bool more = k0 + BK < kend;
-    if (more) {  // next tile's global loads fly while this tile is multiplied
-      sa.fetch(p.A, p.lda, p.ra, m0, p.M, k0 + BK, kend, a_vec);
-      sb.fetch(p.B, p.ldb, p.rb, n0, p.N, k0 + BK, kend, b_vec);
-    }
-    float a[4][4], b[2][4];
+  for (int k0 = kbeg; k0 < kend; k0 += BK * KSUB) {
+    const bool more = k0 + BK * KSUB < kend;
+    if (more) {  // next stage's global loads fly while this one is multiplied
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      int r = wm * 64 + mt * 16 + i;
-      if (A_KCONTIG) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&As[r * LDK + 4 * g]);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a[mt][kk] = v[kk];
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a[mt][kk] = As[(4 * g + kk) * LDM_A + r];
+      for (int u = 0; u < KSUB; ++u) {
+        sa[u].fetch(p.A, p.lda, p.ra, m0, p.M, k0 + (KSUB + u) * BK, kend, a_vec);
+        sb[u].fetch(p.B, p.ldb, p.rb, n0, p.N, k0 + (KSUB + u) * BK, kend, b_vec);
       }
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      int c = wn * 32 + nt * 16 + i;
-      if (B_KCONTIG) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[c * LDK + 4 * g]);
+    for (int u = 0; u < KSUB; ++u) {
+      const float* As = lds + cur * STAGE + u * (A_SZ + B_SZ);
+      const float* Bs = As + A_SZ;
+      float a[4][4], b[2][4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) b[nt][kk] = v[kk];
-      } else {
+      for (int mt = 0; mt < 4; ++mt) {
+        int r = wm * 64 + mt * 16 + i;
+        if (A_KCONTIG) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&As[r * LDK + 4 * g]);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) b[nt][kk] = Bs[(4 * g + kk) * LDM_B + c];
+          for (int kk = 0; kk < 4; ++kk) a[mt][kk] = v[kk];
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) a[mt][kk] = As[(4 * g + kk) * LDM_A + r];
+        }
       }
-    }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+      for (int nt = 0; nt < 2; ++nt) {
+        int c = wn * 32 + nt * 16 + i;
+        if (B_KCONTIG) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[c * LDK + 4 * g]);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+          for (int kk = 0; kk < 4; ++kk) b[nt][kk] = v[kk];
+        } else {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(a[mt][kk], b[nt][kk], acc[mt][nt]);
-    if (!A_KCONTIG) {
-      if (want_asum && threadIdx.x < BM) {
+          for (int kk = 0; kk < 4; ++kk) b[nt][kk] = Bs[(4 * g + kk) * LDM_B + c];
+        }
+      }
 #pragma unroll
-        for (int k = 0; k < BK; ++k) asum += As[k * LDM_A + threadIdx.x];
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(a[mt][kk], b[nt][kk], acc[mt][nt]);
+      if (!A_KCONTIG) {
+        if (want_asum && threadIdx.x < BM) {
+#pragma unroll
+          for (int k = 0; k < BK; ++k) asum += As[k * LDM_A + threadIdx.x];
+        }
       }
     }
     if (more) {
-      float* nxt = lds + (cur ^ 1) * (A_SZ + B_SZ);
-      sa.store(nxt);
-      sb.store(nxt + A_SZ);
+      float* nxt = lds + (cur ^ 1) * STAGE;
+#pragma unroll
+      for (int u = 0; u < KSUB; ++u) {
+        sa[u].store(nxt + u * (A_SZ + B_SZ));
+        sb[u].store(nxt + u * (A_SZ + B_SZ) + A_SZ);
+      }
     }
     __syncthreads();
     cur ^= 1;
@@ -240,7 +258,7 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.ra = RowMap{a_group, a_gstride, a_off};
   p.rb = RowMap{b_group, b_gstride, b_off};
-  int per = ceil_div(ceil_div(K, splits), BK) * BK;
+  int per = ceil_div(ceil_div(K, splits), BK * KSUB) * BK * KSUB;
   p.ksplit = per;
   p.nz = ceil_div(K, per);
   p.sA = stride_a; p.sB = stride_b; p.sC = stride_c; p.sBias = stride_bias; p.sAsum = stride_colsum;

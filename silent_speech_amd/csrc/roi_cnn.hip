@@ -45,9 +45,9 @@ struct CnnFwdParams {
   float* out;
   int ld_out;
   // training stash (all null together)
-  float* st_a1;     // [N][8][H2][W2]
-  uint8_t* st_i1;   // [N][8][H2][W2]
-  float* st_a2;     // [N][16][H4][W4]
+  float* st_a1;     // [N][8][P1]  haloed LDS image of the pooled-1 map, as is
+  uint8_t* st_i1;   // [N][8][I1S] (plane stride I1S = H2*W2 + 4 bytes)
+  float* st_a2;     // [N][16][P2] haloed LDS image of the pooled-2 map, as is
   uint8_t* st_i2;   // [N][16][H4][W4]
   uint8_t* st_m3;   // [N][24][P]
   float* st_feat;   // [N][24]
@@ -58,8 +58,8 @@ struct FwdLds {
   static constexpr int o_xh = 0;                                // [(H+2)][XS]
   static constexpr int o_a1 = ((G::H + 2) * G::XS + 3) & ~3;    // [8][P1]
   static constexpr int o_a2 = o_a1 + 8 * G::P1;                 // [16][P2]
-  static constexpr int o_i1 = (o_a2 + 16 * G::P2 + 3) & ~3;     // bytes [8][HW2]
-  static constexpr int o_i2 = o_i1 + 2 * G::HW2;                // bytes [16][P]
+  static constexpr int o_i1 = (o_a2 + 16 * G::P2 + 3) & ~3;     // bytes [8][I1S]
+  static constexpr int o_i2 = o_i1 + 2 * G::I1S;                // bytes [16][P]
   static constexpr int o_misc = o_i2 + 4 * G::P + 256;  // the 256 floats in front hold the grey-level table
   static constexpr int total = o_misc + 512;
 };
@@ -68,7 +68,7 @@ template <class G>
 __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = FwdLds<G>;
-  constexpr int H = G::H, W = G::W, H2 = G::H2, W2 = G::W2, W4 = G::W4, HW = G::HW, HW2 = G::HW2, P = G::P;
+  constexpr int H = G::H, W = G::W, H2 = G::H2, W2 = G::W2, W4 = G::W4, HW = G::HW, P = G::P;
   constexpr int XS = G::XS, S1 = G::S1, P1 = G::P1, S2 = G::S2, P2 = G::P2;
   constexpr int NCH = (HW / 16 + NT - 1) / NT;  // 16-byte pixel chunks per thread
   float* xh = lds + LL::o_xh;
@@ -231,20 +231,16 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
         const int bi = r1v > r0v ? 2 + r1c : r0c;
         const int pxx = 8 * xt + 2 * g + s;
         a1[c * P1 + (yp + 1) * S1 + pxx + 1] = best;
-        i1s[c * HW2 + yp * W2 + pxx] = (uint8_t)bi;
+        i1s[c * G::I1S + yp * W2 + pxx] = (uint8_t)bi;
       }
     }
     __syncthreads();
     STAMP(1);
-    if (stash) {  // pooled-1 map and its argmaxes leave LDS in 16-byte pieces
-      f32x4* dst = reinterpret_cast<f32x4*>(p.st_a1 + (long)n * 8 * HW2);
-      for (int q = tid; q < 2 * HW2; q += NT) {
-        const int c = q / (HW2 / 4), rem = q % (HW2 / 4), y = rem / (W2 / 4), x4 = rem % (W2 / 4);
-        const float* src = a1 + c * P1 + (y + 1) * S1 + 4 * x4 + 1;
-        dst[q] = f32x4{src[0], src[1], src[2], src[3]};
-      }
-      for (int q = tid; q < HW2 / 2; q += NT)
-        reinterpret_cast<uint4*>(p.st_i1 + (long)n * 8 * HW2)[q] = reinterpret_cast<const uint4*>(i1s)[q];
+    if (stash) {  // pooled-1 map (haloed image as it stands: the backward loads it linearly) and its argmaxes
+      f32x4* dst = reinterpret_cast<f32x4*>(p.st_a1 + (long)n * 8 * P1);
+      for (int q = tid; q < 2 * P1; q += NT) dst[q] = reinterpret_cast<const f32x4*>(a1)[q];
+      for (int q = tid; q < G::I1S / 2; q += NT)
+        reinterpret_cast<uint4*>(p.st_i1 + (long)n * 8 * G::I1S)[q] = reinterpret_cast<const uint4*>(i1s)[q];
     }
 
     // ---------------- stage 2: conv2 (MFMA) + ReLU + pool -> a2 (haloed)
@@ -292,12 +288,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
     __syncthreads();
     STAMP(2);
     if (stash) {
-      f32x4* dst = reinterpret_cast<f32x4*>(p.st_a2 + (long)n * 16 * P);
-      for (int q = tid; q < 4 * P; q += NT) {
-        const int c = q / (P / 4), rem = q % (P / 4), y = rem / (W4 / 4), x4 = rem % (W4 / 4);
-        const float* src = a2 + c * P2 + (y + 1) * S2 + 4 * x4 + 1;
-        dst[q] = f32x4{src[0], src[1], src[2], src[3]};
-      }
+      f32x4* dst = reinterpret_cast<f32x4*>(p.st_a2 + (long)n * 16 * P2);
+      for (int q = tid; q < 4 * P2; q += NT) dst[q] = reinterpret_cast<const f32x4*>(a2)[q];
       for (int q = tid; q < P; q += NT)
         reinterpret_cast<uint4*>(p.st_i2 + (long)n * 16 * P)[q] = reinterpret_cast<const uint4*>(i2s)[q];
     }
@@ -405,6 +397,20 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define SS_DISPATCH(HH, WW) \
   if (H == HH && W == WW) return launch_fwd<Geom<HH, WW>>(p, s);
+  SS_CNN_SHAPES(SS_DISPATCH)
+#undef SS_DISPATCH
+  return SS_ERR_UNSUPPORTED;
+}
+
+extern "C" int ss_roi_cnn_stash_size(int H, int W, int* a1_floats, int* a2_floats, int* i1_bytes) {
+  SS_REQUIRE(a1_floats && a2_floats && i1_bytes, SS_ERR_ARG);
+#define SS_DISPATCH(HH, WW)              \
+  if (H == HH && W == WW) {              \
+    *a1_floats = 8 * Geom<HH, WW>::P1;   \
+    *a2_floats = 16 * Geom<HH, WW>::P2;  \
+    *i1_bytes = 8 * Geom<HH, WW>::I1S;   \
+    return SS_OK;                        \
+  }
   SS_CNN_SHAPES(SS_DISPATCH)
 #undef SS_DISPATCH
   return SS_ERR_UNSUPPORTED;

@@ -12,9 +12,10 @@
 //   S3  dW2[n][c][tap] += sum_x dy2[n][x] * a1[c][x+tap]       M=n(16) N=(tap,c)=72->80 K=pixels
 //   S4  da1[c][y..y+1][x] = sum dy2[n][.] * W2[n][c][.]        M=16 pixels of row y, N=(c, row y|y+1)=16,
 //                                                              K=(4 source rows x 3 cols, n)=192: no N padding
-//   S5  dW1[c][tap] += da1[c][q] * x[2q+argmax+tap]            in S4's epilogue (pool sparsity: 1 of 4 live),
-//                                                              x = the normalised frame, rebuilt in LDS from a
-//                                                              256-entry grey-level table (no per-pixel divides)
+//   S5  G[(c,o)][(ry,rx)] += sum_q [argmax1(c,q)=o] da1[c][q] * x[2q+(ry,rx)-1]   M=(8 ch x 4 window slots)=32,
+//       N=16 shifted views of the normalised frame, K=pooled pixels; dW1[c][ky][kx] = sum_o G[(c,o)][o+(ky,kx)]
+//       (the pool routes each gradient to ONE of 4 input positions, so conv1's weight gradient is a 32x16xK GEMM
+//       on the pooled grid instead of an 8x9x4K one); x is rebuilt in LDS from a 256-entry grey-level table
 //
 // Weight-gradient partial sums stay in registers for the whole frame walk (K = pixels split over the
 // 8 waves) and are reduced through LDS, then one float atomic per element per workgroup, at the end.
@@ -32,24 +33,42 @@ constexpr int NWV = NT / 64;
 
 template <class G>
 struct BwdLds {
-  static constexpr int o_a1h = 0;                         // [8][P1]   haloed pooled-1 map (persistent halo)
-  // phase area.  phase 1: a2h | dy3h | da2m | i2 | w3 ;  phase 2: dy2 | xh (normalised frame, haloed) | i1
+  static constexpr int o_a1h = 0;                         // [8][P1]   haloed pooled-1 map; S4 overwrites it with da1
+  // phase area.  phase 1: a2h | dy3h | da2m | i2 (| w3) ;  phase 2: dy2 | xh (normalised frame, haloed) | i1
   static constexpr int o_ph = 8 * G::P1;
   static constexpr int o_dy3h = o_ph + 16 * G::P2;
   static constexpr int o_da2m = o_dy3h + 24 * G::P2;
   static constexpr int o_i2b = o_da2m + 16 * G::P;
-  static constexpr int o_w3s = (o_i2b + 4 * G::P + 3) & ~3;
-  static constexpr int end1 = o_w3s + 3456;
+  static constexpr int end1a = (o_i2b + 4 * G::P + 3) & ~3;
   static constexpr int PD = plane_stride(G::HW2);         // dy2 plane stride
   static constexpr int o_xh = o_ph + 16 * PD;
   static constexpr int XHN = (G::H + 2) * G::XS;
   static constexpr int o_i1b = (o_xh + XHN + 3) & ~3;
-  static constexpr int end2 = o_i1b + 2 * G::HW2;
-  static constexpr int o_w2t = ((end1 > end2 ? end1 : end2) + 3) & ~3;
+  static constexpr int end2 = (o_i1b + 2 * G::I1S + 3) & ~3;
+  // W3 (13.8 KB) stays resident behind the phase area when the CU's 160 KB allow it; otherwise it lives in the
+  // phase-1 part and is re-staged from L2 every frame
+  static constexpr int fixed = 192 * 16 + 512;             // w2t + misc
+  static constexpr bool W3_RESIDENT = ((end1a > end2 ? end1a : end2) + 3456 + fixed) * 4 <= 160 * 1024;
+  static constexpr int end1 = W3_RESIDENT ? end1a : end1a + 3456;
+  static constexpr int ph_end = end1 > end2 ? end1 : end2;
+  static constexpr int o_w3s = W3_RESIDENT ? ph_end : end1a;
+  static constexpr int o_w2t = W3_RESIDENT ? ph_end + 3456 : ph_end;
   static constexpr int o_misc = o_w2t + 192 * 16;
   static constexpr int total = o_misc + 512;
   static constexpr int TV = (16 * G::P + NT - 1) / NT;    // (da2m, argmax) pairs per thread at the phase switch
 };
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to lds_byte_addr + lane*16 (wave-uniform base), no VGPRs.
+// Inline asm on purpose: hipcc does not track it, so the workgroup barriers between issue and use do not drain it;
+// the consumer waits with ss_dma_wait() before its barrier (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void ss_dma16(const void* gsrc_lane, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc_lane), "s"(lds_byte_addr)
+               : "memory");
+}
+__device__ __forceinline__ void ss_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct CnnBwdParams {
   const uint8_t* R;
@@ -74,7 +93,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H, XS = G::XS;
   constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, PD = LL::PD;
   constexpr int NCH = (HW / 16 + NT - 1) / NT;    // 16-byte pixel chunks per thread
-  constexpr int NI1 = (HW2 / 2 + NT - 1) / NT;    // 16-byte pool-1 argmax chunks per thread
+  constexpr int I1S = G::I1S;
+  constexpr int NI1 = (I1S / 2 + NT - 1) / NT;    // 16-byte pool-1 argmax chunks per thread
   float* a1h = lds + LL::o_a1h;
   float* a2h = lds + LL::o_ph;
   float* dy3h = lds + LL::o_dy3h;
@@ -102,6 +122,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
 
   for (int q = tid; q < LL::total; q += NT) lds[q] = 0.f;
   __syncthreads();
+  if (LL::W3_RESIDENT)
+    for (int q = tid; q < 3456; q += NT) w3s[q] = p.w3[q];
   // S4's B operand: k = (t*3+kx)*16 + n, column j = (c, s): W2[n][c][ky = s+2-t][kx], zero outside the 3x3 window
   for (int q = tid; q < 192 * 16; q += NT) {
     const int k = q >> 4, j = q & 15;
@@ -120,10 +142,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   const int s1_kg = wvu & 3, s1_tbase = (wvu >> 2) * 5, s1_ntap = (wvu >> 2) ? 4 : 5;
 #pragma unroll
   for (int a = 0; a < 5; ++a) acc2[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float acc1[10];  // dW1[c = i&7][tap], db1: this lane's share
-#pragma unroll
-  for (int a = 0; a < 10; ++a) acc1[a] = 0.f;
-  float accfc[3] = {0.f, 0.f, 0.f}, accbfc = 0.f, accb2 = 0.f;
+  f32x4 accG[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // S5: rows (c, window slot), cols (ry, rx)
+  float accfc[3] = {0.f, 0.f, 0.f}, accbfc = 0.f, accb2 = 0.f, accb1 = 0.f;
 
   // S3 B-operand offsets: column idx = 16*nt + i  ->  tap = idx/8, c = idx%8
   int boff[5];
@@ -149,29 +169,13 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     if (tid < E) s_dout[tid] = p.d_out[(long)n * p.ld_dout + tid];
     if (tid < 24) s_feat[tid] = p.st_feat[(long)n * 24 + tid];
     for (int q = tid; q < E * 24; q += NT) s_wfc[q] = p.wfc[q];
-    for (int q = tid; q < 3456 / 4; q += NT)
-      reinterpret_cast<f32x4*>(w3s)[q] = reinterpret_cast<const f32x4*>(p.w3)[q];
-    {  // a2 -> haloed planes (float4 along x), a1 likewise
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.st_a2 + (long)n * 16 * P);
-#pragma unroll 2
-      for (int q = tid; q < 4 * P; q += NT) {
-        const f32x4 v = src[q];
-        const int c = q / (P / 4), rem = q % (P / 4);
-        const int y = rem / (W4 / 4), x4 = rem % (W4 / 4);
-        float* dst = a2h + c * P2 + (y + 1) * S2 + 4 * x4 + 1;
-        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-      }
-    }
-    {
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.st_a1 + (long)n * 8 * HW2);
-#pragma unroll 4
-      for (int q = tid; q < 2 * HW2; q += NT) {
-        const f32x4 v = src[q];
-        const int c = q / (HW2 / 4), rem = q % (HW2 / 4);
-        const int y = rem / (W2 / 4), x4 = rem % (W2 / 4);
-        float* dst = a1h + c * P1 + (y + 1) * S1 + 4 * x4 + 1;
-        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-      }
+    if (!LL::W3_RESIDENT)
+      for (int q = tid; q < 3456 / 4; q += NT)
+        reinterpret_cast<f32x4*>(w3s)[q] = reinterpret_cast<const f32x4*>(p.w3)[q];
+    {  // pooled-2 map: the stash is the haloed LDS image itself -> linear 16-byte copy
+      const f32x4* src = reinterpret_cast<const f32x4*>(p.st_a2 + (long)n * 16 * P2);
+#pragma unroll 3
+      for (int q = tid; q < 4 * P2; q += NT) reinterpret_cast<f32x4*>(a2h)[q] = src[q];
     }
     if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = i2w;
     {
@@ -196,6 +200,15 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         sq += __shfl_xor(sq, o, 64);
       }
       if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
+    }
+    {  // pooled-1 map: LDS-DMA, 1 KB per wave instruction, issued after every compiler-tracked load of this phase
+       // has been consumed and waited for only before S3 (it flies under S1/S2)
+      constexpr int BYTES = 8 * P1 * 4;
+      const char* src = reinterpret_cast<const char*>(p.st_a1 + (long)n * 8 * P1);
+      for (int piece = wvu; piece * 1024 < BYTES; piece += NWV) {
+        const int off = piece * 1024 + lane * 16;
+        if (off < BYTES) ss_dma16(src + off, (unsigned)(LL::o_a1h * 4 + piece * 1024));
+      }
     }
     __syncthreads();  // A
     STAMP(0);
@@ -348,8 +361,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       uint4 ix1[NI1];
 #pragma unroll
       for (int k = 0; k < NI1; ++k)
-        if ((tid + k * NT) * 16 < 8 * HW2)
-          ix1[k] = reinterpret_cast<const uint4*>(p.st_i1 + (long)n * 8 * HW2)[tid + k * NT];
+        if ((tid + k * NT) * 16 < 8 * I1S)
+          ix1[k] = reinterpret_cast<const uint4*>(p.st_i1 + (long)n * 8 * I1S)[tid + k * NT];
       float dv[TV];
       int iv[TV];
 #pragma unroll
@@ -396,8 +409,9 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
 #pragma unroll
       for (int k = 0; k < NI1; ++k)
-        if ((tid + k * NT) * 16 < 8 * HW2) reinterpret_cast<uint4*>(i1b)[tid + k * NT] = ix1[k];
+        if ((tid + k * NT) * 16 < 8 * I1S) reinterpret_cast<uint4*>(i1b)[tid + k * NT] = ix1[k];
     }
+    ss_dma_wait();    // this wave's share of the pooled-1 map has landed in LDS
     __syncthreads();  // T done
     STAMP(5);
 
@@ -464,34 +478,57 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           }
           SS_SCHED_FENCE();
         }
-        // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0, then the pool-sparse dW1:
-        // the gradient lands on the window's argmax position, whose 3x3 input patch is read from the haloed frame.
+        // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0 and leave da1 IN PLACE of
+        // a1 (each cell is read and rewritten by exactly one lane; S3 finished with a1 before the barrier above).
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           if (half == 1 && !two) break;
           const int yy = (half ? y1_ : y0_) + s;
           const int xb0 = (half ? x1_ : x0_) - i + 4 * g;
+          float* cell = a1h + c * P1 + (yy + 1) * S1 + xb0 + 1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int xx = xb0 + r;
-            const float av = a1h[c * P1 + (yy + 1) * S1 + xx + 1];
-            const float d = av > 0.f ? (half ? acc1x[r] : acc0[r]) : 0.f;
-            const int o = i1b[c * HW2 + yy * W2 + xx];
-            const float* xp = xh + (2 * yy + (o >> 1)) * XS + 2 * xx + (o & 1);
-            acc1[9] += d;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-              for (int kx = 0; kx < 3; ++kx) acc1[ky * 3 + kx] += d * xp[ky * XS + kx];
+            const float d = cell[r] > 0.f ? (half ? acc1x[r] : acc0[r]) : 0.f;
+            cell[r] = d;
+            accb1 += d;
           }
         }
       }
     }
+    __syncthreads();  // da1 complete
+    STAMP(9);
+    // ---------------- S5: conv1 weight gradient on the pooled grid (K = pooled pixels, split over the 8 waves)
+    {
+      constexpr int kpw = HW2 / NWV;
+      const int pbase = wvu * kpw;
+      const int c = i & 7, os = i >> 3;         // A rows: tile 0 -> window slot os, tile 1 -> slot 2 + os
+      const int boff = (i >> 2) * XS + (i & 3);  // B column (ry, rx)
+#pragma unroll 1
+      for (int kk = 0; kk < kpw / 4; kk += 4) {  // four k-steps per pass: 12 LDS reads, then 8 MFMAs
+        float d[4], xv[4];
+        int ix[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = pbase + 4 * (kk + u) + g;
+          const int qy = q / W2, qx = q % W2;
+          d[u] = a1h[c * P1 + (qy + 1) * S1 + qx + 1];
+          ix[u] = i1b[c * I1S + q];
+          xv[u] = xh[(2 * qy) * XS + 2 * qx + boff];
+        }
+        SS_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          accG[0] = mfma16(ix[u] == os ? d[u] : 0.f, xv[u], accG[0]);
+          accG[1] = mfma16(ix[u] == 2 + os ? d[u] : 0.f, xv[u], accG[1]);
+        }
+        SS_SCHED_FENCE();
+      }
+    }
     __syncthreads();  // E
     STAMP(7);
-    // restore the zero halos of the phase-1 planes for the next frame (their interiors are rewritten anyway)
-    for (int q = tid; q < (LL::o_da2m - LL::o_ph) / 4; q += NT)
-      reinterpret_cast<f32x4*>(a2h)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // restore the zero halo of the dy3 planes for the next frame (a2h arrives with its halo, interiors are rewritten)
+    for (int q = tid; q < (LL::o_da2m - LL::o_dy3h) / 4; q += NT)
+      reinterpret_cast<f32x4*>(dy3h)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();  // F
     STAMP(8);
   }
@@ -525,16 +562,22 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       for (int r = 0; r < 4; ++r) atomicAdd(&r_w2[(4 * g + r) * 72 + c * 9 + tap], acc2[nt][r]);
     }
   }
-  {
-    const int c = i & 7;
+  // S5 accumulators: row 16mt+4g+r = (c = row&7, window slot o = row>>3), column i = (ry, rx):
+  // dW1[c][ky][kx] gets G[(c,o)][(oy+ky, ox+kx)]
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      float s = acc1[k];  // lanes with equal (i & 7) share a channel: fold i^8 and the 4 lane groups, then the waves
-      s += __shfl_xor(s, 8, 64);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (lane < 8) atomicAdd(k < 9 ? &r_w1[c * 9 + k] : &r_b1[c], s);
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * mt + 4 * g + r, c = row & 7, o = row >> 3;
+      const int ky = (i >> 2) - (o >> 1), kx = (i & 3) - (o & 1);
+      if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) atomicAdd(&r_w1[c * 9 + ky * 3 + kx], accG[mt][r]);
     }
+  {
+    float s = accb1;  // lanes with equal (i & 7) share a channel: fold i^8 and the 4 lane groups, then the waves
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 8) atomicAdd(&r_b1[i & 7], s);
   }
   {
     float s = accb2;

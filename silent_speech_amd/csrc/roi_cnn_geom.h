@@ -17,6 +17,8 @@ struct Geom {
   static constexpr int XS = W + 2;                              // haloed normalised image, row stride
   static constexpr int S1 = W2 + 2, P1 = plane_stride((H2 + 2) * S1);  // haloed pooled-1 map
   static constexpr int S2 = W4 + 2, P2 = plane_stride((H4 + 2) * S2);  // haloed pooled-2 map
+  // pool-1 argmax bytes, plane stride per channel (padding the planes apart by one bank was measured: no gain)
+  static constexpr int I1S = HW2;
   static_assert(H % 4 == 0 && W % 32 == 0 && H2 % 2 == 0 && P % 32 == 0 && HW2 % 32 == 0, "unsupported ROI size");
 };
 

@@ -42,9 +42,11 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): the gates sit on the recurrence's critical path between two workgroup barriers,
+// an IEEE divide there costs ~10 VALU instructions per element; the logit tolerance (1e-3) leaves 4 orders of margin
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // tanh via one exp; saturates cleanly (exp->inf gives 1, exp->0 gives -1)
-__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -109,9 +109,10 @@ class Workspace:
             self.dZ = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
             if cfg.use_roi:
                 Hh, Ww = roi_hw
-                self.st_a1 = torch.empty(N, 8, Hh // 2, Ww // 2, **f32)
-                self.st_i1 = torch.empty(N, 8, Hh // 2, Ww // 2, **u8)
-                self.st_a2 = torch.empty(N, 16, Hh // 4, Ww // 4, **f32)
+                n_a1, n_a2, n_i1 = L.cnn_stash_sizes(Hh, Ww)  # the kernels' own LDS images, kept as they are
+                self.st_a1 = torch.empty(N, n_a1, **f32)
+                self.st_i1 = torch.empty(N, n_i1, **u8)
+                self.st_a2 = torch.empty(N, n_a2, **f32)
                 self.st_i2 = torch.empty(N, 16, Hh // 4, Ww // 4, **u8)
                 self.st_m3 = torch.empty(N, 24, (Hh // 4) * (Ww // 4), **u8)
                 self.st_feat = torch.empty(N, 24, **f32)

@@ -386,9 +386,10 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     R_d = dev(R)
     out = torch.empty(N, 32, device="cuda")
     H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
-    st_a1 = torch.empty(N, 8, H2, W2, device="cuda")
-    st_i1 = torch.empty(N, 8, H2, W2, device="cuda", dtype=torch.uint8)
-    st_a2 = torch.empty(N, 16, H4, W4, device="cuda")
+    n_a1, n_a2, n_i1 = L.cnn_stash_sizes(H, W)
+    st_a1 = torch.empty(N, n_a1, device="cuda")
+    st_i1 = torch.empty(N, n_i1, device="cuda", dtype=torch.uint8)
+    st_a2 = torch.empty(N, n_a2, device="cuda")
     st_i2 = torch.empty(N, 16, H4, W4, device="cuda", dtype=torch.uint8)
     st_m3 = torch.empty(N, 24, H4 * W4, device="cuda", dtype=torch.uint8)
     st_feat = torch.empty(N, 24, device="cuda")
@@ -397,8 +398,15 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
            *[s.data_ptr() for s in st], L.stream())
     sync()
     assert_close("roi_e", out, out_ref, atol=2e-5, rtol=1e-4)
-    assert_close("stash a1", st_a1, a1, atol=1e-5, rtol=1e-5)
-    assert_close("stash a2", st_a2, a2, atol=2e-5, rtol=1e-5)
+
+    def unhalo(st, ch, hh, ww):  # (N, ch*plane) haloed image -> (N, ch, hh, ww); the halo itself must be zero
+        img = st.view(N, ch, -1)[:, :, : (hh + 2) * (ww + 2)].reshape(N, ch, hh + 2, ww + 2)
+        assert float(img[:, :, 0].abs().max()) == 0 and float(img[:, :, :, 0].abs().max()) == 0
+        assert float(img[:, :, -1].abs().max()) == 0 and float(img[:, :, :, -1].abs().max()) == 0
+        return img[:, :, 1:-1, 1:-1]
+
+    assert_close("stash a1", unhalo(st_a1, 8, H2, W2), a1, atol=1e-5, rtol=1e-5)
+    assert_close("stash a2", unhalo(st_a2, 16, H4, W4), a2, atol=2e-5, rtol=1e-5)
     assert_close("stash feat", st_feat, feat, atol=1e-5, rtol=1e-5)
 
     # argmax: compare where the winner is positive and clearly separated (ties / relu zeros carry no gradient)
@@ -412,7 +420,8 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
         top = win.topk(2, dim=-1).values
         return top[..., 0] - top[..., 1]
 
-    for name, st_i, idx, c, a in (("i1", st_i1, i1, c1, a1), ("i2", st_i2, i2, c2, a2)):
+    st_i1v = st_i1.view(N, 8, -1)[:, :, : H2 * W2].reshape(N, 8, H2, W2)  # planes are padded by 4 bytes
+    for name, st_i, idx, c, a in (("i1", st_i1v, i1, c1, a1), ("i2", st_i2, i2, c2, a2)):
         sure = (a > 1e-4) & (top2_gap(c.detach()) > 1e-4)
         got = st_i.cpu()[sure]
         want = idx_to_win(idx, c.shape[3])[sure]
