@@ -227,6 +227,11 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         ws.ev_fork.record()
         with torch.cuda.stream(side):
             side.wait_event(ws.ev_fork)
+            # the cheap bias reduction goes first: whatever is still queued on this stream when the next chip-filling
+            # kernel of the main stream starts only finishes after it
+            L.call("ss_gru_bias_grad", ws.dG[l].data_ptr(), N, H, G[f"gru.bias_ih_l{l}"].data_ptr(),
+                   G[f"gru.bias_hh_l{l}"].data_ptr(), G[f"gru.bias_ih_l{l}_reverse"].data_ptr(),
+                   G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.stream())
             dg = ws.dG[l].data_ptr()
             wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
             wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
@@ -249,9 +254,6 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                      accumulate=True, atomic=True, splits=split_k(H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2,
                      strides=st,
                      **maps)
-            L.call("ss_gru_bias_grad", ws.dG[l].data_ptr(), N, H, G[f"gru.bias_ih_l{l}"].data_ptr(),
-                   G[f"gru.bias_hh_l{l}"].data_ptr(), G[f"gru.bias_ih_l{l}_reverse"].data_ptr(),
-                   G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.stream())
         # d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r
         need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
         if need_dx:
@@ -261,9 +263,13 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                 dst, ld_dst = ws.dZ.data_ptr(), cfg.in_dim
             else:
                 dst, ld_dst = d_X.data_ptr(), cfg.x_dim
-            for d, suf in enumerate(("", "_reverse")):
-                gemm(1, 0, N, K, 3 * H, _addr(ws.dG[l], d * N * 4 * H), 4 * H,
-                     P[f"gru.weight_ih_l{l}{suf}"].data_ptr(), K, dst, ld_dst, accumulate=(d == 1), tag="gemm_gru_dX")
+            # both directions in ONE launch (twice the workgroups: the N=116 case alone leaves half the CUs idle),
+            # summed with float atomics into a zeroed destination
+            dst_t = ws.d_out if l > 0 else (ws.dZ if cfg.use_roi else d_X)
+            dst_t.zero_()
+            wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
+            gemm(1, 0, N, K, 3 * H, ws.dG[l].data_ptr(), 4 * H, P[wi].data_ptr(), K, dst, ld_dst, accumulate=True,
+                 atomic=True, tag="gemm_gru_dX", batch=2, strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0, 0))
             if l > 0 and train and cfg.gru_dropout > 0.0:
                 L.call("ss_dropout", dst, dst, N * 2 * H, cfg.gru_dropout, seed, l << 40, None, s)
     # ---- ROI CNN
