@@ -173,6 +173,26 @@ int ss_layernorm_bwd(const float* d_y, const float* xhat, const float* rstd, con
 int ss_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint64_t offset, const float* relu_of,
                ss_stream_t stream);
 
+/* ---- a8+a9(+CE) fused: the whole classifier tail of one clip per workgroup ----------------------
+ * AttnPool -> LayerNorm -> Linear(D,MID) -> ReLU -> Dropout(drop_p) -> Linear(MID,C), and, when y != NULL,
+ * CrossEntropyLoss(label_smoothing)/denom with d(loss)/d(logits) (train_model_official.py:231-248, 271-277, 405).
+ * Stash outputs (attn (B,T), xhat (B,D), rstd (B), ln (B,D) = LayerNorm output, mid (B,MID) = post-ReLU,
+ * mid_d (B,MID) = after dropout) may each be NULL for inference.  Dropout draws the ss_dropout stream (seed, offset)
+ * at element index b*MID + o. */
+int ss_tail_fwd(const float* h, const int32_t* lengths, const float* w_score, const float* b_score, const float* gamma,
+                const float* beta, const float* w1, const float* b1, const float* w4, const float* b4, const int64_t* y,
+                int B, int T, int D, int MID, int C, float ln_eps, float drop_p, uint64_t seed, uint64_t offset,
+                float label_smoothing, float denom, float* attn, float* xhat, float* rstd, float* ln, float* mid,
+                float* mid_d, float* logits, float* d_logits, float* loss_sum, int32_t* correct, ss_stream_t stream);
+/* Backward of the tail from d_logits (B,C) down to d_h (B,T,D) (written) and d_mid (B,MID) (written: the input of the
+ * first Linear's weight-gradient GEMM); g_gamma, g_beta (D), g_wscore (D), g_bscore (1) are accumulated.  The two
+ * Linear weight/bias gradients are ss_gemm_f32 calls on (d_logits, mid_d) and (d_mid, ln). */
+int ss_tail_bwd(const float* h, const int32_t* lengths, const float* w_score, const float* gamma, const float* w1,
+                const float* w4, const float* attn, const float* xhat, const float* rstd, const float* mid,
+                const float* d_logits, int B, int T, int D, int MID, int C, float drop_p, uint64_t seed,
+                uint64_t offset, float* d_mid, float* d_h, float* g_gamma, float* g_beta, float* g_wscore,
+                float* g_bscore, ss_stream_t stream);
+
 /* ---- a10: loss, clip, Adam -------------------------------------------------------------------
  * CrossEntropyLoss(label_smoothing) mean-reduced over `denom` clips (the GLOBAL batch under data
  * parallelism), forward and d(loss)/d(logits) in one pass (train_model_official.py:405, 434-437).

@@ -59,17 +59,24 @@ __global__ __launch_bounds__(H * 4) void gru_fwd_kernel(GruFwdParams p) {
   const int len = clip_ok ? p.lengths[clip] : 0;
   const int T = p.T;
 
-  // W_hh fragments: A[i][k] = W[(gate*H + 16w + i)][4kk + g]
+  // W_hh fragments.  MFMA slot (kk, g) carries k = 16*(kk/4) + 4g + kk%4 (any bijection works as long as the B
+  // operand uses the same one): a lane's four consecutive slots are then four CONSECUTIVE floats of its weight
+  // row, so the 442 KB matrix streams in as 16-byte loads in full 64-byte sectors (the natural k = 4kk+g mapping
+  // needs 4x the load instructions at 25 % sector efficiency, 40 us per launch).
   float wf[3][C::KREG_F];
   {
     const float* W = p.w_hh[dir];
 #pragma unroll
     for (int G = 0; G < 3; ++G)
 #pragma unroll
-      for (int kk = 0; kk < C::KS; ++kk) {
-        float v = W[(long)(G * H + 16 * w + i) * H + 4 * kk + g];
-        if (kk < C::KREG_F) wf[G][kk] = v;
-        else wlds[((G * C::KLDS_F + kk - C::KREG_F) * C::NW + w) * 64 + lane] = v;
+      for (int kq = 0; kq < C::KS / 4; ++kq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(W + (long)(G * H + 16 * w + i) * H + 16 * kq + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = 4 * kq + e;
+          if (kk < C::KREG_F) wf[G][kk] = v[e];
+          else wlds[((G * C::KLDS_F + kk - C::KREG_F) * C::NW + w) * 64 + lane] = v[e];
+        }
       }
   }
   for (int q = threadIdx.x; q < 3 * H; q += blockDim.x) bias[q] = p.b_hh[dir][q];
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(H * 4) void gru_fwd_kernel(GruFwdParams p) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int kk = kb + u;
-        b[u] = hb[(4 * kk + g) * SLICE + i];
+        b[u] = hb[(16 * (kk >> 2) + 4 * g + (kk & 3)) * SLICE + i];
         if (kk < C::KREG_F) {
           w0[u] = wf[0][kk]; w1[u] = wf[1][kk]; w2[u] = wf[2][kk];
         } else {

@@ -119,10 +119,11 @@ class Workspace:
 
 
 def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Tensor, R: Optional[torch.Tensor], *,
-            train: bool, stash: bool = False, seed: int = 0) -> torch.Tensor:
+            train: bool, stash: bool = False, seed: int = 0, ce=None) -> torch.Tensor:
     """Runs the forward kernels; returns ws.logits (B,C).  ``ws.lengths`` must already hold the int32 lengths.
     ``train`` turns the two dropouts on (p from cfg); ``stash`` keeps what ``backward`` needs (needs a
-    Workspace built with train=True)."""
+    Workspace built with train=True).  ``ce = (y_ptr, label_smoothing, denom, loss_ptr, correct_ptr)`` makes the
+    fused tail kernel also evaluate the loss and leave d(loss)/d(logits) in ``ws.d_logits``."""
     B, T, H, N = ws.B, ws.T, cfg.hidden, ws.B * ws.T
     s = L.stream()
     if stash and not ws.train:
@@ -161,21 +162,17 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
                    (l + 1) << 40, None, s)
             layer_in = ws.out_drop[l].data_ptr()
     top = ws.out[cfg.gru_layers - 1]
-    # ---- AttnPool + head
-    L.call("ss_attn_pool_fwd", top.data_ptr(), ws.lengths.data_ptr(), P["pool.score.weight"].data_ptr(),
-           P["pool.score.bias"].data_ptr(), B, T, 2 * H, ws.attn.data_ptr(), ws.pooled.data_ptr(), s)
-    L.call("ss_layernorm_fwd", ws.pooled.data_ptr(), P["head.0.weight"].data_ptr(), P["head.0.bias"].data_ptr(), B,
-           2 * H, cfg.ln_eps, ws.ln.data_ptr(), ws.xhat.data_ptr() if stash else None,
-           ws.rstd.data_ptr() if stash else None, s)
-    gemm(1, 1, B, cfg.head_mid, 2 * H, ws.ln.data_ptr(), 2 * H, P["head.1.weight"].data_ptr(), 2 * H,
-         ws.mid.data_ptr(), cfg.head_mid, bias=P["head.1.bias"].data_ptr(), relu=True)
-    mid = ws.mid
-    if train and cfg.head_dropout > 0.0:
-        L.call("ss_dropout", ws.mid.data_ptr(), ws.mid_drop.data_ptr(), B * cfg.head_mid, cfg.head_dropout, seed,
-               7 << 40, None, s)
-        mid = ws.mid_drop
-    gemm(1, 1, B, cfg.num_classes, cfg.head_mid, mid.data_ptr(), cfg.head_mid, P["head.4.weight"].data_ptr(),
-         cfg.head_mid, ws.logits.data_ptr(), cfg.num_classes, bias=P["head.4.bias"].data_ptr())
+    # ---- AttnPool + head (+ loss): one fused launch, a workgroup per clip
+    p_drop = cfg.head_dropout if train else 0.0
+    y_ptr, ls, denom, loss_ptr, correct_ptr = ce if ce is not None else (None, 0.0, 1.0, None, None)
+    L.call("ss_tail_fwd", top.data_ptr(), ws.lengths.data_ptr(), P["pool.score.weight"].data_ptr(),
+           P["pool.score.bias"].data_ptr(), P["head.0.weight"].data_ptr(), P["head.0.bias"].data_ptr(),
+           P["head.1.weight"].data_ptr(), P["head.1.bias"].data_ptr(), P["head.4.weight"].data_ptr(),
+           P["head.4.bias"].data_ptr(), y_ptr, B, T, 2 * H, cfg.head_mid, cfg.num_classes, cfg.ln_eps, p_drop, seed,
+           7 << 40, ls, denom, ws.attn.data_ptr() if stash else None, ws.xhat.data_ptr() if stash else None,
+           ws.rstd.data_ptr() if stash else None, ws.ln.data_ptr() if stash else None,
+           ws.mid.data_ptr() if stash else None, ws.mid_drop.data_ptr() if stash else None, ws.logits.data_ptr(),
+           ws.d_logits.data_ptr() if ce is not None else None, loss_ptr, correct_ptr, s)
     return ws.logits
 
 
@@ -187,27 +184,24 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
     B, T, H, N = ws.B, ws.T, cfg.hidden, ws.B * ws.T
     s = L.stream()
     C, MID = cfg.num_classes, cfg.head_mid
-    drop_head = train and cfg.head_dropout > 0.0
-    mid_used = ws.mid_drop if drop_head else ws.mid
-    # ---- head
-    gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, mid_used.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
-         accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
-    gemm(1, 0, B, MID, C, d_logits.data_ptr(), C, P["head.4.weight"].data_ptr(), MID, ws.d_mid.data_ptr(), MID)
-    # dropout mask (same seed/offset as the forward) and ReLU' in one pass
-    L.call("ss_dropout", ws.d_mid.data_ptr(), ws.d_mid.data_ptr(), B * MID, cfg.head_dropout if drop_head else 0.0,
-           seed, 7 << 40, ws.mid.data_ptr(), s)
-    gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
-         2 * H, accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
-    gemm(1, 0, B, 2 * H, MID, ws.d_mid.data_ptr(), MID, P["head.1.weight"].data_ptr(), 2 * H, ws.d_ln.data_ptr(),
-         2 * H)
-    L.call("ss_layernorm_bwd", ws.d_ln.data_ptr(), ws.xhat.data_ptr(), ws.rstd.data_ptr(),
-           P["head.0.weight"].data_ptr(), B, 2 * H, ws.d_pooled.data_ptr(), G["head.0.weight"].data_ptr(),
-           G["head.0.bias"].data_ptr(), s)
-    # ---- AttnPool -> d_out of the top GRU layer
+    p_drop = cfg.head_dropout if train else 0.0
     top = ws.out[cfg.gru_layers - 1]
-    L.call("ss_attn_pool_bwd", top.data_ptr(), ws.lengths.data_ptr(), P["pool.score.weight"].data_ptr(),
-           ws.attn.data_ptr(), ws.d_pooled.data_ptr(), B, T, 2 * H, ws.d_out.data_ptr(),
-           G["pool.score.weight"].data_ptr(), G["pool.score.bias"].data_ptr(), s)
+    # ---- tail: one fused launch down to d_out of the top GRU layer ...
+    L.call("ss_tail_bwd", top.data_ptr(), ws.lengths.data_ptr(), P["pool.score.weight"].data_ptr(),
+           P["head.0.weight"].data_ptr(), P["head.1.weight"].data_ptr(), P["head.4.weight"].data_ptr(),
+           ws.attn.data_ptr(), ws.xhat.data_ptr(), ws.rstd.data_ptr(), ws.mid.data_ptr(), d_logits.data_ptr(), B, T,
+           2 * H, MID, C, p_drop, seed, 7 << 40, ws.d_mid.data_ptr(), ws.d_out.data_ptr(),
+           G["head.0.weight"].data_ptr(), G["head.0.bias"].data_ptr(), G["pool.score.weight"].data_ptr(),
+           G["pool.score.bias"].data_ptr(), s)
+    # ... while the two Linear weight gradients (batched over the clips) go to the side stream
+    side = ws.side if USE_SIDE_STREAM else torch.cuda.current_stream()
+    ws.ev_fork.record()
+    with torch.cuda.stream(side):
+        side.wait_event(ws.ev_fork)
+        gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, ws.mid_drop.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
+             accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
+        gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
+             2 * H, accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
     # ---- GRU layers, top down
     for l in range(cfg.gru_layers - 1, -1, -1):
         K = cfg.in_dim if l == 0 else 2 * H

@@ -130,9 +130,8 @@ class Trainer:
         P = model._param_dict()
         if phase in ("fwd", "both"):
             ws.lengths.copy_(lengths.to(torch.int32), non_blocking=True)
-            logits = E.forward(P, cfg, ws, X, R, train=train, stash=True, seed=seed)
-            L.call("ss_ce_ls_fwd_bwd", logits.data_ptr(), y.data_ptr(), X.shape[0], cfg.num_classes, self.ls, denom,
-                   ws.d_logits.data_ptr(), self.scal.data_ptr(), self.correct.data_ptr(), L.stream())
+            E.forward(P, cfg, ws, X, R, train=train, stash=True, seed=seed,
+                      ce=(y.data_ptr(), self.ls, denom, self.scal.data_ptr(), self.correct.data_ptr()))
         if phase in ("bwd", "both"):
             E.backward(P, self.G, cfg, ws, X, R, ws.d_logits, train=train, seed=seed)
 

@@ -252,6 +252,86 @@ def test_layernorm(L):
     assert_close("ln dbeta", gbet, bg.grad, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,T,C", [(7, 11, 5), (33, 30, 10), (2, 90, 100)])
+def test_fused_tail_fwd_bwd(L, B, T, C):
+    """ss_tail_fwd / ss_tail_bwd (AttnPool + head + CE in one launch per direction) against the oracle's autograd."""
+    D, MID = 384, 128
+    import weights as W
+
+    g = torch.Generator().manual_seed(B * 7 + T)
+    sd = {k: v for k, v in W.make_state_dict(31 + B, 84, C, False).items() if k.startswith(("pool.", "head."))}
+    h = torch.randn(B, T, D, generator=g)
+    lengths = torch.randint(1, T + 1, (B,), generator=g)
+    lengths[0] = T
+    for b in range(B):
+        h[b, lengths[b]:] = 0
+    y = torch.randint(0, C, (B,), generator=g)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hg = h.clone().requires_grad_(True)
+    pooled = MR.attn_pool(hg, lengths, leaves)
+    logits_ref = MR.head(pooled, leaves)
+    loss_ref = MR.ce_label_smoothing(logits_ref, y)
+    loss_ref.backward()
+
+    P = {k: dev(v) for k, v in sd.items()}
+    h_d, len_d, y_d = dev(h), dev(lengths.to(torch.int32)), dev(y)
+    f = lambda *s: torch.empty(*s, device="cuda")
+    attn, xhat, rstd, ln, mid, mid_d = f(B, T), f(B, D), f(B), f(B, D), f(B, MID), f(B, MID)
+    logits, d_logits = f(B, C), f(B, C)
+    loss = torch.zeros(1, device="cuda")
+    correct = torch.zeros(1, device="cuda", dtype=torch.int32)
+    L.call("ss_tail_fwd", h_d.data_ptr(), len_d.data_ptr(), P["pool.score.weight"].data_ptr(), P["pool.score.bias"].data_ptr(),
+           P["head.0.weight"].data_ptr(), P["head.0.bias"].data_ptr(), P["head.1.weight"].data_ptr(),
+           P["head.1.bias"].data_ptr(), P["head.4.weight"].data_ptr(), P["head.4.bias"].data_ptr(), y_d.data_ptr(), B, T, D,
+           MID, C, 1e-5, 0.0, 0, 0, 0.05, float(B), attn.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), ln.data_ptr(),
+           mid.data_ptr(), mid_d.data_ptr(), logits.data_ptr(), d_logits.data_ptr(), loss.data_ptr(), correct.data_ptr(),
+           L.stream())
+    sync()
+    assert_close("tail logits", logits, logits_ref, atol=3e-6, rtol=1e-5)
+    assert abs(float(loss) - float(loss_ref)) < 3e-6 * max(1.0, abs(float(loss_ref)))
+    assert int(correct) == int((logits_ref.argmax(1) == y).sum())
+    assert torch.equal(mid, mid_d)  # p = 0
+    # inference form: no stash, no loss, same logits
+    logits2 = f(B, C)
+    L.call("ss_tail_fwd", h_d.data_ptr(), len_d.data_ptr(), P["pool.score.weight"].data_ptr(), P["pool.score.bias"].data_ptr(),
+           P["head.0.weight"].data_ptr(), P["head.0.bias"].data_ptr(), P["head.1.weight"].data_ptr(),
+           P["head.1.bias"].data_ptr(), P["head.4.weight"].data_ptr(), P["head.4.bias"].data_ptr(), None, B, T, D, MID, C,
+           1e-5, 0.0, 0, 0, 0.0, 1.0, None, None, None, None, None, None, logits2.data_ptr(), None, None, None, L.stream())
+    sync()
+    assert torch.equal(logits2, logits)
+
+    d_mid, d_h = f(B, MID), torch.full((B, T, D), 3.0, device="cuda")
+    gg, gb, gw, gs = (torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"),
+                      torch.zeros(1, device="cuda"))
+    L.call("ss_tail_bwd", h_d.data_ptr(), len_d.data_ptr(), P["pool.score.weight"].data_ptr(), P["head.0.weight"].data_ptr(),
+           P["head.1.weight"].data_ptr(), P["head.4.weight"].data_ptr(), attn.data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+           mid.data_ptr(), d_logits.data_ptr(), B, T, D, MID, C, 0.0, 0, 0, d_mid.data_ptr(), d_h.data_ptr(), gg.data_ptr(),
+           gb.data_ptr(), gw.data_ptr(), gs.data_ptr(), L.stream())
+    sync()
+    mask = (torch.arange(T).unsqueeze(0) < lengths.unsqueeze(1)).unsqueeze(-1)
+    scale = float(hg.grad.abs().max())
+    assert_close("tail d_h", d_h, hg.grad * mask, atol=2e-5 * scale, rtol=1e-4)
+    for name, got, key in (("d gamma", gg, "head.0.weight"), ("d beta", gb, "head.0.bias"), ("d w_score", gw, "pool.score.weight")):
+        ref = leaves[key].grad.reshape(-1)
+        assert_close(name, got, ref, atol=2e-5 * float(ref.abs().max()) + 1e-8, rtol=1e-4)
+    # the two Linear weight gradients are GEMMs over what the kernels stashed
+    dW1 = d_mid.t() @ ln
+    dW4 = d_logits.t() @ mid_d
+    assert_close("dW1 via stash", dW1, leaves["head.1.weight"].grad, atol=2e-5 * float(leaves["head.1.weight"].grad.abs().max()), rtol=1e-4)
+    assert_close("dW4 via stash", dW4, leaves["head.4.weight"].grad, atol=2e-5 * float(leaves["head.4.weight"].grad.abs().max()), rtol=1e-4)
+    # dropout in the fused tail draws the ss_dropout stream
+    if B == 7:
+        L.call("ss_tail_fwd", h_d.data_ptr(), len_d.data_ptr(), P["pool.score.weight"].data_ptr(), P["pool.score.bias"].data_ptr(),
+               P["head.0.weight"].data_ptr(), P["head.0.bias"].data_ptr(), P["head.1.weight"].data_ptr(),
+               P["head.1.bias"].data_ptr(), P["head.4.weight"].data_ptr(), P["head.4.bias"].data_ptr(), None, B, T, D, MID,
+               C, 1e-5, 0.2, 5, 7 << 40, 0.0, 1.0, attn.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), ln.data_ptr(),
+               mid.data_ptr(), mid_d.data_ptr(), logits2.data_ptr(), None, None, None, L.stream())
+        ref_d = torch.empty_like(mid)
+        L.call("ss_dropout", mid.data_ptr(), ref_d.data_ptr(), B * MID, 0.2, 5, 7 << 40, None, L.stream())
+        sync()
+        assert torch.equal(ref_d, mid_d) and not torch.equal(mid, mid_d)
+
+
 @pytest.mark.parametrize("B,C", [(8, 5), (300, 10), (3, 100)])
 def test_ce_label_smoothing(L, B, C):
     g = torch.Generator().manual_seed(B + C)
