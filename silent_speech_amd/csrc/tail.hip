@@ -124,14 +124,23 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
   }
   if (p.rstd && tid == 0) p.rstd[b] = rs;
   __syncthreads();
-  // ---- Linear(D -> MID) + ReLU + Dropout: a wave per output row, lanes across the row (coalesced weight reads)
-  for (int o = wv; o < MID; o += 4) {
-    float acc = 0.f;
-    const float* wr = p.w1 + (long)o * D;
-    for (int d = lane; d < D; d += 64) acc += wr[d] * lnv[d];
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float a = fmaxf(acc + p.b1[o], 0.f);
+  // ---- Linear(D -> MID) + ReLU + Dropout: a wave per output row, lanes across the row (coalesced weight reads);
+  // four rows at a time so the four shuffle-reduction chains interleave
+  for (int o0 = 4 * wv; o0 < MID; o0 += 16) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = lane; d < D; d += 64) {
+      const float x = lnv[d];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (o0 + u < MID) acc[u] += p.w1[(long)(o0 + u) * D + d] * x;
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], sft, 64);
+    if (lane < 4 && o0 + lane < MID) {
+      const int o = o0 + lane;
+      const float a = fmaxf((lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]) + p.b1[o], 0.f);
       const float ad = a * drop_scale((long)b * MID + o, p.drop_p, p.seed, p.offset);
       midv[o] = ad;
       if (p.mid) p.mid[(long)b * MID + o] = a;

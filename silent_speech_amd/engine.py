@@ -82,7 +82,8 @@ class Workspace:
         u8 = dict(device=device, dtype=torch.uint8)
         self.lengths = torch.empty(B, device=device, dtype=torch.int32)
         # weight-gradient GEMMs run on a side stream next to the (32-CU) recurrence of the layer below
-        self.side = torch.cuda.Stream(device=device) if train else None
+        # (lowest priority: it must never delay the dispatch of the critical-path kernels on the caller's stream)
+        self.side = torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[0]) if train else None
         self.ev_fork = torch.cuda.Event() if train else None
         self.ev_join = torch.cuda.Event() if train else None
         self.ev_cnn_fwd = torch.cuda.Event() if train else None  # recorded after the ROI-CNN forward (micro-batch stagger)
