@@ -84,8 +84,17 @@ __global__ __launch_bounds__(256) void gru_bias_grad_kernel(const float* __restr
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rr = threadIdx.x >> 6;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(N, r0 + rows_per_block);
   const float* A = dG + (long)dir * N * 4 * H;
-  float acc = 0.f;
-  for (int r = r0 + rr; r < r1; r += 4) acc += A[(long)r * 4 * H + c];
+  float acc = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;  // four loads in flight per lane
+  int r = r0 + rr;
+  for (; r + 12 < r1; r += 16) {
+    const float* a = A + (long)r * 4 * H + c;
+    acc += a[0];
+    acc1 += a[(long)16 * H];
+    acc2 += a[(long)32 * H];
+    acc3 += a[(long)48 * H];
+  }
+  for (; r < r1; r += 4) acc += A[(long)r * 4 * H + c];
+  acc += acc1 + acc2 + acc3;
   red[rr][threadIdx.x & 63] = acc;
   __syncthreads();
   if (rr == 0) {
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256) void gru_bias_grad_kernel(const float* __restr
 extern "C" int ss_gru_bias_grad(const float* d_g, int N, int H, float* g_bih_f, float* g_bhh_f, float* g_bih_r,
                                 float* g_bhh_r, ss_stream_t stream) {
   SS_REQUIRE(d_g && g_bih_f && g_bhh_f && g_bih_r && g_bhh_r && N > 0 && H > 0 && (H % 16) == 0, SS_ERR_ARG);
-  const int rpb = 512;
+  const int rpb = 128;
   dim3 grid(4 * H / 64, ceil_div(N, rpb), 2);
   hipLaunchKernelGGL(gru_bias_grad_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), d_g, N, H, rpb, g_bih_f,
                      g_bhh_f, g_bih_r, g_bhh_r);

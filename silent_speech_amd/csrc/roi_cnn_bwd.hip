@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         const int tile2 = tile + NWV;
         const bool two = tile2 < tiles;
         const int pp0 = 16 * tile + i, pp1 = 16 * (two ? tile2 : tile) + i;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0, acc0b = acc0, acc1b = acc0;  // 4 independent MFMA chains
         const float* ap0 = dy3h + g * P2 + (pp0 / W4 + 2) * S2 + (pp0 % W4 + 2);
         const float* ap1 = dy3h + g * P2 + (pp1 / W4 + 2) * S2 + (pp1 % W4 + 2);
 #pragma unroll 1
@@ -325,12 +325,16 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           }
           SS_SCHED_FENCE();
 #pragma unroll
-          for (int j = 0; j < 6; ++j) {
+          for (int j = 0; j < 6; j += 2) {
             acc0 = mfma16(a0[j], b[j], acc0);
             acc1x = mfma16(a1[j], b[j], acc1x);
+            acc0b = mfma16(a0[j + 1], b[j + 1], acc0b);
+            acc1b = mfma16(a1[j + 1], b[j + 1], acc1b);
           }
           SS_SCHED_FENCE();
         }
+        acc0 += acc0b;
+        acc1x += acc1b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pq = 16 * tile + 4 * g + r;
@@ -453,31 +457,44 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         const int chb = two ? ch2 : ch;
         const int y0_ = 2 * (ch / xt_n), x0_ = 16 * (ch % xt_n) + i;
         const int y1_ = 2 * (chb / xt_n), x1_ = 16 * (chb % xt_n) + i;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0;
-#pragma unroll 1
-        for (int tk = 0; tk < 12; ++tk) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0, acc0b = acc0, acc1b = acc0;  // 4 independent MFMA chains
+        // software pipeline: the 12 operand reads of tap tk+1 are in flight while the 8 MFMAs of tap tk issue
+        float b[2][4], a0[2][4], a1[2][4];
+        bool in0[2], in1[2];
+        auto load_tap = [&](int tk, int slot) {
           const int t = tk / 3, kx = tk % 3;
           const int sy0 = y0_ - 1 + t, sx0 = x0_ + 1 - kx, sy1 = y1_ - 1 + t, sx1 = x1_ + 1 - kx;
-          const bool in0 = sy0 >= 0 && sy0 < H2 && sx0 >= 0 && sx0 < W2;
-          const bool in1 = sy1 >= 0 && sy1 < H2 && sx1 >= 0 && sx1 < W2;
-          const float* ap0 = dy2 + g * PD + (in0 ? sy0 * W2 + sx0 : 0);
-          const float* ap1 = dy2 + g * PD + (in1 ? sy1 * W2 + sx1 : 0);
+          in0[slot] = sy0 >= 0 && sy0 < H2 && sx0 >= 0 && sx0 < W2;
+          in1[slot] = sy1 >= 0 && sy1 < H2 && sx1 >= 0 && sx1 < W2;
+          const float* ap0 = dy2 + g * PD + (in0[slot] ? sy0 * W2 + sx0 : 0);
+          const float* ap1 = dy2 + g * PD + (in1[slot] ? sy1 * W2 + sx1 : 0);
           const float* bt = w2t + (tk * 16 + g) * 16 + i;
-          float b[4], a0[4], a1[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            b[j] = bt[4 * j * 16];
-            a0[j] = ap0[4 * j * PD];
-            a1[j] = ap1[4 * j * PD];
+            b[slot][j] = bt[4 * j * 16];
+            a0[slot][j] = ap0[4 * j * PD];
+            a1[slot][j] = ap1[4 * j * PD];
           }
-          SS_SCHED_FENCE();
+        };
+        load_tap(0, 0);
+#pragma unroll 1
+        for (int tk = 0; tk < 12; tk += 2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc0 = mfma16(in0 ? a0[j] : 0.f, b[j], acc0);
-            acc1x = mfma16(in1 ? a1[j] : 0.f, b[j], acc1x);
+          for (int u = 0; u < 2; ++u) {  // static ping-pong between the two register sets
+            if (tk + u + 1 < 12) load_tap(tk + u + 1, u ^ 1);
+            SS_SCHED_FENCE();
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+              acc0 = mfma16(in0[u] ? a0[u][j] : 0.f, b[u][j], acc0);
+              acc1x = mfma16(in1[u] ? a1[u][j] : 0.f, b[u][j], acc1x);
+              acc0b = mfma16(in0[u] ? a0[u][j + 1] : 0.f, b[u][j + 1], acc0b);
+              acc1b = mfma16(in1[u] ? a1[u][j + 1] : 0.f, b[u][j + 1], acc1b);
+            }
+            SS_SCHED_FENCE();
           }
-          SS_SCHED_FENCE();
         }
+        acc0 += acc0b;
+        acc1x += acc1b;
         // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0 and leave da1 IN PLACE of
         // a1 (each cell is read and rewritten by exactly one lane; S3 finished with a1 before the barrier above).
 #pragma unroll

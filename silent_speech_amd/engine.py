@@ -25,6 +25,7 @@ from . import _lib as L
 INT_MAX = 2**31 - 1
 # bench.py turns this off for its per-kernel timing pass: HIP-event pairs only bracket a kernel's own run time when
 # every launch sits on one stream
+JOIN_BEFORE_CNN_BWD = True
 USE_SIDE_STREAM = True
 
 
@@ -272,6 +273,12 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         Hh, Ww = ws.roi_hw
         if d_X is not None:
             L.call("ss_copy_rows_f32", ws.dZ.data_ptr(), cfg.in_dim, d_X.data_ptr(), cfg.x_dim, N, cfg.x_dim, s)
+        if USE_SIDE_STREAM and JOIN_BEFORE_CNN_BWD:
+            # the persistent ROI-CNN kernel takes every CU for ~1 ms: weight-gradient GEMMs still queued on the side
+            # stream at that point would only finish after it (measured: a 180 us tail), so let them drain first --
+            # they run beside the d layer_in GEMM above and cost the critical path a few tens of microseconds
+            ws.ev_join.record(ws.side)
+            torch.cuda.current_stream().wait_event(ws.ev_join)
         names = ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight", "roi_cnn.net.3.bias",
                  "roi_cnn.net.6.weight", "roi_cnn.net.6.bias", "roi_cnn.fc.weight", "roi_cnn.fc.bias")
         L.call("ss_roi_cnn_bwd", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
