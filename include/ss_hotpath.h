@@ -135,16 +135,24 @@ int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_st
  * lengths (B) int32, 1 <= len <= T
  * out     (B,T,2H): forward states in [0,H), reverse in [H,2H); zeros for t >= len
  * save    (2, B*T, 4, H) or NULL: r, z, n, W_hn h + b_hn for the backward pass
+ * sync_ws NULL, or ss_gru_sync_bytes() bytes of device memory the caller zeroed ONCE and then leaves alone: with it,
+ *         a batch small enough to leave most CUs idle runs each (16-clip slice, direction) on several CUs that
+ *         exchange the state through `out` every step (same results, lower latency).  Launches that may run
+ *         concurrently (different streams) need different sync_ws; launches on one stream can share one.
  * H in {64, 192} */
 int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
                const float* b_hh_r, const int32_t* lengths, int B, int T, int H, float* out, float* save,
-               ss_stream_t stream);
+               void* sync_ws, ss_stream_t stream);
+
+/* bytes of sync_ws the multi-CU recurrence needs for this shape; 0 = the shape always takes the one-CU-per-slice
+ * kernels (pass NULL). */
+int ss_gru_sync_bytes(int B, int T, int H, long* bytes);
 
 /* BPTT.  d_out (B,T,2H) gradient of the layer output; d_g (2, B*T, 4, H) receives
  * d(gi_r), d(gi_z), d(gi_n) and d(W_hn h + b_hn) = d(gi_n) * r; rows with t >= len are zero. */
 int ss_gru_bwd(const float* d_out, const float* out, const float* save, const float* w_hh_f,
                const float* w_hh_r, const int32_t* lengths, int B, int T, int H, float* d_g,
-               ss_stream_t stream);
+               void* sync_ws, ss_stream_t stream);
 
 /* bias gradients of one GRU layer from d_g: g_bih_* (3H) += colsum(d_g[dir][:, 0:3H]),
  * g_bhh_* (3H) += colsum(d_g[dir][:, 0:2H] | d_g[dir][:, 3H:4H]).  N = B*T rows per direction. */

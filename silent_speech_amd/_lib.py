@@ -35,8 +35,9 @@ SIGNATURES = {
     "ss_gemm_f32_batched": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i,
                             _l, _l, _l, _l, _l, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
-    "ss_gru_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
-    "ss_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "ss_gru_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "ss_gru_sync_bytes": [_i, _i, _i, _vp],
+    "ss_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "ss_gru_bias_grad": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ss_attn_pool_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "ss_attn_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -80,6 +81,15 @@ def cnn_stash_sizes(H: int, W: int):
     if st != 0:
         raise RuntimeError(f"ROI size {H}x{W} is not one the CNN kernels are built for")
     return a1.value, a2.value, i1.value
+
+
+def gru_sync_bytes(B: int, T: int, H: int) -> int:
+    """Bytes of the zero-initialised sync workspace the multi-CU recurrence wants for this shape (0: not used)."""
+    n = C.c_long(0)
+    st = load().ss_gru_sync_bytes(B, T, H, C.byref(n))
+    if st != 0:
+        raise RuntimeError(f"ss_gru_sync_bytes({B}, {T}, {H}) -> {st}")
+    return n.value
 
 
 def ptr(t):

@@ -270,9 +270,20 @@ __global__ __launch_bounds__(H * 4) void gru_bwd_kernel(GruBwdParams p) {
 
 }  // namespace
 
+STAMP_TABLE(ss_debug_stamps_gru)
+
+#include "gru_split.h"
+
+extern "C" int ss_gru_sync_bytes(int B, int T, int H, long* bytes) {
+  SS_REQUIRE(bytes && B > 0 && T > 0 && H > 0, SS_ERR_ARG);
+  const int P = gru_split_parts(B, T, H);
+  *bytes = P ? SYNC_HDR_WORDS * 4L + (gru_fwd_granules(B, H) + gru_bwd_granules(B, H, P)) * 8 : 0;
+  return SS_OK;
+}
+
 extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
                           const float* b_hh_r, const int32_t* lengths, int B, int T, int H, float* out, float* save,
-                          ss_stream_t stream) {
+                          void* sync_ws, ss_stream_t stream) {
   SS_REQUIRE(gi && w_hh_f && w_hh_r && b_hh_f && b_hh_r && lengths && out, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0, SS_ERR_ARG);
   GruFwdParams p;
@@ -280,6 +291,15 @@ extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_h
   p.lengths = lengths; p.out = out; p.save = save; p.B = B; p.T = T;
   dim3 grid(ceil_div(B, SLICE), 2);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int P = sync_ws ? gru_split_parts(B, T, H) : 0;
+  if (P) {
+    dim3 sgrid(2 * ceil_div(B, SLICE) * P);
+    unsigned* sy = static_cast<unsigned*>(sync_ws);
+    u64* hx = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
+    if (H == 192) hipLaunchKernelGGL((gru_split_fwd_kernel<192, 6>), sgrid, dim3(256), 0, s, p, sy, hx);
+    else hipLaunchKernelGGL((gru_split_fwd_kernel<64, 2>), sgrid, dim3(256), 0, s, p, sy, hx);
+    return ss_launch_status();
+  }
   if (H == 192) hipLaunchKernelGGL(gru_fwd_kernel<192>, grid, dim3(768), 0, s, p);
   else if (H == 64) hipLaunchKernelGGL(gru_fwd_kernel<64>, grid, dim3(256), 0, s, p);
   else return SS_ERR_UNSUPPORTED;
@@ -288,7 +308,7 @@ extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_h
 
 extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* save, const float* w_hh_f,
                           const float* w_hh_r, const int32_t* lengths, int B, int T, int H, float* d_g,
-                          ss_stream_t stream) {
+                          void* sync_ws, ss_stream_t stream) {
   SS_REQUIRE(d_out && out && save && w_hh_f && w_hh_r && lengths && d_g, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0, SS_ERR_ARG);
   GruBwdParams p;
@@ -296,6 +316,15 @@ extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* sav
   p.lengths = lengths; p.d_g = d_g; p.B = B; p.T = T;
   dim3 grid(ceil_div(B, SLICE), 2);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int P = sync_ws ? gru_split_parts(B, T, H) : 0;
+  if (P) {
+    dim3 sgrid(2 * ceil_div(B, SLICE) * P);
+    unsigned* sy = static_cast<unsigned*>(sync_ws);
+    u64* xg = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS) + gru_fwd_granules(B, H);
+    if (H == 192) hipLaunchKernelGGL((gru_split_bwd_kernel<192, 6>), sgrid, dim3(256), 0, s, p, sy, xg);
+    else hipLaunchKernelGGL((gru_split_bwd_kernel<64, 2>), sgrid, dim3(256), 0, s, p, sy, xg);
+    return ss_launch_status();
+  }
   if (H == 192) hipLaunchKernelGGL(gru_bwd_kernel<192>, grid, dim3(768), 0, s, p);
   else if (H == 64) hipLaunchKernelGGL(gru_bwd_kernel<64>, grid, dim3(256), 0, s, p);
   else return SS_ERR_UNSUPPORTED;

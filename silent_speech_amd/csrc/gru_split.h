@@ -1,0 +1,411 @@
+// Latency form of the masked BiGRU recurrence: one (16-clip slice, direction) spread over P compute units.
+//
+// The single-workgroup kernels in gru.hip keep the whole 3H x H matrix W_hh on one CU, so a time step can never be
+// shorter than 3H*H*16*2 flop / (one CU's MFMA rate) = 5.8 us at H = 192 -- and the recurrence is a chain of T such
+// steps with nothing else to do on the other 224 CUs.  Here part p of P owns hidden units [p*H/P, (p+1)*H/P):
+//   forward   it holds those rows of W_hh (all three gates), multiplies them by the FULL previous state and
+//             publishes its slice of the new state (an all-gather of 16 x H floats per step);
+//   backward  the transposed product dh_prev = W_hh^T d_pre is split over its CONTRACTION index instead: the part
+//             multiplies by the 3*H/P pre-activation gradients of its own units (no gather needed), gets a partial
+//             dh_prev for ALL H units and publishes it; every part sums the P slices of its own units (a
+//             reduce-scatter, 16 x H floats into each workgroup per step where an all-gather of d_pre would pull
+//             16 x 3H through every one).
+//
+// Exchange: 8-byte {value, tag} granules written with ONE agent-scope (sc1, write-through) store each and swept
+// with agent-scope loads until every tag matches -- the data is its own flag, so a hop costs one store->load
+// round trip and needs no fence, no drain and no barrier on the producer side (MI355X_MICROARCH.md, hand-off price
+// list: "handoff-1to1" vs "handoff-flag"; measured here: 5.3 us/step with flags).  tag =
+// (generation << 10) + step + 1; the generation lives in the sync header and is bumped by the last workgroup of
+// every launch, so granules left by an earlier launch -- or an earlier replay of a captured graph -- never match and
+// nothing has to be cleared between launches.  Buffers alternate with the step parity: a slot is rewritten two
+// steps later, which its reader has provably left (it had to publish the step in between first).
+//
+// Progress: the P partners are consecutive workgroups of the grid, the launcher only picks this form when the whole
+// grid is co-resident (<= 240 workgroups of 4 waves), and every wait is bounded -- a lost partner poisons the output
+// with NaN and counts an error in the sync header instead of hanging the GPU.
+//
+// sync_ws layout: [0] generation, [1] finished workgroups of the running launch, [2] sweep time-outs ever seen,
+// [.. 64) pad | forward granules [2][pairs][16][H] u64 | backward granules [2][pairs][P dest][P src][16][H/P] u64.
+// The owner zeroes it once; after that the kernels keep it consistent.
+#pragma once
+
+namespace {
+
+constexpr int SYNC_HDR_WORDS = 64;
+constexpr int SPLIT_MAX_WGS = 240;   // co-residency bound (256 CUs, one 4-wave workgroup each, some slack)
+constexpr int SPLIT_MAX_T = 1022;
+
+#define SS_AGENT __HIP_MEMORY_SCOPE_AGENT
+typedef unsigned long long u64;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int AUX_SC1 = 16;  // cache-policy operand of the raw buffer intrinsics: bit 4 = sc1 (agent scope)
+
+__device__ __forceinline__ rsrc_t granule_rsrc(u64* base, long granules) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(granules * 8), 0x00020000);
+}
+
+// Two adjacent granules in ONE 16-byte write-through store (each 8-byte half lands whole; a 16-byte sc1 store costs
+// the fabric what an 8-byte one does).  `pair` = index of the granule pair.
+__device__ __forceinline__ void store_granule_pair(rsrc_t rs, int pair, unsigned tag, float v0, float v1) {
+  const u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  __builtin_amdgcn_raw_buffer_store_b128(d, rs, pair * 16, 0, AUX_SC1);
+}
+
+// One wave re-reads its N granule pairs (pair stride 256: the whole workgroup sweeps a contiguous run) until every
+// tag matches.
+template <int N>
+__device__ __forceinline__ bool sweep_granules(rsrc_t rs, int pair0, unsigned tag, float (&v)[2 * N], unsigned* errors, int lane) {
+  for (int spins = 0;;) {
+    bool ok = true;
+    asm volatile("" ::: "memory");  // every pass really loads again
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, (pair0 + 256 * k) * 16, 0, AUX_SC1);
+      v[2 * k] = __uint_as_float(x[0]);
+      v[2 * k + 1] = __uint_as_float(x[2]);
+      ok &= x[1] == tag && x[3] == tag;
+    }
+    if (__all(ok)) return true;
+    if (++spins > (1 << 20)) {  // ~1 s of sweeping: a partner is gone
+      if (lane == 0) atomicAdd(errors, 1u);
+      return false;
+    }
+  }
+}
+
+__device__ __forceinline__ void finish_launch(unsigned* sync, unsigned gen) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = atomicAdd(&sync[1], 1u);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, SS_AGENT);
+      __hip_atomic_store(&sync[0], gen + 1u, __ATOMIC_RELEASE, SS_AGENT);
+    }
+  }
+}
+
+template <int H, int P>
+struct SplitCfg {
+  static constexpr int UP = H / P;          // hidden units per part
+  static constexpr int UT = UP / 16;        // 16-unit MFMA tiles per part
+  static constexpr int KSPLIT = 4 / UT;     // forward: waves sharing one tile split the contraction
+  static_assert(UP == 32 && UT * KSPLIT == 4, "a part is two unit tiles");
+  static constexpr int QF = H / 16 / KSPLIT;       // 16-wide k groups per wave, forward (K = H)
+  static_assert(QF * 16 * KSPLIT == H, "k split");
+  static constexpr int RED = (KSPLIT - 1) * UT * 3 * 64 * 4;
+  static constexpr int NGP = SLICE * H / 512;      // granule pairs per thread in a sweep of a 16 x H panel
+};
+
+// grid: pairs * P workgroups, blockIdx.x = pair * P + part, pair = slice * 2 + direction
+template <int H, int P>
+__global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsigned* sync, u64* hx) {
+  using C = SplitCfg<H, P>;
+  constexpr int LDH = H + 4;  // panel row stride: 16-byte aligned rows, clips 4 banks apart
+  __shared__ __attribute__((aligned(16))) float red[C::RED];
+  __shared__ __attribute__((aligned(16))) float hpan[SLICE * LDH];  // previous state of the slice, [clip][unit]
+  __shared__ unsigned s_gen;
+  const int part = blockIdx.x % P, pair = blockIdx.x / P, pairs = gridDim.x / P;
+  const int dir = pair & 1, b0 = (pair >> 1) * SLICE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ut = w % C::UT, kh = w / C::UT;
+  const bool owner = kh == 0;
+  const int i = lane & 15, g = lane >> 4;
+  const int j0 = part * C::UP + 16 * ut + 4 * g;  // first of this lane's 4 hidden units (D rows 4g..4g+3)
+  const int clip = b0 + i;
+  const bool clip_ok = clip < p.B;
+  const int len = clip_ok ? p.lengths[clip] : 0;
+  const int T = p.T;
+  if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
+
+  // A fragments: rows = this tile's units of gate G, slots (q, e) carry k = 16*(kh*QF + q) + 4g + e
+  float wf[3][4 * C::QF];
+  {
+    const float* W = p.w_hh[dir];
+#pragma unroll
+    for (int G = 0; G < 3; ++G)
+#pragma unroll
+      for (int q = 0; q < C::QF; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(W + (long)(G * H + part * C::UP + 16 * ut + i) * H +
+                                                        16 * (kh * C::QF + q) + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wf[G][4 * q + e] = v[e];
+      }
+  }
+  f32x4 br = {0.f, 0.f, 0.f, 0.f}, bz = br, bn = br;
+  if (owner) {
+    br = *reinterpret_cast<const f32x4*>(p.b_hh[dir] + j0);
+    bz = *reinterpret_cast<const f32x4*>(p.b_hh[dir] + H + j0);
+    bn = *reinterpret_cast<const f32x4*>(p.b_hh[dir] + 2 * H + j0);
+  }
+  __syncthreads();
+  const unsigned gen = s_gen;
+  const unsigned base = (gen & 0x3FFFFFu) << 10;
+
+  f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+  const long dir_off = (long)dir * p.B * T;
+  const rsrc_t hrs = granule_rsrc(hx, 2L * pairs * SLICE * H);
+  bool dead = false;
+  STAMP_DECL;
+  for (int s = 0; s < T; ++s) {
+    STAMP(15);
+    const int t = dir ? (T - 1 - s) : s;
+    const long frame = (long)clip * T + t;
+    const bool valid = t < len;
+    // input-projection gates of this step: independent of the recurrence, in flight during the sweep below
+    f32x4 gr = {0.f, 0.f, 0.f, 0.f}, gz = gr, gn = gr;
+    if (owner && valid) {
+      const float* gp = p.gi + (dir_off + frame) * (3 * H) + j0;
+      gr = *reinterpret_cast<const f32x4*>(gp);
+      gz = *reinterpret_cast<const f32x4*>(gp + H);
+      gn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+    }
+    f32x4 ar = br, az = bz, an = bn;
+    if (s > 0) {
+      // the full previous state of the slice, swept ONCE per workgroup into an LDS panel (what a step publishes is
+      // what it emits: a masked step emits what it keeps -- zeros in the reverse direction -- and the forward
+      // direction never uses a frozen state again)
+      float hv[2 * C::NGP];
+      const int hr = (((s - 1) & 1) * pairs + pair) * (SLICE * H / 2) + threadIdx.x;
+      if (!dead) dead = !sweep_granules<C::NGP>(hrs, hr, base + (unsigned)s, hv, &sync[2], lane);
+      STAMP(0);
+#pragma unroll
+      for (int k = 0; k < C::NGP; ++k) {
+        const int idx = 2 * (threadIdx.x + 256 * k);
+        *reinterpret_cast<float2*>(&hpan[(idx / H) * LDH + idx % H]) = float2{hv[2 * k], hv[2 * k + 1]};
+      }
+      __syncthreads();
+      STAMP(1);
+      f32x4 hq[C::QF];
+#pragma unroll
+      for (int q = 0; q < C::QF; ++q) hq[q] = *reinterpret_cast<const f32x4*>(&hpan[i * LDH + 16 * (kh * C::QF + q) + 4 * g]);
+#pragma unroll
+      for (int q = 0; q < C::QF; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ar = mfma16(wf[0][4 * q + e], hq[q][e], ar);
+          az = mfma16(wf[1][4 * q + e], hq[q][e], az);
+          an = mfma16(wf[2][4 * q + e], hq[q][e], an);
+        }
+    }
+    STAMP(2);
+    if (C::KSPLIT > 1) {  // sum the k slices of a tile in its owner wave
+      if (!owner) {
+        f32x4* r4 = reinterpret_cast<f32x4*>(red) + (((kh - 1) * C::UT + ut) * 3) * 64 + lane;
+        r4[0] = ar; r4[64] = az; r4[128] = an;
+      }
+      __syncthreads();
+      if (owner) {
+#pragma unroll
+        for (int k2 = 1; k2 < C::KSPLIT; ++k2) {
+          const f32x4* r4 = reinterpret_cast<const f32x4*>(red) + (((k2 - 1) * C::UT + ut) * 3) * 64 + lane;
+          ar += r4[0]; az += r4[64]; an += r4[128];
+        }
+      }
+    }
+    STAMP(3);
+    if (owner) {
+      f32x4 r, z, n, hn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r[e] = sigmoid_f(gr[e] + ar[e]);
+        z[e] = sigmoid_f(gz[e] + az[e]);
+        n[e] = tanh_f(gn[e] + r[e] * an[e]);
+        hn[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
+      }
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        hp = hn;
+        o = hn;
+      }
+      if (s + 1 < T) {  // publish (padding clips too: the partners sweep whole panels)
+        const int hw = ((((s & 1) * pairs + pair) * SLICE + i) * H + j0) / 2;
+        store_granule_pair(hrs, hw, base + (unsigned)s + 1u, o[0], o[1]);
+        store_granule_pair(hrs, hw + 1, base + (unsigned)s + 1u, o[2], o[3]);
+      }
+      STAMP(4);
+      if (clip_ok) {
+        *reinterpret_cast<f32x4*>(p.out + frame * (2 * H) + dir * H + j0) = o;
+        if (p.save && valid) {
+          float* sp = p.save + (dir_off + frame) * (4 * H) + j0;
+          *reinterpret_cast<f32x4*>(sp) = r;
+          *reinterpret_cast<f32x4*>(sp + H) = z;
+          *reinterpret_cast<f32x4*>(sp + 2 * H) = n;
+          *reinterpret_cast<f32x4*>(sp + 3 * H) = an;
+        }
+      }
+    }
+  }
+  if (dead && lane == 0) p.out[0] = __builtin_nanf("");
+  STAMP_FLUSH();
+  finish_launch(sync, gen);
+}
+
+// xg: [2 step parity][pairs][P dest parts][P source parts][16 clips][UP]  partial dh_prev granules
+template <int H, int P>
+__global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsigned* sync, u64* xg) {
+  using C = SplitCfg<H, P>;
+  constexpr int KR = 3 * C::UP;        // contraction length of this part: its r | z | n rows
+  constexpr int QK = KR / 16;          // 16-wide k groups
+  constexpr int NT = H / 16 / 4;       // output unit tiles per wave
+  constexpr int LDP = KR + 4;
+  constexpr int NGP = P;               // granule pairs per thread: 16 * UP / 2 = 256 position pairs x P sources
+  static_assert(QK * 16 == KR && NT * 64 == H && SLICE * C::UP == 512, "tile split");
+  __shared__ __attribute__((aligned(16))) float dpan[SLICE * LDP];     // this part's d_pre, [clip][local row]
+  __shared__ __attribute__((aligned(16))) float dsum[SLICE * C::UP];   // summed dh_prev of this part's units
+  __shared__ unsigned s_gen;
+  const int part = blockIdx.x % P, pair = blockIdx.x / P, pairs = gridDim.x / P;
+  const int dir = pair & 1, b0 = (pair >> 1) * SLICE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ut = w % C::UT;
+  const bool owner = w < C::UT;        // owner waves carry dh of one unit tile of this part
+  const int i = lane & 15, g = lane >> 4;
+  const int j0 = part * C::UP + 16 * ut + 4 * g;
+  const int clip = b0 + i;
+  const bool clip_ok = clip < p.B;
+  const int len = clip_ok ? p.lengths[clip] : 0;
+  const int T = p.T;
+  if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
+
+  // A fragments: A[i = output unit 16*(NT*w + nt) + i][slot (q, e)] = W[row(16q + 4g + e)][unit], local row
+  // kk = G * UP + u  <->  W row G*H + part*UP + u
+  float wf[NT][4 * QK];
+  {
+    const float* W = p.w_hh[dir];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < QK; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = 16 * q + 4 * g + e;
+          wf[nt][4 * q + e] = W[(long)((kk / C::UP) * H + part * C::UP + kk % C::UP) * H + 16 * (NT * w + nt) + i];
+        }
+  }
+  __syncthreads();
+  const unsigned gen = s_gen;
+  const unsigned base = (gen & 0x3FFFFFu) << 10;
+
+  f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+  const long dir_off = (long)dir * p.B * T;
+  const rsrc_t xrs = granule_rsrc(xg, 2L * pairs * P * SLICE * H);
+  bool dead = false;
+  // inputs of one step (owner waves): loaded a step ahead, while the exchange of the current step is in flight
+  f32x4 go, sr, sz, sn, sq, hprev;
+  auto load_inputs = [&](int s) {
+    const int t = dir ? s : (T - 1 - s);
+    const int tp = dir ? t + 1 : t - 1;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    go = sr = sz = sn = sq = hprev = zero;
+    if (owner && t < len) {
+      const long frame = (long)clip * T + t;
+      go = *reinterpret_cast<const f32x4*>(p.d_out + frame * (2 * H) + dir * H + j0);
+      const float* sp = p.save + (dir_off + frame) * (4 * H) + j0;
+      sr = *reinterpret_cast<const f32x4*>(sp);
+      sz = *reinterpret_cast<const f32x4*>(sp + H);
+      sn = *reinterpret_cast<const f32x4*>(sp + 2 * H);
+      sq = *reinterpret_cast<const f32x4*>(sp + 3 * H);
+      if (tp >= 0 && tp < len) hprev = *reinterpret_cast<const f32x4*>(p.out + ((long)clip * T + tp) * (2 * H) + dir * H + j0);
+    }
+  };
+  load_inputs(0);
+  STAMP_DECL;
+  for (int s = 0; s < T; ++s) {
+    STAMP(15);
+    const int t = dir ? s : (T - 1 - s);
+    const long frame = (long)clip * T + t;
+    const bool valid = t < len;
+    const bool last = s + 1 == T;  // nothing consumes the last dh_prev
+    f32x4 dcarry = dh;
+    f32x4 dar = {0.f, 0.f, 0.f, 0.f}, daz = dar, dan = dar, dqn = dar;
+    if (owner) {
+      if (valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = go[e] + dh[e];
+          const float dn = d * (1.0f - sz[e]);
+          const float dz = d * (hprev[e] - sn[e]);
+          dan[e] = dn * (1.0f - sn[e] * sn[e]);
+          dar[e] = dan[e] * sq[e] * sr[e] * (1.0f - sr[e]);
+          daz[e] = dz * sz[e] * (1.0f - sz[e]);
+          dqn[e] = dan[e] * sr[e];
+          dcarry[e] = d * sz[e];
+        }
+      }
+      if (!last) {
+        float* dp = &dpan[i * LDP + 16 * ut + 4 * g];
+        *reinterpret_cast<f32x4*>(dp) = dar;
+        *reinterpret_cast<f32x4*>(dp + C::UP) = daz;
+        *reinterpret_cast<f32x4*>(dp + 2 * C::UP) = dqn;
+      }
+    }
+    if (!last) {
+      __syncthreads();
+      STAMP(4);
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 dq[QK];
+#pragma unroll
+      for (int q = 0; q < QK; ++q) dq[q] = *reinterpret_cast<const f32x4*>(&dpan[i * LDP + 16 * q + 4 * g]);
+#pragma unroll
+      for (int q = 0; q < QK; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[nt][4 * q + e], dq[q][e], acc[nt]);
+      // D rows 4g..4g+3 = units U of tile NT*w + nt, column i = clip: the partial goes to the part that owns U
+      const int xw = ((s & 1) * pairs + pair) * P * P * SLICE * C::UP;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int U = 16 * (NT * w + nt) + 4 * g;
+        const int dst = (xw + (((U / C::UP) * P + part) * SLICE + i) * C::UP + U % C::UP) / 2;
+        store_granule_pair(xrs, dst, base + (unsigned)s + 1u, acc[nt][0], acc[nt][1]);
+        store_granule_pair(xrs, dst + 1, base + (unsigned)s + 1u, acc[nt][2], acc[nt][3]);
+      }
+      STAMP(2);
+    }
+    if (owner && clip_ok) {
+      float* gp = p.d_g + (dir_off + frame) * (4 * H) + j0;
+      *reinterpret_cast<f32x4*>(gp) = dar;
+      *reinterpret_cast<f32x4*>(gp + H) = daz;
+      *reinterpret_cast<f32x4*>(gp + 2 * H) = dan;
+      *reinterpret_cast<f32x4*>(gp + 3 * H) = dqn;
+    }
+    if (last) break;
+    load_inputs(s + 1);
+    // sum the P partials of this part's units: thread -> positions 2 tid, 2 tid + 1 of the [clip][UP] tile
+    float xv[2 * NGP];
+    const int xr = ((((s & 1) * pairs + pair) * P + part) * P * SLICE * C::UP) / 2 + threadIdx.x;
+    if (!dead) dead = !sweep_granules<NGP>(xrs, xr, base + (unsigned)s + 1u, xv, &sync[2], lane);
+    STAMP(0);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      s0 += xv[2 * q];
+      s1 += xv[2 * q + 1];
+    }
+    *reinterpret_cast<float2*>(&dsum[2 * threadIdx.x]) = float2{s0, s1};
+    __syncthreads();
+    if (owner) dh = dcarry + *reinterpret_cast<const f32x4*>(&dsum[i * C::UP + 16 * ut + 4 * g]);
+    STAMP(1);
+  }
+  if (dead && lane == 0) p.d_g[0] = __builtin_nanf("");
+  STAMP_FLUSH();
+  finish_launch(sync, gen);
+}
+
+// sync_ws sections, in granules
+inline long gru_fwd_granules(int B, int H) { return 2L * (2 * ceil_div(B, SLICE)) * SLICE * H; }
+inline long gru_bwd_granules(int B, int H, int P) { return 2L * (2 * ceil_div(B, SLICE)) * P * SLICE * H; }
+
+// parts per (slice, direction) for a shape, or 0 when the single-workgroup form is the right one
+inline int gru_split_parts(int B, int T, int H) {
+  const int pairs = 2 * ceil_div(B, SLICE);
+  if (T > SPLIT_MAX_T) return 0;
+  const int P = H == 192 ? 6 : (H == 64 ? 2 : 0);
+  return (P && pairs * P <= SPLIT_MAX_WGS) ? P : 0;
+}
+
+}  // namespace

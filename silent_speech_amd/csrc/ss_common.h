@@ -77,6 +77,12 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
     __syncthreads();  \
     STAMP(k);         \
   } while (0)
+// stamp after every outstanding memory operation of the wave has returned (delimits a load phase)
+#define STAMP_WAIT(k)                \
+  do {                               \
+    __builtin_amdgcn_s_waitcnt(0);   \
+    STAMP(k);                        \
+  } while (0)
 #define STAMP_FLUSH()                                                                       \
   do {                                                                                      \
     if (threadIdx.x == 0 && blockIdx.x < 256)                                               \
@@ -86,6 +92,7 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #define STAMP_DECL
 #define STAMP(k)
 #define STAMP_SYNC(k)
+#define STAMP_WAIT(k)
 #define STAMP_FLUSH()
 #define STAMP_TABLE(reader)
 #endif

@@ -26,6 +26,7 @@ INT_MAX = 2**31 - 1
 # bench.py turns this off for its per-kernel timing pass: HIP-event pairs only bracket a kernel's own run time when
 # every launch sits on one stream
 JOIN_BEFORE_CNN_BWD = True
+USE_SPLIT_GRU = True
 USE_SIDE_STREAM = True
 
 
@@ -82,6 +83,10 @@ class Workspace:
         f32 = dict(device=device, dtype=torch.float32)
         u8 = dict(device=device, dtype=torch.uint8)
         self.lengths = torch.empty(B, device=device, dtype=torch.int32)
+        # step counters of the multi-CU recurrence (zeroed once; the kernels keep them consistent): only shapes small
+        # enough to leave most of the chip idle under the one-CU-per-slice kernels get one
+        nb = L.gru_sync_bytes(B, T, H) if USE_SPLIT_GRU else 0
+        self.gru_sync = torch.zeros(nb // 4, device=device, dtype=torch.int32) if nb else None
         # weight-gradient GEMMs run on a side stream next to the (32-CU) recurrence of the layer below
         # (lowest priority: it must never delay the dispatch of the critical-path kernels on the caller's stream)
         self.side = torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[0]) if train else None
@@ -157,7 +162,7 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
         L.call("ss_gru_fwd", ws.gi[l].data_ptr(), P[f"gru.weight_hh_l{l}"].data_ptr(),
                P[f"gru.weight_hh_l{l}_reverse"].data_ptr(), P[f"gru.bias_hh_l{l}"].data_ptr(),
                P[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.lengths.data_ptr(), B, T, H, ws.out[l].data_ptr(),
-               ws.save[l].data_ptr() if stash else None, s)
+               ws.save[l].data_ptr() if stash else None, L.ptr(ws.gru_sync), s)
         layer_in, ld_in = ws.out[l].data_ptr(), 2 * H
         if train and l < cfg.gru_layers - 1 and cfg.gru_dropout > 0.0:
             L.call("ss_dropout", ws.out[l].data_ptr(), ws.out_drop[l].data_ptr(), N * 2 * H, cfg.gru_dropout, seed,
@@ -209,7 +214,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         K = cfg.in_dim if l == 0 else 2 * H
         L.call("ss_gru_bwd", ws.d_out.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(),
                P[f"gru.weight_hh_l{l}"].data_ptr(), P[f"gru.weight_hh_l{l}_reverse"].data_ptr(),
-               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), s)
+               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), L.ptr(ws.gru_sync), s)
         if l == 0:
             if cfg.use_roi:
                 lin, ld_in = ws.Z.data_ptr(), cfg.in_dim

@@ -136,9 +136,19 @@ def _gru_case(H, In, B, T, seed, lengths=None):
     return sd, x, torch.as_tensor(lengths, dtype=torch.int64)
 
 
-@pytest.mark.parametrize("H,B,T", [(192, 5, 7), (192, 37, 12), (64, 3, 20), (192, 16, 1)])
-def test_gru_fwd_bwd(L, H, B, T):
+@pytest.mark.parametrize("split", [False, True], ids=["one_cu", "multi_cu"])
+@pytest.mark.parametrize("H,B,T", [(192, 5, 7), (192, 37, 12), (64, 3, 20), (192, 16, 1), (192, 130, 30), (64, 250, 9)])
+def test_gru_fwd_bwd(L, H, B, T, split):
+    """split=True hands the kernels a sync workspace: the (slice, direction) recurrences then run on several CUs each
+    and exchange their state through `out` / `d_g`; three launches share the workspace (generation counter)."""
     In = 20
+    sync_ws = None
+    if split:
+        nb = L.gru_sync_bytes(B, T, H)
+        if nb == 0:
+            pytest.skip("shape always takes the one-CU-per-slice kernels")
+        sync_ws = torch.zeros(nb // 4, device="cuda", dtype=torch.int32)
+    sw = L.ptr(sync_ws)
     sd, x, lengths = _gru_case(H, In, B, T, seed=H + B + T)
     N = B * T
     # reference: explicit masked GRU on CPU with autograd
@@ -169,22 +179,25 @@ def test_gru_fwd_bwd(L, H, B, T):
     save_d = torch.zeros(2, N, 4, H, device="cuda")
     L.call("ss_gru_fwd", gi_d.data_ptr(), P["gru.weight_hh_l0"].data_ptr(), P["gru.weight_hh_l0_reverse"].data_ptr(),
            P["gru.bias_hh_l0"].data_ptr(), P["gru.bias_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H,
-           out_d.data_ptr(), save_d.data_ptr(), L.stream())
+           out_d.data_ptr(), save_d.data_ptr(), sw, L.stream())
     sync()
     assert_close("gru out", out_d.view(B, T, 2 * H), out_ref, atol=2e-5)
     # inference form (no stash) gives the same bits
     out2 = torch.empty_like(out_d)
     L.call("ss_gru_fwd", gi_d.data_ptr(), P["gru.weight_hh_l0"].data_ptr(), P["gru.weight_hh_l0_reverse"].data_ptr(),
            P["gru.bias_hh_l0"].data_ptr(), P["gru.bias_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H,
-           out2.data_ptr(), None, L.stream())
+           out2.data_ptr(), None, sw, L.stream())
     sync()
     assert torch.equal(out2, out_d)
 
     dout_d = dev(wgt.reshape(N, 2 * H))
     dg_d = torch.full((2, N, 4, H), 5.0, device="cuda")
     L.call("ss_gru_bwd", dout_d.data_ptr(), out_d.data_ptr(), save_d.data_ptr(), P["gru.weight_hh_l0"].data_ptr(),
-           P["gru.weight_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H, dg_d.data_ptr(), L.stream())
+           P["gru.weight_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H, dg_d.data_ptr(), sw, L.stream())
     sync()
+    if split:
+        assert int(sync_ws[2]) == 0, "a wait on a partner workgroup timed out"
+        assert int(sync_ws[0]) == 3 and int(sync_ws[1]) == 0  # three launches, each closed its generation
     for d in range(2):
         dgi_ref = gi_ref[d].grad.reshape(N, 3 * H)
         assert_close(f"d gi dir{d}", dg_d[d, :, :3].reshape(N, 3 * H), dgi_ref, atol=3e-5, rtol=1e-4)

@@ -264,7 +264,7 @@ def test_real_weights_kat_gru(ss, golden_dir):
     lens = torch.full((B,), T, device="cuda", dtype=torch.int32)
     L.call("ss_gru_fwd", gi.data_ptr(), sd["gru.weight_hh_l0"].data_ptr(), sd["gru.weight_hh_l0_reverse"].data_ptr(),
            sd["gru.bias_hh_l0"].data_ptr(), sd["gru.bias_hh_l0_reverse"].data_ptr(), lens.data_ptr(), B, T, H,
-           out.data_ptr(), None, L.stream())
+           out.data_ptr(), None, None, L.stream())
     torch.cuda.synchronize()
     err = float((out.view(B, T, 2 * H).cpu() - torch.from_numpy(d["gru_out"])).abs().max())
     assert err < 2e-5, err

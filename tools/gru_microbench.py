@@ -25,8 +25,10 @@ def timed(fn, n=20):
 def main():
     dev = torch.device("cuda")
     H = 192
-    for B, T in ((256, 30), (128, 30), (16, 30), (256, 60)):
+    for B, T, split in ((256, 30, False), (256, 30, True), (128, 30, True), (16, 30, True), (256, 60, True)):
         N = B * T
+        nb = L.gru_sync_bytes(B, T, H) if split else 0
+        sync_ws = torch.zeros(nb // 4, device=dev, dtype=torch.int32) if nb else None
         gi = torch.randn(2, N, 3 * H, device=dev) * 0.5
         w = [torch.randn(3 * H, H, device=dev) * 0.07 for _ in range(2)]
         b = [torch.randn(3 * H, device=dev) * 0.07 for _ in range(2)]
@@ -39,14 +41,15 @@ def main():
 
         def fwd(sv):
             L.call("ss_gru_fwd", gi.data_ptr(), w[0].data_ptr(), w[1].data_ptr(), b[0].data_ptr(), b[1].data_ptr(),
-                   lens.data_ptr(), B, T, H, out.data_ptr(), sv, s)
+                   lens.data_ptr(), B, T, H, out.data_ptr(), sv, L.ptr(sync_ws), s)
 
         def bwd():
             L.call("ss_gru_bwd", dout.data_ptr(), out.data_ptr(), save.data_ptr(), w[0].data_ptr(), w[1].data_ptr(),
-                   lens.data_ptr(), B, T, H, dg.data_ptr(), s)
+                   lens.data_ptr(), B, T, H, dg.data_ptr(), L.ptr(sync_ws), s)
 
         t1, t2, t3 = timed(lambda: fwd(save.data_ptr())), timed(lambda: fwd(None)), timed(bwd)
-        print(f"B={B:4d} T={T}: fwd+stash {t1:7.1f} us ({t1 / T:5.2f}/step)  fwd {t2:7.1f} us ({t2 / T:5.2f}/step)  "
+        errs = int(sync_ws[2]) if sync_ws is not None else 0
+        print(f"B={B:4d} T={T} {'multi-CU' if sync_ws is not None else 'one-CU  '} (wait time-outs {errs}): fwd+stash {t1:7.1f} us ({t1 / T:5.2f}/step)  fwd {t2:7.1f} us ({t2 / T:5.2f}/step)  "
               f"bwd {t3:7.1f} us ({t3 / T:5.2f}/step)")
 
 
