@@ -21,7 +21,10 @@ constexpr int LDM_B = BN + 4;
 
 struct RowMap {
   int G, S, off;
-  __device__ __forceinline__ long operator()(int r) const { return (long)(r / G) * S + (r % G) + off; }
+  __device__ __forceinline__ long operator()(int r) const {
+    if (G == 0x7fffffff) return r + off;  // identity map (wave-uniform branch): no integer division on the fetch path
+    return (long)(r / G) * S + (r % G) + off;
+  }
 };
 
 struct GemmParams {

@@ -118,6 +118,9 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   const int len = clip_ok ? p.lengths[clip] : 0;
   const int T = p.T;
   if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
+  // every cycle of this chain is on the step's critical path: issue ahead of the weight-gradient GEMM waves that
+  // share the SIMDs
+  __builtin_amdgcn_s_setprio(3);
 
   // A fragments: rows = this tile's units of gate G, slots (q, e) carry k = 16*(kh*QF + q) + 4g + e
   float wf[3][4 * C::QF];
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   const int len = clip_ok ? p.lengths[clip] : 0;
   const int T = p.T;
   if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
+  __builtin_amdgcn_s_setprio(3);  // as in the forward kernel
 
   // A fragments: A[i = output unit 16*(NT*w + nt) + i][slot (q, e)] = W[row(16q + 4g + e)][unit], local row
   // kk = G * UP + u  <->  W row G*H + part*UP + u

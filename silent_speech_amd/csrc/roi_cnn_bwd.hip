@@ -157,26 +157,44 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   __syncthreads();
   STAMP_DECL;
 
-  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
-    STAMP(15);
-    // ---------------- L0: issue every global load of the frame; pixel statistics
-    uint4 px[NCH], m3w = {0, 0, 0, 0}, i2w = {0, 0, 0, 0};
+  // Frame inputs that go through registers (uint8 frame, conv3 sign mask, pool-2 argmaxes, d_out row, features) and
+  // the pooled-2 map (LDS-DMA straight into its place) are fetched ONE FRAME AHEAD, right before S5 of the previous
+  // frame: phase 1's a2h lies under the dense dy2 image, which is dead by then, and S5 is long enough to cover HBM.
+  uint4 px[NCH], m3w = {0, 0, 0, 0}, i2w = {0, 0, 0, 0};
+  float dout_r = 0.f, feat_r = 0.f;
+  float wfc_r[3];  // fc weight: the same for every frame
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wfc_r[k] = (tid + k * NT < E * 24) ? p.wfc[tid + k * NT] : 0.f;
+  auto prefetch_frame = [&](int nf) {
+    {  // pooled-2 map: the stash is the haloed LDS image itself -> linear LDS-DMA, 1 KB per wave instruction
+      constexpr int BYTES = 16 * P2 * 4;
+      const char* src = reinterpret_cast<const char*>(p.st_a2 + (long)nf * 16 * P2);
+      for (int piece = wvu; piece * 1024 < BYTES; piece += NWV) {
+        const int off = piece * 1024 + lane * 16;
+        if (off < BYTES) ss_dma16(src + off, (unsigned)(LL::o_ph * 4 + piece * 1024));
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
-      if ((tid + k * NT) * 16 < HW) px[k] = reinterpret_cast<const uint4*>(p.R + (long)n * HW)[tid + k * NT];
-    if (tid * 16 < 24 * P) m3w = reinterpret_cast<const uint4*>(p.st_m3 + (long)n * 24 * P)[tid];
-    if (tid * 16 < 16 * P) i2w = reinterpret_cast<const uint4*>(p.st_i2 + (long)n * 16 * P)[tid];
-    if (tid < E) s_dout[tid] = p.d_out[(long)n * p.ld_dout + tid];
-    if (tid < 24) s_feat[tid] = p.st_feat[(long)n * 24 + tid];
-    for (int q = tid; q < E * 24; q += NT) s_wfc[q] = p.wfc[q];
+      if ((tid + k * NT) * 16 < HW) px[k] = reinterpret_cast<const uint4*>(p.R + (long)nf * HW)[tid + k * NT];
+    if (tid * 16 < 24 * P) m3w = reinterpret_cast<const uint4*>(p.st_m3 + (long)nf * 24 * P)[tid];
+    if (tid * 16 < 16 * P) i2w = reinterpret_cast<const uint4*>(p.st_i2 + (long)nf * 16 * P)[tid];
+    if (tid < E) dout_r = p.d_out[(long)nf * p.ld_dout + tid];
+    if (tid < 24) feat_r = p.st_feat[(long)nf * 24 + tid];
+  };
+  if ((int)blockIdx.x < p.N) prefetch_frame(blockIdx.x);
+
+  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    STAMP(15);
+    // ---------------- L0: stage the prefetched inputs; pixel statistics
+    if (tid < E) s_dout[tid] = dout_r;
+    if (tid < 24) s_feat[tid] = feat_r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (tid + k * NT < E * 24) s_wfc[tid + k * NT] = wfc_r[k];
     if (!LL::W3_RESIDENT)
       for (int q = tid; q < 3456 / 4; q += NT)
         reinterpret_cast<f32x4*>(w3s)[q] = reinterpret_cast<const f32x4*>(p.w3)[q];
-    {  // pooled-2 map: the stash is the haloed LDS image itself -> linear 16-byte copy
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.st_a2 + (long)n * 16 * P2);
-#pragma unroll 3
-      for (int q = tid; q < 4 * P2; q += NT) reinterpret_cast<f32x4*>(a2h)[q] = src[q];
-    }
     if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = i2w;
     {
       unsigned su = 0, sq = 0;
@@ -201,6 +219,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
       if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
     }
+    ss_dma_wait();  // this wave's pieces of the pooled-2 map (issued a frame ago) are in LDS
     {  // pooled-1 map: LDS-DMA, 1 KB per wave instruction, issued after every compiler-tracked load of this phase
        // has been consumed and waited for only before S3 (it flies under S1/S2)
       constexpr int BYTES = 8 * P1 * 4;
@@ -213,10 +232,13 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     __syncthreads();  // A
     STAMP(0);
 
-    if (tid < 24) {
+    if (tid < 24 * 16) {  // d feat[c] = sum_e d_out[e] * Wfc[e][c]: 16 lanes per channel, then a shuffle tree
+      const int c = tid >> 4, sub = tid & 15;
       float s = 0.f;
-      for (int e = 0; e < E; ++e) s += s_dout[e] * s_wfc[e * 24 + tid];
-      s_dfeat[tid] = s / (float)P;
+      for (int e = sub; e < E; e += 16) s += s_dout[e] * s_wfc[e * 24 + c];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (sub == 0) s_dfeat[c] = s / (float)P;
     }
     if (tid == 32) {
       unsigned long long tsu = 0, tsq = 0;
@@ -301,6 +323,12 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
     }
     STAMP_SYNC(3);
+    // pool-1 argmaxes for the phase switch: fetched here so that HBM answers under S2
+    uint4 ix1[NI1];
+#pragma unroll
+    for (int k = 0; k < NI1; ++k)
+      if ((tid + k * NT) * 16 < 8 * I1S)
+        ix1[k] = reinterpret_cast<const uint4*>(p.st_i1 + (long)n * 8 * I1S)[tid + k * NT];
     // ---------------- S2: da2 (masked by a2 > 0) -> da2m ; db2.  Two pixel tiles per pass share the W3 reads.
     {
       constexpr int tiles = P / 16;
@@ -362,11 +390,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // phase-2 images are written over the phase-1 area: dense dy2, the normalised frame (haloed), pool-1 argmaxes.
     {
       constexpr int TV = LL::TV;
-      uint4 ix1[NI1];
-#pragma unroll
-      for (int k = 0; k < NI1; ++k)
-        if ((tid + k * NT) * 16 < 8 * I1S)
-          ix1[k] = reinterpret_cast<const uint4*>(p.st_i1 + (long)n * 8 * I1S)[tid + k * NT];
       float dv[TV];
       int iv[TV];
 #pragma unroll
@@ -514,6 +537,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     }
     __syncthreads();  // da1 complete
     STAMP(9);
+    if (n + (int)gridDim.x < p.N) prefetch_frame(n + gridDim.x);
     // ---------------- S5: conv1 weight gradient on the pooled grid (K = pooled pixels, split over the 8 waves)
     {
       constexpr int kpw = HW2 / NWV;
