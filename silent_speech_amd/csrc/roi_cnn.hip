@@ -48,7 +48,7 @@ struct CnnFwdParams {
   float* st_a1;     // [N][8][P1]  haloed LDS image of the pooled-1 map, as is
   uint8_t* st_i1;   // [N][8][I1S] (plane stride I1S = H2*W2 + 4 bytes)
   float* st_a2;     // [N][16][P2] haloed LDS image of the pooled-2 map, as is
-  uint8_t* st_i2;   // [N][16][H4][W4]
+  uint8_t* st_i2;   // [N][H4][W4][16]  pixel-major: the backward pass consumes it next to its pixel-major da2
   uint8_t* st_m3;   // [N][24][P]
   float* st_feat;   // [N][24]
 };
@@ -59,7 +59,7 @@ struct FwdLds {
   static constexpr int o_a1 = ((G::H + 2) * G::XS + 3) & ~3;    // [8][P1]
   static constexpr int o_a2 = o_a1 + 8 * G::P1;                 // [16][P2]
   static constexpr int o_i1 = (o_a2 + 16 * G::P2 + 3) & ~3;     // bytes [8][I1S]
-  static constexpr int o_i2 = o_i1 + 2 * G::I1S;                // bytes [16][P]
+  static constexpr int o_i2 = o_i1 + 2 * G::I1S;                // bytes [P][16]
   static constexpr int o_misc = o_i2 + 4 * G::P + 256;  // the 256 floats in front hold the grey-level table
   static constexpr int total = o_misc + 512;
 };
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
           if (v11 > best) { best = v11; bi = 3; }
           const int pxx = 8 * xt + 2 * g + e;
           a2[i * P2 + (yp + 1) * S2 + pxx + 1] = best;
-          i2s[i * P + yp * W4 + pxx] = (uint8_t)bi;
+          i2s[(yp * W4 + pxx) * 16 + i] = (uint8_t)bi;
         }
       }
     }

@@ -40,8 +40,10 @@ struct BwdLds {
   static constexpr int o_da2m = o_dy3h + 24 * G::P2;
   static constexpr int o_i2b = o_da2m + 16 * G::P;
   static constexpr int end1a = (o_i2b + 4 * G::P + 3) & ~3;
-  static constexpr int PD = plane_stride(G::HW2);         // dy2 plane stride
-  static constexpr int o_xh = o_ph + 16 * PD;
+  // dy2 is pixel-major with a zero column left and right of every row: [H2][W2 + 2][16 channels].  A lane's four
+  // k-steps of an S4 tap are then ONE ds_read_b128 at (lane base + immediate): no address arithmetic, no edge selects
+  static constexpr int W2H = G::W2 + 2;
+  static constexpr int o_xh = o_ph + 16 * G::H2 * W2H;
   static constexpr int XHN = (G::H + 2) * G::XS;
   static constexpr int o_i1b = (o_xh + XHN + 3) & ~3;
   static constexpr int end2 = (o_i1b + 2 * G::I1S + 3) & ~3;
@@ -55,6 +57,7 @@ struct BwdLds {
   static constexpr int o_w2t = W3_RESIDENT ? ph_end + 3456 : ph_end;
   static constexpr int o_misc = o_w2t + 192 * 16;
   static constexpr int total = o_misc + 512;
+  static_assert(total * 4 <= 160 * 1024, "LDS image exceeds a CU");
   static constexpr int TV = (16 * G::P + NT - 1) / NT;    // (da2m, argmax) pairs per thread at the phase switch
 };
 
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = BwdLds<G>;
   constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H, XS = G::XS;
-  constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, PD = LL::PD;
+  constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, W2H = LL::W2H;
   constexpr int NCH = (HW / 16 + NT - 1) / NT;    // 16-byte pixel chunks per thread
   constexpr int I1S = G::I1S;
   constexpr int NI1 = (I1S / 2 + NT - 1) / NT;    // 16-byte pool-1 argmax chunks per thread
@@ -124,10 +127,12 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   __syncthreads();
   if (LL::W3_RESIDENT)
     for (int q = tid; q < 3456; q += NT) w3s[q] = p.w3[q];
-  // S4's B operand: k = (t*3+kx)*16 + n, column j = (c, s): W2[n][c][ky = s+2-t][kx], zero outside the 3x3 window
+  // S4's B operand: k = (t*3+kx)*16 + n, column j = (c, s): W2[n][c][ky = s+2-t][kx], zero outside the 3x3 window.
+  // Stored [tap tk][g][column j][e] with n = 4g + e: lane (j, g) takes its four k-steps of a tap in ONE ds_read_b128
+  // (MFMA slot (e, g) carries n = 4g + e for both operands).
   for (int q = tid; q < 192 * 16; q += NT) {
-    const int k = q >> 4, j = q & 15;
-    const int tk = k >> 4, n = k & 15, t = tk / 3, kx = tk % 3, c = j & 7, s = j >> 3;
+    const int e = q & 3, j = (q >> 2) & 15, gg = (q >> 6) & 3, tk = q >> 8;
+    const int n = 4 * gg + e, t = tk / 3, kx = tk % 3, c = j & 7, s = j >> 3;
     const int ky = s + 2 - t;
     w2t[q] = (ky >= 0 && ky <= 2) ? p.w2[n * 72 + c * 9 + ky * 3 + kx] : 0.f;
   }
@@ -145,13 +150,14 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   f32x4 accG[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // S5: rows (c, window slot), cols (ry, rx)
   float accfc[3] = {0.f, 0.f, 0.f}, accbfc = 0.f, accb2 = 0.f, accb1 = 0.f;
 
-  // S3 B-operand offsets: column idx = 16*nt + i  ->  tap = idx/8, c = idx%8
+  // S3 B-operand offsets: column idx = 16*nt + i  ->  tap = idx/8, c = idx%8.  Columns 72..79 are padding: their
+  // results are dropped at the flush and a D column depends on its own B column only, so they read any valid cell.
   int boff[5];
 #pragma unroll
   for (int nt = 0; nt < 5; ++nt) {
     const int idx = 16 * nt + i;
     const int tap = idx >> 3, c = idx & 7;
-    boff[nt] = (idx < 72) ? c * P1 + (tap / 3) * S1 + (tap % 3) : -1;
+    boff[nt] = (idx < 72) ? c * P1 + (tap / 3) * S1 + (tap % 3) : 0;
   }
 
   __syncthreads();
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           const int pq = 16 * tile + 4 * g + r;
           const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
           const float v = av > 0.f ? acc0[r] : 0.f;
-          da2m[i * P + pq] = v;
+          da2m[pq * 16 + i] = v;
           accb2 += v;
         }
         if (two) {
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
             const int pq = 16 * tile2 + 4 * g + r;
             const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
             const float v = av > 0.f ? acc1x[r] : 0.f;
-            da2m[i * P + pq] = v;
+            da2m[pq * 16 + i] = v;
             accb2 += v;
           }
         }
@@ -401,16 +407,23 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       __syncthreads();  // every read of the phase-1 images is done before the first overwrite
 #pragma unroll
       for (int e = 0; e < TV; ++e) {
-        const int q = tid + e * NT;
+        const int q = tid + e * NT;  // da2m and the argmaxes are pixel-major: q = pooled-2 pixel * 16 + channel
         if (q < 16 * P) {
-          const int c = q / P, r = q % P;
+          const int c = q & 15, r = q >> 4;
           const int qy = r / W4, qx = r % W4;
-          float* dst = dy2 + c * PD + (2 * qy) * W2 + 2 * qx;
+          float* dst = dy2 + ((2 * qy) * W2H + 2 * qx + 1) * 16 + c;
           const float v = dv[e];
           const int o = iv[e];
-          *reinterpret_cast<float2*>(dst) = make_float2(o == 0 ? v : 0.f, o == 1 ? v : 0.f);
-          *reinterpret_cast<float2*>(dst + W2) = make_float2(o == 2 ? v : 0.f, o == 3 ? v : 0.f);
+          dst[0] = o == 0 ? v : 0.f;
+          dst[16] = o == 1 ? v : 0.f;
+          dst[16 * W2H] = o == 2 ? v : 0.f;
+          dst[16 * W2H + 16] = o == 3 ? v : 0.f;
         }
+      }
+      // the zero columns of dy2 (the area held phase-1 data)
+      for (int q = tid; q < 2 * H2 * 4; q += NT) {
+        const int y = q >> 3, side = (q >> 2) & 1, part = q & 3;
+        reinterpret_cast<f32x4*>(dy2)[(y * W2H + (side ? W2 + 1 : 0)) * 4 + part] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       // normalised frame: interior by table lookup, halo cells zeroed (the area held phase-1 data)
 #pragma unroll
@@ -442,28 +455,35 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     __syncthreads();  // T done
     STAMP(5);
 
-    // ---------------- S3: dW2
+    // ---------------- S3: dW2.  A wave owns whole rows of the pooled-1 grid: per row one A base and five B bases,
+    // everything else is an immediate offset (VALU work between MFMAs is not hidden by them)
     {
-      constexpr int kpw = HW2 / NWV;
-      const int pbase = wvu * kpw;
+      constexpr int kpw = HW2 / NWV, rows = kpw / W2;
+      static_assert(rows * W2 == kpw && (W2 / 4) % 2 == 0, "S3 row split");
+      const int y0 = wvu * rows;
 #pragma unroll 1
-      for (int kk = 0; kk < kpw / 4; kk += 2) {  // two k-steps per pass: 12 LDS reads in flight, then 10 MFMAs
-        float a[2], b[2][5];
+      for (int r = 0; r < rows; ++r) {
+        const float* ap = dy2 + ((y0 + r) * W2H + 1 + g) * 16 + i;
+        const float* bp = a1h + (y0 + r) * S1 + g;
+        const float* bpn[5];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int p0 = pbase + 4 * (kk + u);
-          const int y = p0 / W2, x = p0 % W2 + g;
-          a[u] = dy2[i * PD + p0 + g];
-          const float* bp = a1h + y * S1 + x;
+        for (int nt = 0; nt < 5; ++nt) bpn[nt] = bp + boff[nt];
 #pragma unroll
-          for (int nt = 0; nt < 5; ++nt) b[u][nt] = bp[boff[nt] < 0 ? 0 : boff[nt]];
+        for (int xq = 0; xq < W2 / 4; xq += 2) {  // two k-steps per pass: 12 LDS reads in flight, then 10 MFMAs
+          float a[2], b[2][5];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            a[u] = ap[(xq + u) * 64];
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) b[u][nt] = bpn[nt][(xq + u) * 4];
+          }
+          SS_SCHED_FENCE();
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) acc2[nt] = mfma16(a[u], b[u][nt], acc2[nt]);
+          SS_SCHED_FENCE();
         }
-        SS_SCHED_FENCE();
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int nt = 0; nt < 5; ++nt) acc2[nt] = mfma16(a[u], boff[nt] >= 0 ? b[u][nt] : 0.f, acc2[nt]);
-        SS_SCHED_FENCE();
       }
     }
     STAMP_SYNC(6);
@@ -480,44 +500,38 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         const int chb = two ? ch2 : ch;
         const int y0_ = 2 * (ch / xt_n), x0_ = 16 * (ch % xt_n) + i;
         const int y1_ = 2 * (chb / xt_n), x1_ = 16 * (chb % xt_n) + i;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0, acc0b = acc0, acc1b = acc0;  // 4 independent MFMA chains
-        // software pipeline: the 12 operand reads of tap tk+1 are in flight while the 8 MFMAs of tap tk issue
-        float b[2][4], a0[2][4], a1[2][4];
-        bool in0[2], in1[2];
-        auto load_tap = [&](int tk, int slot) {
-          const int t = tk / 3, kx = tk % 3;
-          const int sy0 = y0_ - 1 + t, sx0 = x0_ + 1 - kx, sy1 = y1_ - 1 + t, sx1 = x1_ + 1 - kx;
-          in0[slot] = sy0 >= 0 && sy0 < H2 && sx0 >= 0 && sx0 < W2;
-          in1[slot] = sy1 >= 0 && sy1 < H2 && sx1 >= 0 && sx1 < W2;
-          const float* ap0 = dy2 + g * PD + (in0[slot] ? sy0 * W2 + sx0 : 0);
-          const float* ap1 = dy2 + g * PD + (in1[slot] ? sy1 * W2 + sx1 : 0);
-          const float* bt = w2t + (tk * 16 + g) * 16 + i;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0;
+        // source pixel of tap (t, kx) for output (y, x) is (y - 1 + t, x + 1 - kx): lane base + immediate; the zero
+        // columns take care of x = -1 / W2, rows outside the map exist only for t = 0 (y = 0) and t = 3 (y = H2 - 2)
+        // and are skipped (wave-uniform)
+        const float* ab0 = dy2 + ((y0_ - 1) * W2H + x0_) * 16 + 4 * g;
+        const float* ab1 = dy2 + ((y1_ - 1) * W2H + x1_) * 16 + 4 * g;
+        const float* bb = w2t + (g * 16 + i) * 4;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            b[slot][j] = bt[4 * j * 16];
-            a0[slot][j] = ap0[4 * j * PD];
-            a1[slot][j] = ap1[4 * j * PD];
+        for (int tp = 0; tp < 12; tp += 2) {
+          f32x4 a0[2], a1[2], b[2];
+          bool ok0[2], ok1[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int tk = tp + u, t = tk / 3, kx = tk % 3;
+            const int off = (t * W2H + 2 - kx) * 16;
+            ok0[u] = !(t == 0 && y0_ == 0) && !(t == 3 && y0_ == H2 - 2);
+            ok1[u] = !(t == 0 && y1_ == 0) && !(t == 3 && y1_ == H2 - 2);
+            a0[u] = a1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok0[u]) a0[u] = *reinterpret_cast<const f32x4*>(ab0 + off);
+            if (ok1[u]) a1[u] = *reinterpret_cast<const f32x4*>(ab1 + off);
+            b[u] = *reinterpret_cast<const f32x4*>(bb + tk * 256);
           }
-        };
-        load_tap(0, 0);
-#pragma unroll 1
-        for (int tk = 0; tk < 12; tk += 2) {
+          SS_SCHED_FENCE();
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {  // static ping-pong between the two register sets
-            if (tk + u + 1 < 12) load_tap(tk + u + 1, u ^ 1);
-            SS_SCHED_FENCE();
+          for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-              acc0 = mfma16(in0[u] ? a0[u][j] : 0.f, b[u][j], acc0);
-              acc1x = mfma16(in1[u] ? a1[u][j] : 0.f, b[u][j], acc1x);
-              acc0b = mfma16(in0[u] ? a0[u][j + 1] : 0.f, b[u][j + 1], acc0b);
-              acc1b = mfma16(in1[u] ? a1[u][j + 1] : 0.f, b[u][j + 1], acc1b);
+            for (int e = 0; e < 4; ++e) {
+              acc0 = mfma16(a0[u][e], b[u][e], acc0);
+              acc1x = mfma16(a1[u][e], b[u][e], acc1x);
             }
-            SS_SCHED_FENCE();
-          }
+          SS_SCHED_FENCE();
         }
-        acc0 += acc0b;
-        acc1x += acc1b;
         // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0 and leave da1 IN PLACE of
         // a1 (each cell is read and rewritten by exactly one lane; S3 finished with a1 before the barrier above).
 #pragma unroll
@@ -538,31 +552,37 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     __syncthreads();  // da1 complete
     STAMP(9);
     if (n + (int)gridDim.x < p.N) prefetch_frame(n + gridDim.x);
-    // ---------------- S5: conv1 weight gradient on the pooled grid (K = pooled pixels, split over the 8 waves)
+    // ---------------- S5: conv1 weight gradient on the pooled grid (K = pooled pixels, whole rows per wave: row
+    // bases + immediates)
     {
-      constexpr int kpw = HW2 / NWV;
-      const int pbase = wvu * kpw;
+      constexpr int kpw = HW2 / NWV, rows = kpw / W2;
+      static_assert(rows * W2 == kpw && (W2 / 4) % 4 == 0, "S5 row split");
+      const int y0 = wvu * rows;
       const int c = i & 7, os = i >> 3;         // A rows: tile 0 -> window slot os, tile 1 -> slot 2 + os
-      const int boff = (i >> 2) * XS + (i & 3);  // B column (ry, rx)
+      const int boff5 = (i >> 2) * XS + (i & 3);  // B column (ry, rx)
 #pragma unroll 1
-      for (int kk = 0; kk < kpw / 4; kk += 4) {  // four k-steps per pass: 12 LDS reads, then 8 MFMAs
-        float d[4], xv[4];
-        int ix[4];
+      for (int r = 0; r < rows; ++r) {
+        const float* dp = a1h + c * P1 + (y0 + r + 1) * S1 + g + 1;
+        const uint8_t* ip = i1b + c * I1S + (y0 + r) * W2 + g;
+        const float* xp = xh + 2 * (y0 + r) * XS + 2 * g + boff5;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int q = pbase + 4 * (kk + u) + g;
-          const int qy = q / W2, qx = q % W2;
-          d[u] = a1h[c * P1 + (qy + 1) * S1 + qx + 1];
-          ix[u] = i1b[c * I1S + q];
-          xv[u] = xh[(2 * qy) * XS + 2 * qx + boff];
-        }
-        SS_SCHED_FENCE();
+        for (int xq = 0; xq < W2 / 4; xq += 4) {  // four k-steps per pass: 12 LDS reads, then 8 MFMAs
+          float d[4], xv[4];
+          int ix[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          accG[0] = mfma16(ix[u] == os ? d[u] : 0.f, xv[u], accG[0]);
-          accG[1] = mfma16(ix[u] == 2 + os ? d[u] : 0.f, xv[u], accG[1]);
+          for (int u = 0; u < 4; ++u) {
+            d[u] = dp[(xq + u) * 4];
+            ix[u] = ip[(xq + u) * 4];
+            xv[u] = xp[(xq + u) * 8];
+          }
+          SS_SCHED_FENCE();
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            accG[0] = mfma16(ix[u] == os ? d[u] : 0.f, xv[u], accG[0]);
+            accG[1] = mfma16(ix[u] == 2 + os ? d[u] : 0.f, xv[u], accG[1]);
+          }
+          SS_SCHED_FENCE();
         }
-        SS_SCHED_FENCE();
       }
     }
     __syncthreads();  // E

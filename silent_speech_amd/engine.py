@@ -120,7 +120,7 @@ class Workspace:
                 self.st_a1 = torch.empty(N, n_a1, **f32)
                 self.st_i1 = torch.empty(N, n_i1, **u8)
                 self.st_a2 = torch.empty(N, n_a2, **f32)
-                self.st_i2 = torch.empty(N, 16, Hh // 4, Ww // 4, **u8)
+                self.st_i2 = torch.empty(N, Hh // 4, Ww // 4, 16, **u8)
                 self.st_m3 = torch.empty(N, 24, (Hh // 4) * (Ww // 4), **u8)
                 self.st_feat = torch.empty(N, 24, **f32)
 

@@ -483,7 +483,7 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     st_a1 = torch.empty(N, n_a1, device="cuda")
     st_i1 = torch.empty(N, n_i1, device="cuda", dtype=torch.uint8)
     st_a2 = torch.empty(N, n_a2, device="cuda")
-    st_i2 = torch.empty(N, 16, H4, W4, device="cuda", dtype=torch.uint8)
+    st_i2 = torch.empty(N, H4, W4, 16, device="cuda", dtype=torch.uint8)  # pixel-major
     st_m3 = torch.empty(N, 24, H4 * W4, device="cuda", dtype=torch.uint8)
     st_feat = torch.empty(N, 24, device="cuda")
     st = [st_a1, st_i1, st_a2, st_i2, st_m3, st_feat]
@@ -514,7 +514,7 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
         return top[..., 0] - top[..., 1]
 
     st_i1v = st_i1.view(N, 8, -1)[:, :, : H2 * W2].reshape(N, 8, H2, W2)  # planes are padded by 4 bytes
-    for name, st_i, idx, c, a in (("i1", st_i1v, i1, c1, a1), ("i2", st_i2, i2, c2, a2)):
+    for name, st_i, idx, c, a in (("i1", st_i1v, i1, c1, a1), ("i2", st_i2.permute(0, 3, 1, 2), i2, c2, a2)):
         sure = (a > 1e-4) & (top2_gap(c.detach()) > 1e-4)
         got = st_i.cpu()[sure]
         want = idx_to_win(idx, c.shape[3])[sure]
