@@ -199,39 +199,59 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       constexpr int chains = (H / 2) * XT;
       const int c = i & 7, s = i >> 3;
       const float bias = s_b1[c];
-      for (int ch = wv; ch < chains; ch += NWV) {
-        const int yp = ch / XT, xt = ch % XT;
-        const float* ap = xh + (2 * yp) * XS + 16 * xt + i;
-        float av[3];
+      // UC independent chains per pass: their reads, 3-deep MFMA chains and pooling epilogues overlap (one chain alone
+      // is a serial read -> MFMA -> MFMA -> MFMA -> exchange -> write dependency, ~550 cycles with nothing beside it)
+      constexpr int cpw = chains / NWV;
+      static_assert(cpw * NWV == chains && cpw % 2 == 0, "conv1 chain split");
+      constexpr int UC = (cpw % 4 == 0) ? 4 : 2;
+#pragma unroll 1
+      for (int ch0 = wv; ch0 < chains; ch0 += UC * NWV) {
+        float av[UC][3];
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) av[kk] = ap[aoff1[kk]];
-        SS_SCHED_FENCE();
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < UC; ++q) {
+          const int ch = ch0 + q * NWV;
+          const float* ap = xh + (2 * (ch / XT)) * XS + 16 * (ch % XT) + i;
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) acc = mfma16(av[kk], bw1[kk], acc);
-        // lane holds 4 pixels x0+4g+r of row 2yp+s for channel c
-        float m[2];
-        int cb[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float v0 = fmaxf(acc[2 * e] + bias, 0.f), v1 = fmaxf(acc[2 * e + 1] + bias, 0.f);
-          m[e] = v1 > v0 ? v1 : v0;
-          cb[e] = v1 > v0 ? 1 : 0;
+          for (int kk = 0; kk < 3; ++kk) av[q][kk] = ap[aoff1[kk]];
         }
-        // row s = 0 lanes finish column pair 0, row s = 1 lanes finish column pair 1
-        const float send_v = s ? m[0] : m[1];
-        const int send_c = s ? cb[0] : cb[1];
-        const float recv_v = __shfl_xor(send_v, 8, 64);
-        const int recv_c = __shfl_xor(send_c, 8, 64);
-        const float own_v = s ? m[1] : m[0];
-        const int own_c = s ? cb[1] : cb[0];
-        const float r0v = s ? recv_v : own_v, r1v = s ? own_v : recv_v;
-        const int r0c = s ? recv_c : own_c, r1c = s ? own_c : recv_c;
-        const float best = r1v > r0v ? r1v : r0v;
-        const int bi = r1v > r0v ? 2 + r1c : r0c;
-        const int pxx = 8 * xt + 2 * g + s;
-        a1[c * P1 + (yp + 1) * S1 + pxx + 1] = best;
-        i1s[c * G::I1S + yp * W2 + pxx] = (uint8_t)bi;
+        SS_SCHED_FENCE();
+        f32x4 acc[UC];
+#pragma unroll
+        for (int q = 0; q < UC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+          for (int q = 0; q < UC; ++q) acc[q] = mfma16(av[q][kk], bw1[kk], acc[q]);
+        SS_SCHED_FENCE();
+#pragma unroll
+        for (int q = 0; q < UC; ++q) {
+          const int ch = ch0 + q * NWV;
+          const int yp = ch / XT, xt = ch % XT;
+          // lane holds 4 pixels x0+4g+r of row 2yp+s for channel c
+          float m[2];
+          int cb[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float v0 = fmaxf(acc[q][2 * e] + bias, 0.f), v1 = fmaxf(acc[q][2 * e + 1] + bias, 0.f);
+            m[e] = v1 > v0 ? v1 : v0;
+            cb[e] = v1 > v0 ? 1 : 0;
+          }
+          // row s = 0 lanes finish column pair 0, row s = 1 lanes finish column pair 1; the partner (other row, same
+          // channel) is lane ^ 8: a rotate by 8 inside the 16-lane DPP row, no LDS round trip
+          const float send_v = s ? m[0] : m[1];
+          const int send_c = s ? cb[0] : cb[1];
+          const float recv_v = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send_v), 0x128, 0xf, 0xf, false));
+          const int recv_c = __builtin_amdgcn_update_dpp(0, send_c, 0x128, 0xf, 0xf, false);
+          const float own_v = s ? m[1] : m[0];
+          const int own_c = s ? cb[1] : cb[0];
+          const float r0v = s ? recv_v : own_v, r1v = s ? own_v : recv_v;
+          const int r0c = s ? recv_c : own_c, r1c = s ? own_c : recv_c;
+          const float best = r1v > r0v ? r1v : r0v;
+          const int bi = r1v > r0v ? 2 + r1c : r0c;
+          const int pxx = 8 * xt + 2 * g + s;
+          a1[c * P1 + (yp + 1) * S1 + pxx + 1] = best;
+          i1s[c * G::I1S + yp * W2 + pxx] = (uint8_t)bi;
+        }
       }
     }
     __syncthreads();
