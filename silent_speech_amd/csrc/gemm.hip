@@ -12,6 +12,8 @@
 // what lets the [row][k] form use a single 16-byte read.
 #include "ss_common.h"
 
+STAMP_TABLE(ss_debug_stamps_gemm)
+
 namespace {
 
 constexpr int BM = 128, BN = 64, BK = 16;
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   float asum = 0.f;  // column sums of the [k][row] A tile (bias gradient), thread t < BM owns row m0 + t
   const bool want_asum = (!A_KCONTIG) && p.asum && blockIdx.x == 0;
 
+  STAMP_DECL;
   Stager<BM, A_KCONTIG> sa[KSUB];
   Stager<BN, B_KCONTIG> sb[KSUB];
 #pragma unroll
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     sb[u].store(lds + u * (A_SZ + B_SZ) + A_SZ);
   }
   __syncthreads();
+  STAMP(15);
 
   int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK * KSUB) {
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
       }
     }
+    STAMP(1);
     if (more) {
       float* nxt = lds + (cur ^ 1) * STAGE;
 #pragma unroll
@@ -209,7 +214,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         sb[u].store(nxt + u * (A_SZ + B_SZ) + A_SZ);
       }
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     cur ^= 1;
   }
 
@@ -241,6 +248,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
       }
     }
+  STAMP_WAIT(4);
+#ifdef SS_STAMP
+  {  // the first 256 workgroups in dispatch order report
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && lin < 256)
+      for (int k_ = 0; k_ < SS_STAMP_SLOTS; ++k_) ss_stamp_buf[lin * SS_STAMP_SLOTS + k_] = st_acc[k_];
+  }
+#endif
 }
 
 }  // namespace

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a weight-gradient GEMM workgroup spends its life (needs the -DSS_STAMP build).
+
+Thread 0 of workgroups 0..255 accumulates clock64() deltas: prologue (first fetch -> LDS -> barrier), per k tile:
+fetch issue + LDS reads + MFMAs, LDS store of the next tile, barrier; epilogue (atomics, drained)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("SS_HOTPATH_LIB", os.path.join(ROOT, "silent_speech_amd", "libss_hotpath_stamp.so"))
+from silent_speech_amd import _lib as L  # noqa: E402
+from silent_speech_amd import engine as E  # noqa: E402
+
+NAMES = {15: "prologue", 1: "fetch issue + LDS reads + MFMAs", 2: "LDS store of next tile", 3: "barrier", 4: "epilogue (drained)"}
+
+
+def main():
+    dev = torch.device("cuda")
+    B, T, H = 256, 30, 192
+    N = B * T
+    dG = torch.randn(2, N, 4 * H, device=dev)
+    out = torch.randn(N, 2 * H, device=dev)
+    gWh = torch.zeros(2, 3 * H, H, device=dev)
+    lib = L.load()
+    fn = lib.ss_debug_stamps_gemm
+    fn.argtypes, fn.restype = [C.c_void_p], C.c_int
+    for target in (256, 768):
+        splits = E.split_k(2 * H, H, B * (T - 1), 2, target)
+        maps = dict(a_map=(T - 1, T, 1), b_map=(T - 1, T, 0))
+        st = (N * 4 * H - 4 * H, H + 2 * H, 3 * H * H, 0, 0)
+        for _ in range(3):
+            E.gemm(0, 0, 2 * H, H, B * (T - 1), dG.data_ptr(), 4 * H, out.data_ptr(), 2 * H, gWh.data_ptr(), H,
+                   accumulate=True, atomic=True, splits=splits, batch=2, strides=st, **maps)
+        buf = np.zeros(256 * 16, np.uint64)
+        assert fn(buf.ctypes.data) == 0
+        t = buf.reshape(256, 16).astype(np.float64)
+        tot = t.sum(1).mean()
+        ktiles = -(-(B * (T - 1)) // splits) // 16
+        print(f"dW_hh 384x192xK, batch 2, splits {splits} (~{ktiles} k tiles per workgroup): {tot / 2400:.2f} us per workgroup")
+        for k, nm in NAMES.items():
+            print(f"   {nm:34s} {t[:, k].mean() / 2400:7.2f} us  {100 * t[:, k].mean() / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
