@@ -65,8 +65,18 @@ struct BwdLds {
 // Inline asm on purpose: hipcc does not track it, so the workgroup barriers between issue and use do not drain it;
 // the consumer waits with ss_dma_wait() before its barrier (cdna_hip_programming.md section 5.7).
 __device__ __forceinline__ void ss_dma16(const void* gsrc_lane, unsigned lds_byte_addr) {
+  lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);  // wave-uniform by contract: make it an SGPR
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc_lane), "s"(lds_byte_addr)
+               : "memory");
+}
+// same with 4 bytes per lane (lane l -> lds_byte_addr + 4 l)
+__device__ __forceinline__ void ss_dma4(const void* gsrc_lane, unsigned lds_byte_addr) {
+  lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(gsrc_lane), "s"(lds_byte_addr)
                : "memory");
@@ -163,45 +173,72 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   __syncthreads();
   STAMP_DECL;
 
-  // Frame inputs that go through registers (uint8 frame, conv3 sign mask, pool-2 argmaxes, d_out row, features) and
-  // the pooled-2 map (LDS-DMA straight into its place) are fetched ONE FRAME AHEAD, right before S5 of the previous
-  // frame: phase 1's a2h lies under the dense dy2 image, which is dead by then, and S5 is long enough to cover HBM.
-  uint4 px[NCH], m3w = {0, 0, 0, 0}, i2w = {0, 0, 0, 0};
-  float dout_r = 0.f, feat_r = 0.f;
+  // Every per-frame input is fetched ONE FRAME AHEAD by LDS-DMA, issued right before S5 of the previous frame and
+  // waited for at the top of the next one: the pooled-2 map straight into its place (phase 1's a2h lies under the dense
+  // dy2 image, dead by then), the uint8 frame / conv3 sign mask / pool-2 argmaxes into a staging area inside the (equally
+  // dead) dy3 planes, the d_out row and the averaged features into their misc slots.  No registers are involved, so
+  // nothing the compiler does with its own loads can wait on these (a register prefetch cost 2.8 us of serialised HBM
+  // round trips per frame: spilled pointers and split destination registers each forced an s_waitcnt vmcnt(0)).
+  constexpr int STG_PX = LL::o_dy3h, STG_M3 = STG_PX + HW / 4, STG_I2 = STG_M3 + 6 * P;   // float offsets
+  static_assert(HW / 4 + 10 * P <= 24 * P2 && HW % 16 == 0 && P % 16 == 0, "staging");
+  uint4 px[NCH];
   float wfc_r[3];  // fc weight: the same for every frame
 #pragma unroll
   for (int k = 0; k < 3; ++k) wfc_r[k] = (tid + k * NT < E * 24) ? p.wfc[tid + k * NT] : 0.f;
   auto prefetch_frame = [&](int nf) {
-    {  // pooled-2 map: the stash is the haloed LDS image itself -> linear LDS-DMA, 1 KB per wave instruction
-      constexpr int BYTES = 16 * P2 * 4;
-      const char* src = reinterpret_cast<const char*>(p.st_a2 + (long)nf * 16 * P2);
-      for (int piece = wvu; piece * 1024 < BYTES; piece += NWV) {
-        const int off = piece * 1024 + lane * 16;
-        if (off < BYTES) ss_dma16(src + off, (unsigned)(LL::o_ph * 4 + piece * 1024));
+    constexpr int A2_PIECES = (16 * P2 * 4 + 1023) / 1024, PX_PIECES = (HW + 1023) / 1024,
+                  M3_PIECES = (24 * P + 1023) / 1024, I2_PIECES = (16 * P + 1023) / 1024;
+    const char* a2src = reinterpret_cast<const char*>(p.st_a2 + (long)nf * 16 * P2);
+    const char* pxsrc = reinterpret_cast<const char*>(p.R + (long)nf * HW);
+    const char* m3src = reinterpret_cast<const char*>(p.st_m3 + (long)nf * 24 * P);
+    const char* i2src = reinterpret_cast<const char*>(p.st_i2 + (long)nf * 16 * P);
+    for (int piece = wvu; piece < A2_PIECES + PX_PIECES + M3_PIECES + I2_PIECES; piece += NWV) {
+      int q = piece;
+      if (q < A2_PIECES) {
+        const int off = q * 1024 + lane * 16;
+        if (off < 16 * P2 * 4) ss_dma16(a2src + off, (unsigned)(LL::o_ph * 4 + q * 1024));
+        continue;
       }
+      q -= A2_PIECES;
+      if (q < PX_PIECES) {
+        const int off = q * 1024 + lane * 16;
+        if (off < HW) ss_dma16(pxsrc + off, (unsigned)(STG_PX * 4 + q * 1024));
+        continue;
+      }
+      q -= PX_PIECES;
+      if (q < M3_PIECES) {
+        const int off = q * 1024 + lane * 16;
+        if (off < 24 * P) ss_dma16(m3src + off, (unsigned)(STG_M3 * 4 + q * 1024));
+        continue;
+      }
+      q -= M3_PIECES;
+      const int off = q * 1024 + lane * 16;
+      if (off < 16 * P) ss_dma16(i2src + off, (unsigned)(STG_I2 * 4 + q * 1024));
     }
-#pragma unroll
-    for (int k = 0; k < NCH; ++k)
-      if ((tid + k * NT) * 16 < HW) px[k] = reinterpret_cast<const uint4*>(p.R + (long)nf * HW)[tid + k * NT];
-    if (tid * 16 < 24 * P) m3w = reinterpret_cast<const uint4*>(p.st_m3 + (long)nf * 24 * P)[tid];
-    if (tid * 16 < 16 * P) i2w = reinterpret_cast<const uint4*>(p.st_i2 + (long)nf * 16 * P)[tid];
-    if (tid < E) dout_r = p.d_out[(long)nf * p.ld_dout + tid];
-    if (tid < 24) feat_r = p.st_feat[(long)nf * 24 + tid];
+    if (wvu == NWV - 1) {
+      if (lane < E) ss_dma4(p.d_out + (long)nf * p.ld_dout + lane, (unsigned)((LL::o_misc) * 4));
+      if (lane < 24) ss_dma4(p.st_feat + (long)nf * 24 + lane, (unsigned)((LL::o_misc + 64) * 4));
+    }
   };
   if ((int)blockIdx.x < p.N) prefetch_frame(blockIdx.x);
 
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     STAMP(15);
-    // ---------------- L0: stage the prefetched inputs; pixel statistics
-    if (tid < E) s_dout[tid] = dout_r;
-    if (tid < 24) s_feat[tid] = feat_r;
+    // ---------------- L0: the prefetched inputs have landed; pixel statistics
+    ss_dma_wait();    // this wave's pieces (issued a frame ago)
+    __syncthreads();  // A0: everybody's
+    uint4 m3w = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+      if ((tid + k * NT) * 16 < HW) px[k] = reinterpret_cast<const uint4*>(lds + STG_PX)[tid + k * NT];
+    if (tid * 16 < 24 * P) m3w = reinterpret_cast<const uint4*>(lds + STG_M3)[tid];
+    if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = reinterpret_cast<const uint4*>(lds + STG_I2)[tid];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (tid + k * NT < E * 24) s_wfc[tid + k * NT] = wfc_r[k];
     if (!LL::W3_RESIDENT)
       for (int q = tid; q < 3456 / 4; q += NT)
         reinterpret_cast<f32x4*>(w3s)[q] = reinterpret_cast<const f32x4*>(p.w3)[q];
-    if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = i2w;
     {
       unsigned su = 0, sq = 0;
 #pragma unroll
@@ -225,7 +262,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
       if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
     }
-    ss_dma_wait();  // this wave's pieces of the pooled-2 map (issued a frame ago) are in LDS
     {  // pooled-1 map: LDS-DMA, 1 KB per wave instruction, issued after every compiler-tracked load of this phase
        // has been consumed and waited for only before S3 (it flies under S1/S2)
       constexpr int BYTES = 8 * P1 * 4;
@@ -238,6 +274,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     __syncthreads();  // A
     STAMP(0);
 
+    // the dy3 planes held the staged inputs (all consumed before barrier A): back to zero, the fill below writes the
+    // interiors and the halo must be zero
+    for (int q = tid; q < (LL::o_da2m - LL::o_dy3h) / 4; q += NT)
+      reinterpret_cast<f32x4*>(dy3h)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < 24 * 16) {  // d feat[c] = sum_e d_out[e] * Wfc[e][c]: 16 lanes per channel, then a shuffle tree
       const int c = tid >> 4, sub = tid & 15;
       float s = 0.f;
@@ -552,6 +592,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     __syncthreads();  // da1 complete
     STAMP(9);
     if (n + (int)gridDim.x < p.N) prefetch_frame(n + gridDim.x);
+    STAMP(10);
     // ---------------- S5: conv1 weight gradient on the pooled grid (K = pooled pixels, whole rows per wave: row
     // bases + immediates)
     {
@@ -601,10 +642,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     }
     __syncthreads();  // E
     STAMP(7);
-    // restore the zero halo of the dy3 planes for the next frame (a2h arrives with its halo, interiors are rewritten)
-    for (int q = tid; q < (LL::o_da2m - LL::o_dy3h) / 4; q += NT)
-      reinterpret_cast<f32x4*>(dy3h)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();  // F
     STAMP(8);
   }
 

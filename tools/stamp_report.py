@@ -20,7 +20,7 @@ from silent_speech_amd import _lib as L  # noqa: E402
 FWD = {15: "loop top", 0: "stats+normalise", 1: "conv1 (MFMA)", 2: "a1 stash copy + conv2 (MFMA)", 3: "a2 stash copy",
        4: "conv3 (MFMA)", 5: "feat + fc"}
 BWD = {15: "loop top", 0: "L0 loads a2/i2/a1", 1: "dfeat + fc grads", 2: "dy3 fill", 3: "S1 dW3", 4: "S2 da2",
-       5: "T phase switch (dy2, x, i1)", 6: "S3 dW2", 9: "S4 da1", 7: "S5 dW1 (MFMA)", 8: "halo re-zero"}
+       5: "T phase switch (dy2, x, i1)", 6: "S3 dW2", 9: "S4 da1", 10: "prefetch of the next frame (issue)", 7: "S5 dW1 (MFMA)", 8: "halo re-zero"}
 
 
 def main():
