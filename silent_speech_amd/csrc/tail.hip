@@ -10,7 +10,8 @@
 
 namespace {
 
-constexpr int TNT = 256;
+constexpr int TNT = 1024;  // 16 waves per clip: the stages are chains of L2 / HBM latencies, more waves = fewer links per chain
+constexpr int NWT = TNT / 64;
 
 __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                         uint32_t out[4]) {
@@ -34,12 +35,15 @@ __device__ __forceinline__ float drop_scale(long idx, float p, uint64_t seed, ui
   return rnd[idx & 3] >= thr ? 1.0f / (1.0f - p) : 0.f;
 }
 
-__device__ __forceinline__ float block_sum(float v, float* red) {  // 4 waves; all threads get the sum
+__device__ __forceinline__ float block_sum(float v, float* red) {  // NWT waves; all threads get the sum
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NWT; ++k) s += red[k];
+  return s;
 }
 
 struct TailFwdParams {
@@ -57,7 +61,7 @@ struct TailFwdParams {
 // dynamic LDS: sc[T] | pooled[D] | lnv[D] | midv[MID] | lg[C]
 __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  __shared__ float red[8];
+  __shared__ float red[2 * NWT];
   const int T = p.T, D = p.D, MID = p.MID, C = p.C;
   float* sc = sm;
   float* pooled = sc + T;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
 
   // ---- AttnPool: scores, masked softmax over t, weighted sum
   const float bsc = p.b_score[0];
-  for (int t = wv; t < T; t += 4) {
+  for (int t = wv; t < T; t += NWT) {
     float s = -1e9f;  // masked_fill(~mask, -1e9), train_model_official.py:245
     if (t < len) {
       s = 0.f;
@@ -85,14 +89,16 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
   m = wave_max(m);
   if (lane == 0) red[wv] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  m = red[0];
+#pragma unroll
+  for (int k = 1; k < NWT; ++k) m = fmaxf(m, red[k]);
   float sum = 0.f;
   for (int t = tid; t < T; t += TNT) {
     const float e = expf(sc[t] - m);
     sc[t] = e;
     sum += e;
   }
-  sum = block_sum(sum, red + 4);
+  sum = block_sum(sum, red + NWT);
   const float inv = 1.0f / sum;
   for (int t = tid; t < T; t += TNT) {
     const float wt = sc[t] * inv;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
     const float c = pooled[d] - mean;
     s2 += c * c;
   }
-  const float rs = rsqrtf(block_sum(s2, red + 4) / D + p.eps);
+  const float rs = rsqrtf(block_sum(s2, red + NWT) / D + p.eps);
   for (int d = tid; d < D; d += TNT) {
     const float xh = (pooled[d] - mean) * rs;
     const float v = xh * p.gamma[d] + p.beta[d];
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
   __syncthreads();
   // ---- Linear(D -> MID) + ReLU + Dropout: a wave per output row, lanes across the row (coalesced weight reads);
   // four rows at a time so the four shuffle-reduction chains interleave
-  for (int o0 = 4 * wv; o0 < MID; o0 += 16) {
+  for (int o0 = 4 * wv; o0 < MID; o0 += 4 * NWT) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int d = lane; d < D; d += 64) {
       const float x = lnv[d];
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
   }
   __syncthreads();
   // ---- Linear(MID -> C)
-  for (int c = wv; c < C; c += 4) {
+  for (int c = wv; c < C; c += NWT) {
     float acc = 0.f;
     const float* wr = p.w4 + (long)c * MID;
     for (int o = lane; o < MID; o += 64) acc += wr[o] * midv[o];
@@ -209,7 +215,7 @@ struct TailBwdParams {
 // dynamic LDS: dmid[MID] | dp[D] | ds[T] | wt[T] | dl[C]
 __global__ __launch_bounds__(TNT) void tail_bwd_kernel(TailBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  __shared__ float red[8];
+  __shared__ float red[2 * NWT];
   const int T = p.T, D = p.D, MID = p.MID, C = p.C;
   float* dmid = sm;
   float* dp = dmid + MID;
@@ -247,12 +253,12 @@ __global__ __launch_bounds__(TNT) void tail_bwd_kernel(TailBwdParams p) {
     s2 += dxh * xh;
   }
   s1 = block_sum(s1, red) / D;
-  s2 = block_sum(s2, red + 4) / D;
+  s2 = block_sum(s2, red + NWT) / D;
   const float rs = p.rstd[b];
   for (int d = tid; d < D; d += TNT) dp[d] = rs * (dp[d] - s1 - p.xhat[(long)b * D + d] * s2);  // d pooled
   __syncthreads();
   // ---- AttnPool backward
-  for (int t = wv; t < T; t += 4) {
+  for (int t = wv; t < T; t += NWT) {
     float c = 0.f;
     if (t < len) {
       for (int d = lane; d < D; d += 64) c += hb[(long)t * D + d] * dp[d];
