@@ -226,28 +226,44 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
   const bool accumulate = p.flags & 1, relu = p.flags & 2;
   const bool atomic = p.nz > 1 || (p.flags & 4);
+  auto emit = [&](const f32x4& av, int mt, int nt) {
+    int col = n0 + wn * 32 + nt * 16 + i;
+    if (col >= p.N) return;
+    float bv = (p.bias && zs == 0) ? p.bias[col] : 0.f;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      int col = n0 + wn * 32 + nt * 16 + i;
-      if (col >= p.N) continue;
-      float bv = (p.bias && zs == 0) ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = m0 + wm * 64 + mt * 16 + 4 * g + r;
-        if (row >= p.M) continue;
-        float v = acc[mt][nt][r] + bv;
-        float* dst = p.C + (long)row * p.ldc + col;
-        if (atomic) {
-          atomicAdd(dst, v);
-        } else {
-          if (accumulate) v += *dst;
-          if (relu) v = fmaxf(v, 0.f);
-          *dst = v;
-        }
+    for (int r = 0; r < 4; ++r) {
+      int row = m0 + wm * 64 + mt * 16 + 4 * g + r;
+      if (row >= p.M) continue;
+      float v = av[r] + bv;
+      float* dst = p.C + (long)row * p.ldc + col;
+      if (atomic) {
+        atomicAdd(dst, v);
+      } else {
+        if (accumulate) v += *dst;
+        if (relu) v = fmaxf(v, 0.f);
+        *dst = v;
       }
     }
+  };
+  if (p.nz > 1) {
+    // split-K slices of one tile reach their epilogues together: each starts at a different row group so that their
+    // atomics meet on different lines (wave-uniform rotation; costs a register-indexed read of the accumulators)
+    const int rot = zs & 3;
+#pragma unroll
+    for (int mt_ = 0; mt_ < 4; ++mt_) {
+      const int mt = (mt_ + rot) & 3;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 av = mt == 0 ? acc[0][nt] : mt == 1 ? acc[1][nt] : mt == 2 ? acc[2][nt] : acc[3][nt];
+        emit(av, mt, nt);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) emit(acc[mt][nt], mt, nt);
+  }
   STAMP_WAIT(4);
 #ifdef SS_STAMP
   {  // the first 256 workgroups in dispatch order report
