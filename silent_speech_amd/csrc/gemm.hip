@@ -109,7 +109,7 @@ struct Stager {
 constexpr int KSUB = 1;  // 16-wide k tiles per barrier (2 measured slower: the doubled LDS halves the co-resident workgroups)
 
 template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 waves per SIMD: <= 96 VGPRs, 5 x 29 KB of LDS per CU
   constexpr int A_SZ = A_KCONTIG ? BM * LDK : BK * LDM_A;
   constexpr int B_SZ = B_KCONTIG ? BN * LDK : BK * LDM_B;
   constexpr int STAGE = KSUB * (A_SZ + B_SZ);

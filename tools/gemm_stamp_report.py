@@ -19,6 +19,16 @@ from silent_speech_amd import engine as E  # noqa: E402
 NAMES = {15: "prologue", 1: "fetch issue + LDS reads + MFMAs", 2: "LDS store of next tile", 3: "barrier", 4: "epilogue (drained)"}
 
 
+def report(fn, title):
+    buf = np.zeros(256 * 16, np.uint64)
+    assert fn(buf.ctypes.data) == 0
+    t = buf.reshape(256, 16).astype(np.float64)
+    tot = t.sum(1).mean()
+    print(f"{title}: {tot / 2400:.2f} us per workgroup (first 256 workgroups)")
+    for k, nm in NAMES.items():
+        print(f"   {nm:34s} {t[:, k].mean() / 2400:7.2f} us  {100 * t[:, k].mean() / tot:5.1f} %")
+
+
 def main():
     dev = torch.device("cuda")
     B, T, H = 256, 30, 192
@@ -36,14 +46,17 @@ def main():
         for _ in range(3):
             E.gemm(0, 0, 2 * H, H, B * (T - 1), dG.data_ptr(), 4 * H, out.data_ptr(), 2 * H, gWh.data_ptr(), H,
                    accumulate=True, atomic=True, splits=splits, batch=2, strides=st, **maps)
-        buf = np.zeros(256 * 16, np.uint64)
-        assert fn(buf.ctypes.data) == 0
-        t = buf.reshape(256, 16).astype(np.float64)
-        tot = t.sum(1).mean()
         ktiles = -(-(B * (T - 1)) // splits) // 16
-        print(f"dW_hh 384x192xK, batch 2, splits {splits} (~{ktiles} k tiles per workgroup): {tot / 2400:.2f} us per workgroup")
-        for k, nm in NAMES.items():
-            print(f"   {nm:34s} {t[:, k].mean() / 2400:7.2f} us  {100 * t[:, k].mean() / tot:5.1f} %")
+        report(fn, f"dW_hh 384x192xK, batch 2, splits {splits} (~{ktiles} k tiles per workgroup)")
+    # the layer-1 input projection: (N x 384) . (576 x 384)^T per direction, K contiguous on both sides
+    x = torch.randn(N, 2 * H, device=dev)
+    w = torch.randn(2, 3 * H, 2 * H, device=dev)
+    b = torch.randn(2, 3 * H, device=dev)
+    gi = torch.empty(2, N, 3 * H, device=dev)
+    for _ in range(3):
+        E.gemm(1, 1, N, 3 * H, 2 * H, x.data_ptr(), 2 * H, w.data_ptr(), 2 * H, gi.data_ptr(), 3 * H, bias=b.data_ptr(), batch=2,
+               strides=(0, 3 * H * 2 * H, N * 3 * H, 3 * H, 0))
+    report(fn, "ih l1 7680x576x384, batch 2 (24 k tiles per workgroup, 1080 workgroups)")
 
 
 if __name__ == "__main__":
