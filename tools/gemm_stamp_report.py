@@ -57,6 +57,18 @@ def main():
         E.gemm(1, 1, N, 3 * H, 2 * H, x.data_ptr(), 2 * H, w.data_ptr(), 2 * H, gi.data_ptr(), 3 * H, bias=b.data_ptr(), batch=2,
                strides=(0, 3 * H * 2 * H, N * 3 * H, 3 * H, 0))
     report(fn, "ih l1 7680x576x384, batch 2 (24 k tiles per workgroup, 1080 workgroups)")
+    # d layer_in of layer 1: (N x 576) . (576 x 384) per direction, atomically summed over the directions
+    dx = torch.zeros(N, 2 * H, device=dev)
+    for _ in range(3):
+        E.gemm(1, 0, N, 2 * H, 3 * H, dG.data_ptr(), 4 * H, w.data_ptr(), 2 * H, dx.data_ptr(), 2 * H, accumulate=True, atomic=True,
+               batch=2, strides=(N * 4 * H, 3 * H * 2 * H, 0, 0, 0))
+    report(fn, "dX l1 7680x384x576, batch 2 (36 k tiles per workgroup, 720 workgroups, atomic)")
+    x0 = torch.randn(N, 116, device=dev)
+    w0 = torch.randn(2, 3 * H, 116, device=dev)
+    for _ in range(3):
+        E.gemm(1, 1, N, 3 * H, 116, x0.data_ptr(), 116, w0.data_ptr(), 116, gi.data_ptr(), 3 * H, bias=b.data_ptr(), batch=2,
+               strides=(0, 3 * H * 116, N * 3 * H, 3 * H, 0))
+    report(fn, "ih l0 7680x576x116, batch 2 (8 k tiles per workgroup, 1080 workgroups)")
 
 
 if __name__ == "__main__":
