@@ -277,7 +277,7 @@ STAMP_TABLE(ss_debug_stamps_gru)
 extern "C" int ss_gru_sync_bytes(int B, int T, int H, long* bytes) {
   SS_REQUIRE(bytes && B > 0 && T > 0 && H > 0, SS_ERR_ARG);
   const int P = gru_split_parts(B, T, H);
-  *bytes = P ? SYNC_HDR_WORDS * 4L + (gru_fwd_granules(B, H) + gru_bwd_granules(B, H, P)) * 8 : 0;
+  *bytes = P ? SYNC_HDR_WORDS * 4L + (gru_xid_granules(B, P) + gru_fwd_granules(B, H) + gru_bwd_granules(B, H, P)) * 8 : 0;
   return SS_OK;
 }
 
@@ -295,9 +295,10 @@ extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_h
   if (P) {
     dim3 sgrid(2 * ceil_div(B, SLICE) * P);
     unsigned* sy = static_cast<unsigned*>(sync_ws);
-    u64* hx = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
-    if (H == 192) hipLaunchKernelGGL((gru_split_fwd_kernel<192, 6>), sgrid, dim3(256), 0, s, p, sy, hx);
-    else hipLaunchKernelGGL((gru_split_fwd_kernel<64, 2>), sgrid, dim3(256), 0, s, p, sy, hx);
+    u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
+    u64* hx = xid + gru_xid_granules(B, P);
+    if (H == 192) hipLaunchKernelGGL((gru_split_fwd_kernel<192, 6>), sgrid, dim3(256), 0, s, p, sy, xid, hx);
+    else hipLaunchKernelGGL((gru_split_fwd_kernel<64, 2>), sgrid, dim3(256), 0, s, p, sy, xid, hx);
     return ss_launch_status();
   }
   if (H == 192) hipLaunchKernelGGL(gru_fwd_kernel<192>, grid, dim3(768), 0, s, p);
@@ -320,9 +321,10 @@ extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* sav
   if (P) {
     dim3 sgrid(2 * ceil_div(B, SLICE) * P);
     unsigned* sy = static_cast<unsigned*>(sync_ws);
-    u64* xg = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS) + gru_fwd_granules(B, H);
-    if (H == 192) hipLaunchKernelGGL((gru_split_bwd_kernel<192, 6>), sgrid, dim3(256), 0, s, p, sy, xg);
-    else hipLaunchKernelGGL((gru_split_bwd_kernel<64, 2>), sgrid, dim3(256), 0, s, p, sy, xg);
+    u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
+    u64* xg = xid + gru_xid_granules(B, P) + gru_fwd_granules(B, H);
+    if (H == 192) hipLaunchKernelGGL((gru_split_bwd_kernel<192, 6>), sgrid, dim3(256), 0, s, p, sy, xid, xg);
+    else hipLaunchKernelGGL((gru_split_bwd_kernel<64, 2>), sgrid, dim3(256), 0, s, p, sy, xid, xg);
     return ss_launch_status();
   }
   if (H == 192) hipLaunchKernelGGL(gru_bwd_kernel<192>, grid, dim3(768), 0, s, p);

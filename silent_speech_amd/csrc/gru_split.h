@@ -20,12 +20,23 @@
 // nothing has to be cleared between launches.  Buffers alternate with the step parity: a slot is rewritten two
 // steps later, which its reader has provably left (it had to publish the step in between first).
 //
-// Progress: the P partners are consecutive workgroups of the grid, the launcher only picks this form when the whole
+// Same-XCD fast path: a write-through (sc1) granule leaves the writer's L2 and a partner reads it back from memory.
+// When all P partners of a pair run on ONE XCD -- workgroups are dealt round-robin over the 8 XCDs, so the grid is
+// ordered part-major whenever the pair count is a multiple of 8 -- their shared L2 is the coherence point: plain
+// stores stay in it and the partners' sc1 loads (L1-bypassing, L2-served) find them there, a shorter round trip
+// (forward 3.5 -> 3.0 us per step, backward 4.7 -> 3.4).  Placement is never assumed: every workgroup reads its
+// HW_REG_XCC_ID, the partners exchange the ids once per launch through write-through granules, and only a pair whose
+// ids all agree switches to plain stores; the rest keep the write-through form.  Dirty granule lines never outlive a
+// launch (the end-of-kernel release writes the L2 back), and a stale copy can only ever show an old tag.
+//
+// Progress: the launcher only picks this form when the whole
 // grid is co-resident (<= 240 workgroups of 4 waves), and every wait is bounded -- a lost partner poisons the output
 // with NaN and counts an error in the sync header instead of hanging the GPU.
 //
 // sync_ws layout: [0] generation, [1] finished workgroups of the running launch, [2] sweep time-outs ever seen,
-// [.. 64) pad | forward granules [2][pairs][16][H] u64 | backward granules [2][pairs][P dest][P src][16][H/P] u64.
+// [3] workgroup-launches that took the same-XCD fast path,
+// [.. 64) pad | XCD ids [pairs][P] u64 | forward granules [2][pairs][16][H] u64 | backward granules
+// [2][pairs][P dest][P src][16][H/P] u64.
 // The owner zeroes it once; after that the kernels keep it consistent.
 #pragma once
 
@@ -48,9 +59,36 @@ __device__ __forceinline__ rsrc_t granule_rsrc(u64* base, long granules) {
 
 // Two adjacent granules in ONE 16-byte write-through store (each 8-byte half lands whole; a 16-byte sc1 store costs
 // the fabric what an 8-byte one does).  `pair` = index of the granule pair.
-__device__ __forceinline__ void store_granule_pair(rsrc_t rs, int pair, unsigned tag, float v0, float v1) {
+__device__ __forceinline__ void store_granule_pair(rsrc_t rs, int pair, unsigned tag, float v0, float v1, bool same_xcd) {
   const u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
-  __builtin_amdgcn_raw_buffer_store_b128(d, rs, pair * 16, 0, AUX_SC1);
+  if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(d, rs, pair * 16, 0, 0);  // stays in the shared L2 (wave-uniform branch)
+  else __builtin_amdgcn_raw_buffer_store_b128(d, rs, pair * 16, 0, AUX_SC1);
+}
+
+// Which XCD this workgroup runs on, and whether all P partners of its pair share it.  xid: [pairs][P] granules in the
+// sync header area, tag = generation base + 1023 (step tags are base + 1 .. base + 1022; never 0, the cleared state).
+__device__ __forceinline__ bool partners_share_xcd(u64* xid, int pair, int part, int P, unsigned base, unsigned* errors, int lane) {
+  base += 1023u;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 15u;
+  u64* mine = xid + (long)pair * P;
+  if (threadIdx.x == 0) __hip_atomic_store(mine + part, ((u64)base << 32) | xcc, __ATOMIC_RELAXED, SS_AGENT);
+  bool same = true;
+  for (int spins = 0;; ++spins) {
+    const u64 x = lane < P ? __hip_atomic_load(mine + lane, __ATOMIC_RELAXED, SS_AGENT) : (((u64)base << 32) | xcc);
+    const bool ok = (unsigned)(x >> 32) == base;
+    if (__all(ok)) {
+      same = __all((unsigned)x == xcc);
+      break;
+    }
+    if (spins > (1 << 20)) {
+      if (lane == 0) atomicAdd(errors, 1u);
+      same = false;
+      break;
+    }
+  }
+  return same;
 }
 
 // One wave re-reads its N granule pairs (pair stride 256: the whole workgroup sweeps a contiguous run) until every
@@ -100,13 +138,16 @@ struct SplitCfg {
 
 // grid: pairs * P workgroups, blockIdx.x = pair * P + part, pair = slice * 2 + direction
 template <int H, int P>
-__global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsigned* sync, u64* hx) {
+__global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsigned* sync, u64* xid, u64* hx) {
   using C = SplitCfg<H, P>;
   constexpr int LDH = H + 4;  // panel row stride: 16-byte aligned rows, clips 4 banks apart
   __shared__ __attribute__((aligned(16))) float red[C::RED];
   __shared__ __attribute__((aligned(16))) float hpan[SLICE * LDH];  // previous state of the slice, [clip][unit]
   __shared__ unsigned s_gen;
-  const int part = blockIdx.x % P, pair = blockIdx.x / P, pairs = gridDim.x / P;
+  // part-major when the pair count is a multiple of 8: workgroups b and b + 8k share an XCD, so do the partners then
+  const int pairs = gridDim.x / P;
+  const bool part_major = (pairs & 7) == 0;
+  const int part = part_major ? blockIdx.x / pairs : blockIdx.x % P, pair = part_major ? blockIdx.x % pairs : blockIdx.x / P;
   const int dir = pair & 1, b0 = (pair >> 1) * SLICE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ut = w % C::UT, kh = w / C::UT;
@@ -145,6 +186,8 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   __syncthreads();
   const unsigned gen = s_gen;
   const unsigned base = (gen & 0x3FFFFFu) << 10;
+  const bool same_xcd = partners_share_xcd(xid, pair, part, P, base, &sync[2], lane);
+  if (threadIdx.x == 0 && same_xcd) atomicAdd(&sync[3], 1u);  // observability: workgroup-launches on the fast path
 
   f32x4 hp = {0.f, 0.f, 0.f, 0.f};
   const long dir_off = (long)dir * p.B * T;
@@ -224,8 +267,8 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
       }
       if (s + 1 < T) {  // publish (padding clips too: the partners sweep whole panels)
         const int hw = ((((s & 1) * pairs + pair) * SLICE + i) * H + j0) / 2;
-        store_granule_pair(hrs, hw, base + (unsigned)s + 1u, o[0], o[1]);
-        store_granule_pair(hrs, hw + 1, base + (unsigned)s + 1u, o[2], o[3]);
+        store_granule_pair(hrs, hw, base + (unsigned)s + 1u, o[0], o[1], same_xcd);
+        store_granule_pair(hrs, hw + 1, base + (unsigned)s + 1u, o[2], o[3], same_xcd);
       }
       STAMP(4);
       if (clip_ok) {
@@ -247,7 +290,7 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
 
 // xg: [2 step parity][pairs][P dest parts][P source parts][16 clips][UP]  partial dh_prev granules
 template <int H, int P>
-__global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsigned* sync, u64* xg) {
+__global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsigned* sync, u64* xid, u64* xg) {
   using C = SplitCfg<H, P>;
   constexpr int KR = 3 * C::UP;        // contraction length of this part: its r | z | n rows
   constexpr int QK = KR / 16;          // 16-wide k groups
@@ -258,7 +301,10 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   __shared__ __attribute__((aligned(16))) float dpan[SLICE * LDP];     // this part's d_pre, [clip][local row]
   __shared__ __attribute__((aligned(16))) float dsum[SLICE * C::UP];   // summed dh_prev of this part's units
   __shared__ unsigned s_gen;
-  const int part = blockIdx.x % P, pair = blockIdx.x / P, pairs = gridDim.x / P;
+  // part-major when the pair count is a multiple of 8: workgroups b and b + 8k share an XCD, so do the partners then
+  const int pairs = gridDim.x / P;
+  const bool part_major = (pairs & 7) == 0;
+  const int part = part_major ? blockIdx.x / pairs : blockIdx.x % P, pair = part_major ? blockIdx.x % pairs : blockIdx.x / P;
   const int dir = pair & 1, b0 = (pair >> 1) * SLICE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ut = w % C::UT;
@@ -290,6 +336,8 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   __syncthreads();
   const unsigned gen = s_gen;
   const unsigned base = (gen & 0x3FFFFFu) << 10;
+  const bool same_xcd = partners_share_xcd(xid, pair, part, P, base, &sync[2], lane);
+  if (threadIdx.x == 0 && same_xcd) atomicAdd(&sync[3], 1u);  // observability: workgroup-launches on the fast path
 
   f32x4 dh = {0.f, 0.f, 0.f, 0.f};
   const long dir_off = (long)dir * p.B * T;
@@ -365,8 +413,8 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
       for (int nt = 0; nt < NT; ++nt) {
         const int U = 16 * (NT * w + nt) + 4 * g;
         const int dst = (xw + (((U / C::UP) * P + part) * SLICE + i) * C::UP + U % C::UP) / 2;
-        store_granule_pair(xrs, dst, base + (unsigned)s + 1u, acc[nt][0], acc[nt][1]);
-        store_granule_pair(xrs, dst + 1, base + (unsigned)s + 1u, acc[nt][2], acc[nt][3]);
+        store_granule_pair(xrs, dst, base + (unsigned)s + 1u, acc[nt][0], acc[nt][1], same_xcd);
+        store_granule_pair(xrs, dst + 1, base + (unsigned)s + 1u, acc[nt][2], acc[nt][3], same_xcd);
       }
       STAMP(2);
     }
@@ -401,6 +449,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
 }
 
 // sync_ws sections, in granules
+inline long gru_xid_granules(int B, int P) { return ((2L * ceil_div(B, SLICE) * P) + 7) / 8 * 8; }
 inline long gru_fwd_granules(int B, int H) { return 2L * (2 * ceil_div(B, SLICE)) * SLICE * H; }
 inline long gru_bwd_granules(int B, int H, int P) { return 2L * (2 * ceil_div(B, SLICE)) * P * SLICE * H; }
 

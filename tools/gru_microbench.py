@@ -49,7 +49,8 @@ def main():
 
         t1, t2, t3 = timed(lambda: fwd(save.data_ptr())), timed(lambda: fwd(None)), timed(bwd)
         errs = int(sync_ws[2]) if sync_ws is not None else 0
-        print(f"B={B:4d} T={T} {'multi-CU' if sync_ws is not None else 'one-CU  '} (wait time-outs {errs}): fwd+stash {t1:7.1f} us ({t1 / T:5.2f}/step)  fwd {t2:7.1f} us ({t2 / T:5.2f}/step)  "
+        fast = int(sync_ws[3]) if sync_ws is not None else 0
+        print(f"B={B:4d} T={T} {'multi-CU' if sync_ws is not None else 'one-CU  '} (wait time-outs {errs}, same-XCD workgroup launches {fast}): fwd+stash {t1:7.1f} us ({t1 / T:5.2f}/step)  fwd {t2:7.1f} us ({t2 / T:5.2f}/step)  "
               f"bwd {t3:7.1f} us ({t3 / T:5.2f}/step)")
 
 
