@@ -15,6 +15,8 @@ Data layout (fp32 row-major unless noted; N = B*T frames):
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -26,8 +28,9 @@ INT_MAX = 2**31 - 1
 # bench.py turns this off for its per-kernel timing pass: HIP-event pairs only bracket a kernel's own run time when
 # every launch sits on one stream
 JOIN_BEFORE_CNN_BWD = True
+SIDE_AFTER_DX = os.environ.get("SS_SIDE_AFTER_DX", "0") == "1"  # measured: 2.55 vs 2.52 ms/step, off
 USE_SPLIT_GRU = True
-USE_SIDE_STREAM = True
+USE_SIDE_STREAM = os.environ.get("SS_NO_SIDE_STREAM", "0") != "1"
 
 
 @dataclass
@@ -223,38 +226,45 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         else:
             use_drop = train and cfg.gru_dropout > 0.0
             lin, ld_in = (ws.out_drop[l - 1] if use_drop else ws.out[l - 1]).data_ptr(), 2 * H
-        # fork: everything that only feeds the parameter gradients of this layer goes to the side stream
-        side = ws.side if USE_SIDE_STREAM else torch.cuda.current_stream()
-        ws.ev_fork.record()
-        with torch.cuda.stream(side):
-            side.wait_event(ws.ev_fork)
-            # the cheap bias reduction goes first: whatever is still queued on this stream when the next chip-filling
-            # kernel of the main stream starts only finishes after it
-            L.call("ss_gru_bias_grad", ws.dG[l].data_ptr(), N, H, G[f"gru.bias_ih_l{l}"].data_ptr(),
-                   G[f"gru.bias_hh_l{l}"].data_ptr(), G[f"gru.bias_ih_l{l}_reverse"].data_ptr(),
-                   G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.stream())
-            dg = ws.dG[l].data_ptr()
-            wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
-            wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
-            # d W_ih = dGi^T . layer_in, both directions in one launch
-            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
-                 splits=split_k(3 * H, K, N, 2), tag="gemm_gru_dW", batch=2,
-                 strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0, 0))
-            # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse).
-            # With the row remap (group T-1 of stride T, A offset 1, B offset 0) the reverse direction is the same
-            # pairing seen from one row earlier in dG and one row later in out, i.e. two pointer shifts.
-            if T > 1:
-                maps = dict(a_map=(T - 1, T, 1), b_map=(T - 1, T, 0))
-                st = (N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr), 0, 0)
-                gw = G[wh]
-                gemm(0, 0, 2 * H, H, B * (T - 1), dg, 4 * H, ws.out[l].data_ptr(), 2 * H, gw.data_ptr(), H,
-                     accumulate=True, atomic=True, splits=split_k(2 * H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2,
-                     strides=st,
-                     **maps)
-                gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, ws.out[l].data_ptr(), 2 * H, _addr(gw, 2 * H * H), H,
-                     accumulate=True, atomic=True, splits=split_k(H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2,
-                     strides=st,
-                     **maps)
+        def side_work(l=l, K=K, lin=lin, ld_in=ld_in):
+            # fork: everything that only feeds the parameter gradients of this layer goes to the side stream
+            side = ws.side if USE_SIDE_STREAM else torch.cuda.current_stream()
+            ws.ev_fork.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ws.ev_fork)
+                # the cheap bias reduction goes first: whatever is still queued on this stream when the next chip-filling
+                # kernel of the main stream starts only finishes after it
+                L.call("ss_gru_bias_grad", ws.dG[l].data_ptr(), N, H, G[f"gru.bias_ih_l{l}"].data_ptr(),
+                       G[f"gru.bias_hh_l{l}"].data_ptr(), G[f"gru.bias_ih_l{l}_reverse"].data_ptr(),
+                       G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.stream())
+                dg = ws.dG[l].data_ptr()
+                wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
+                wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
+                # d W_ih = dGi^T . layer_in, both directions in one launch
+                gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
+                     splits=split_k(3 * H, K, N, 2), tag="gemm_gru_dW", batch=2,
+                     strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0, 0))
+                # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse).
+                # With the row remap (group T-1 of stride T, A offset 1, B offset 0) the reverse direction is the same
+                # pairing seen from one row earlier in dG and one row later in out, i.e. two pointer shifts.
+                if T > 1:
+                    maps = dict(a_map=(T - 1, T, 1), b_map=(T - 1, T, 0))
+                    st = (N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr), 0, 0)
+                    gw = G[wh]
+                    gemm(0, 0, 2 * H, H, B * (T - 1), dg, 4 * H, ws.out[l].data_ptr(), 2 * H, gw.data_ptr(), H,
+                         accumulate=True, atomic=True, splits=split_k(2 * H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2,
+                         strides=st,
+                         **maps)
+                    gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, ws.out[l].data_ptr(), 2 * H, _addr(gw, 2 * H * H), H,
+                         accumulate=True, atomic=True, splits=split_k(H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2,
+                         strides=st,
+                         **maps)
+        # the weight-gradient GEMMs of the upper layers start only when this layer's d layer_in GEMM is through: two
+        # MFMA-bound GEMMs side by side gain nothing and the one on the critical path loses half its rate; beside the
+        # latency-bound recurrence of the layer below they fill idle matrix pipes.  Layer 0 has no recurrence left to
+        # hide behind, so its weight gradients run beside its (short) d layer_in GEMM.
+        if not (SIDE_AFTER_DX and l > 0):
+            side_work()
         # d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r
         need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
         if need_dx:
@@ -273,6 +283,8 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                  atomic=True, tag="gemm_gru_dX", batch=2, strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0, 0))
             if l > 0 and train and cfg.gru_dropout > 0.0:
                 L.call("ss_dropout", dst, dst, N * 2 * H, cfg.gru_dropout, seed, l << 40, None, s)
+        if SIDE_AFTER_DX and l > 0:
+            side_work()
     # ---- ROI CNN
     if cfg.use_roi:
         Hh, Ww = ws.roi_hw
