@@ -33,7 +33,8 @@ extern "C" int ss_roi_cnn_set_max_workgroups(int n) {
 
 namespace {
 
-constexpr int NT = 512;  // threads per workgroup
+constexpr int NT = 256;  // threads per workgroup; TWO workgroups per CU (LDS image <= 80 KB): while one is in an epilogue, a
+                         // barrier or the statistics, the other's MFMAs keep the matrix pipes busy
 constexpr int NWV = NT / 64;
 
 struct CnnFwdParams {
@@ -55,17 +56,20 @@ struct CnnFwdParams {
 
 template <class G>
 struct FwdLds {
+  // region U holds the normalised frame + pool-1 argmaxes while conv1 runs, then the pooled-2 map + pool-2 argmaxes
+  // (conv2 writes them when conv1's inputs are dead): the image stays under half a CU's LDS
   static constexpr int o_xh = 0;                                // [(H+2)][XS]
-  static constexpr int o_a1 = ((G::H + 2) * G::XS + 3) & ~3;    // [8][P1]
-  static constexpr int o_a2 = o_a1 + 8 * G::P1;                 // [16][P2]
-  static constexpr int o_i1 = (o_a2 + 16 * G::P2 + 3) & ~3;     // bytes [8][I1S]
-  static constexpr int o_i2 = o_i1 + 2 * G::I1S;                // bytes [P][16]
-  static constexpr int o_misc = o_i2 + 4 * G::P + 256;  // the 256 floats in front hold the grey-level table
+  static constexpr int o_i1 = ((G::H + 2) * G::XS + 3) & ~3;    // bytes [8][I1S]
+  static constexpr int o_a2 = 0;                                // [16][P2]
+  static constexpr int o_i2 = 16 * G::P2;                       // bytes [P][16]
+  static constexpr int u_end1 = o_i1 + 2 * G::I1S, u_end2 = o_i2 + 4 * G::P;
+  static constexpr int o_a1 = ((u_end1 > u_end2 ? u_end1 : u_end2) + 3) & ~3;  // [8][P1]
+  static constexpr int o_misc = o_a1 + 8 * G::P1 + 256;  // the 256 floats in front hold the grey-level table
   static constexpr int total = o_misc + 512;
 };
 
 template <class G>
-__global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
+__global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = FwdLds<G>;
   constexpr int H = G::H, W = G::W, H2 = G::H2, W2 = G::W2, W4 = G::W4, HW = G::HW, P = G::P;
@@ -188,6 +192,15 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
           for (int b = 0; b < 4; ++b) dst[4 * e + b] = s_xn[(wds[e] >> (8 * b)) & 255u];
       }
     }
+    // the zero border of the frame: region U held the previous frame's pooled-2 map
+    for (int q = tid; q < 2 * XS + 2 * H; q += NT) {
+      int cell;
+      if (q < XS) cell = q;                                   // top row
+      else if (q < 2 * XS) cell = (H + 1) * XS + (q - XS);    // bottom row
+      else if (q < 2 * XS + H) cell = (q - 2 * XS + 1) * XS;  // left column
+      else cell = (q - 2 * XS - H + 1) * XS + W + 1;          // right column
+      xh[cell] = 0.f;
+    }
     // prefetch the next frame's bytes while this one is computed
     if (n + (int)gridDim.x < p.N) load_frame(n + gridDim.x);
     __syncthreads();
@@ -256,11 +269,25 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
     }
     __syncthreads();
     STAMP(1);
-    if (stash) {  // pooled-1 map (haloed image as it stands: the backward loads it linearly) and its argmaxes
-      f32x4* dst = reinterpret_cast<f32x4*>(p.st_a1 + (long)n * 8 * P1);
-      for (int q = tid; q < 2 * P1; q += NT) dst[q] = reinterpret_cast<const f32x4*>(a1)[q];
+    if (stash) {  // pool-1 argmaxes first: conv2 is about to write the pooled-2 map over them
       for (int q = tid; q < G::I1S / 2; q += NT)
         reinterpret_cast<uint4*>(p.st_i1 + (long)n * 8 * G::I1S)[q] = reinterpret_cast<const uint4*>(i1s)[q];
+    }
+    __syncthreads();
+    // the zero border of the pooled-2 planes (region U held the frame and the pool-1 argmaxes); conv2 writes interiors only
+    for (int q = tid; q < 16 * (2 * S2 + 2 * G::H4); q += NT) {
+      constexpr int per = 2 * S2 + 2 * G::H4;
+      const int pl = q / per, r = q % per;
+      int cell;
+      if (r < S2) cell = r;
+      else if (r < 2 * S2) cell = (G::H4 + 1) * S2 + (r - S2);
+      else if (r < 2 * S2 + G::H4) cell = (r - 2 * S2 + 1) * S2;
+      else cell = (r - 2 * S2 - G::H4 + 1) * S2 + W4 + 1;
+      a2[pl * P2 + cell] = 0.f;
+    }
+    if (stash) {  // pooled-1 map (haloed image as it stands: the backward loads it linearly)
+      f32x4* dst = reinterpret_cast<f32x4*>(p.st_a1 + (long)n * 8 * P1);
+      for (int q = tid; q < 2 * P1; q += NT) dst[q] = reinterpret_cast<const f32x4*>(a1)[q];
     }
 
     // ---------------- stage 2: conv2 (MFMA) + ReLU + pool -> a2 (haloed)
@@ -382,15 +409,15 @@ __global__ __launch_bounds__(NT) void roi_cnn_fwd_kernel(CnnFwdParams p) {
 template <class G>
 int launch_fwd(const CnnFwdParams& p, hipStream_t s) {
   constexpr size_t lds_bytes = (size_t)FwdLds<G>::total * sizeof(float);
-  static_assert(lds_bytes <= 160 * 1024, "ROI size does not fit the CU's LDS");
+  static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU: the LDS image must stay under half a CU");
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_cnn_fwd_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
+                            80 * 1024) != hipSuccess)
       return SS_ERR_LAUNCH;
     attr_set = true;
   }
-  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256;
+  const int cap = 2 * (ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256);  // the cap counts CUs
   const int grid = p.N < cap ? p.N : cap;
   hipLaunchKernelGGL(roi_cnn_fwd_kernel<G>, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();

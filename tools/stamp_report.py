@@ -42,9 +42,10 @@ def main():
         assert fn(buf.ctypes.data) == 0
         t = buf.reshape(256, 16).astype(np.float64)
         tot = t.sum(1).mean()
-        print(f"kernel {'roi_cnn_fwd' if which == 0 else 'roi_cnn_bwd'}: {tot / 30:.0f} cycles per frame (mean over workgroups, 30 frames each)")
+        fpw = 15 if which == 0 else 30  # forward: 512 workgroups of 256 threads (two per CU), backward: 256 of 512
+        print(f"kernel {'roi_cnn_fwd' if which == 0 else 'roi_cnn_bwd'}: {tot / fpw:.0f} cycles per frame (mean over the first 256 workgroups, {fpw} frames each)")
         for k, name in names.items():
-            print(f"   {name:28s} {t[:, k].mean() / 30:9.0f} cyc/frame  {100 * t[:, k].mean() / tot:5.1f} %")
+            print(f"   {name:28s} {t[:, k].mean() / fpw:9.0f} cyc/frame  {100 * t[:, k].mean() / tot:5.1f} %")
 
 
 if __name__ == "__main__":
