@@ -168,6 +168,10 @@ struct GruBwdParams {
   const int* lengths;
   float* d_g;           // [2][B*T][4][H]: d a_r, d a_z, d a_n (= d gi), and d a_n * r (hh side of n)
   int B, T;
+  // d_out is the gradient w.r.t. the DROPPED-OUT output of this layer when drop_p > 0: the mask of the forward
+  // (ss_dropout stream (seed, offset) over the (B*T, 2H) tensor) is re-drawn while d_out is read
+  float drop_p;
+  uint64_t drop_seed, drop_off;
 };
 
 template <int H>
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(H * 4) void gru_bwd_kernel(GruBwdParams p) {
     f32x4 dar = {0.f, 0.f, 0.f, 0.f}, daz = dar, dan = dar, dqn = dar, dcarry = dh;
     if (valid) {
       f32x4 go = *reinterpret_cast<const f32x4*>(p.d_out + frame * (2 * H) + dir * H + j0);
+      if (p.drop_p > 0.f) go *= drop_scale4((frame * (2 * H) + dir * H + j0) >> 2, p.drop_p, p.drop_seed, p.drop_off);
       const float* sp = p.save + (dir_off + frame) * (4 * H) + j0;
       f32x4 r = *reinterpret_cast<const f32x4*>(sp);
       f32x4 z = *reinterpret_cast<const f32x4*>(sp + H);
@@ -309,12 +314,13 @@ extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_h
 
 extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* save, const float* w_hh_f,
                           const float* w_hh_r, const int32_t* lengths, int B, int T, int H, float* d_g,
-                          void* sync_ws, ss_stream_t stream) {
+                          float drop_p, uint64_t drop_seed, uint64_t drop_offset, void* sync_ws, ss_stream_t stream) {
   SS_REQUIRE(d_out && out && save && w_hh_f && w_hh_r && lengths && d_g, SS_ERR_ARG);
-  SS_REQUIRE(B > 0 && T > 0, SS_ERR_ARG);
+  SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
   GruBwdParams p;
   p.d_out = d_out; p.out = out; p.save = save; p.w_hh[0] = w_hh_f; p.w_hh[1] = w_hh_r;
   p.lengths = lengths; p.d_g = d_g; p.B = B; p.T = T;
+  p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_off = drop_offset;
   dim3 grid(ceil_div(B, SLICE), 2);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int P = sync_ws ? gru_split_parts(B, T, H) : 0;

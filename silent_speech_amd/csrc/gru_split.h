@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
     if (owner && t < len) {
       const long frame = (long)clip * T + t;
       go = *reinterpret_cast<const f32x4*>(p.d_out + frame * (2 * H) + dir * H + j0);
+      if (p.drop_p > 0.f) go *= drop_scale4((frame * (2 * H) + dir * H + j0) >> 2, p.drop_p, p.drop_seed, p.drop_off);
       const float* sp = p.save + (dir_off + frame) * (4 * H) + j0;
       sr = *reinterpret_cast<const f32x4*>(sp);
       sz = *reinterpret_cast<const f32x4*>(sp + H);

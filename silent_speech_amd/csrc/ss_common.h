@@ -48,6 +48,30 @@ __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rc
 // tanh via one exp; saturates cleanly (exp->inf gives 1, exp->0 gives -1)
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
+// Philox4x32-10, one counter per 4 consecutive elements: the dropout stream of ss_dropout (pool_head.hip), also drawn
+// inside the fused kernels so a mask never has to be materialised.
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                        uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// keep-scales of the 4 elements [4q, 4q+4) of a dropout stream (p > 0)
+__device__ __forceinline__ f32x4 drop_scale4(long q, float p, uint64_t seed, uint64_t offset) {
+  uint32_t rnd[4];
+  const uint64_t ctr = offset + (uint64_t)q;
+  philox4((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  const float keep = 1.0f / (1.0f - p);
+  return f32x4{rnd[0] >= thr ? keep : 0.f, rnd[1] >= thr ? keep : 0.f, rnd[2] >= thr ? keep : 0.f, rnd[3] >= thr ? keep : 0.f};
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- diagnostic build only (-DSS_STAMP): per-stage cycle shares of the persistent kernels.

@@ -13,17 +13,6 @@ namespace {
 constexpr int TNT = 1024;  // 16 waves per clip: the stages are chains of L2 / HBM latencies, more waves = fewer links per chain
 constexpr int NWT = TNT / 64;
 
-__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                        uint32_t out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
 
 // keep-scale of element idx of a dropout stream: the same stream ss_dropout draws (one Philox counter per 4 elements)
 __device__ __forceinline__ float drop_scale(long idx, float p, uint64_t seed, uint64_t offset) {

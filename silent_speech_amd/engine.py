@@ -110,6 +110,10 @@ class Workspace:
             self.save = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
             self.dG = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
             self.d_out = torch.empty(N, 2 * H, **f32)
+            # gradient w.r.t. the output of layer l-1 (destination of layer l's d layer_in GEMM, l >= 1): zeroed on the side
+            # stream while the top of the backward pass runs, summed into with atomics by both directions
+            self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
+            self.ev_zero = torch.cuda.Event()
             self.xhat = torch.empty(B, 2 * H, **f32)
             self.rstd = torch.empty(B, **f32)
             self.d_logits = torch.empty(B, cfg.num_classes, **f32)
@@ -212,12 +216,23 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
              accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
         gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
              2 * H, accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
+        # the atomically summed destinations of the d layer_in GEMMs: cleared here, off the critical path
+        for t_ in ws.d_lower[1:]:
+            t_.zero_()
+        if cfg.use_roi:
+            ws.dZ.zero_()
+        ws.ev_zero.record()
     # ---- GRU layers, top down
+    use_drop = train and cfg.gru_dropout > 0.0
     for l in range(cfg.gru_layers - 1, -1, -1):
         K = cfg.in_dim if l == 0 else 2 * H
-        L.call("ss_gru_bwd", ws.d_out.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(),
+        # layers below the top read the gradient w.r.t. their DROPPED-OUT output; the kernel re-draws the mask
+        top_layer = l == cfg.gru_layers - 1
+        g_in = ws.d_out if top_layer else ws.d_lower[l + 1]
+        L.call("ss_gru_bwd", g_in.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(),
                P[f"gru.weight_hh_l{l}"].data_ptr(), P[f"gru.weight_hh_l{l}_reverse"].data_ptr(),
-               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), L.ptr(ws.gru_sync), s)
+               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(),
+               0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed, (l + 1) << 40, L.ptr(ws.gru_sync), s)
         if l == 0:
             if cfg.use_roi:
                 lin, ld_in = ws.Z.data_ptr(), cfg.in_dim
@@ -268,21 +283,19 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         # d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r
         need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
         if need_dx:
+            # both directions in ONE launch (twice the workgroups: the N=116 case alone leaves half the CUs idle),
+            # summed with float atomics into a destination that was zeroed on the side stream
             if l > 0:
-                dst, ld_dst = ws.d_out.data_ptr(), 2 * H
+                dst, ld_dst = ws.d_lower[l].data_ptr(), 2 * H
             elif cfg.use_roi:
                 dst, ld_dst = ws.dZ.data_ptr(), cfg.in_dim
             else:
                 dst, ld_dst = d_X.data_ptr(), cfg.x_dim
-            # both directions in ONE launch (twice the workgroups: the N=116 case alone leaves half the CUs idle),
-            # summed with float atomics into a zeroed destination
-            dst_t = ws.d_out if l > 0 else (ws.dZ if cfg.use_roi else d_X)
-            dst_t.zero_()
+                d_X.zero_()
+            torch.cuda.current_stream().wait_event(ws.ev_zero)
             wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
             gemm(1, 0, N, K, 3 * H, ws.dG[l].data_ptr(), 4 * H, P[wi].data_ptr(), K, dst, ld_dst, accumulate=True,
                  atomic=True, tag="gemm_gru_dX", batch=2, strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0, 0))
-            if l > 0 and train and cfg.gru_dropout > 0.0:
-                L.call("ss_dropout", dst, dst, N * 2 * H, cfg.gru_dropout, seed, l << 40, None, s)
         if SIDE_AFTER_DX and l > 0:
             side_work()
     # ---- ROI CNN
