@@ -151,11 +151,8 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
           }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      su += __shfl_xor(su, o, 64);
-      sq += __shfl_xor(sq, o, 64);
-    }
+    su = wave_sum_u32(su);
+    sq = wave_sum_u32(sq);
     if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
     __syncthreads();
     if (tid == 0) {

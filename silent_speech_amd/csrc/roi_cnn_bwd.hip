@@ -255,11 +255,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
             }
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        su += __shfl_xor(su, o, 64);
-        sq += __shfl_xor(sq, o, 64);
-      }
+      su = wave_sum_u32(su);
+      sq = wave_sum_u32(sq);
       if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
     }
     {  // pooled-1 map: LDS-DMA, 1 KB per wave instruction, issued after every compiler-tracked load of this phase
@@ -282,8 +279,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       const int c = tid >> 4, sub = tid & 15;
       float s = 0.f;
       for (int e = sub; e < E; e += 16) s += s_dout[e] * s_wfc[e * 24 + c];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      s = row_sum(s);  // the 16 lanes of a channel are one DPP row
       if (sub == 0) s_dfeat[c] = s / (float)P;
     }
     if (tid == 32) {

@@ -30,16 +30,52 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // (left alone, hipcc sinks every read next to its MFMA and waits lgkmcnt(0) in between: one LDS latency per MFMA).
 #define SS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide reductions on the DPP crossbar instead of __shfl_xor (which lowers to ds_bpermute_b32: one LDS round
+// trip, ~100 cycles, per butterfly level).  Four DPP levels leave every lane of a 16-lane row with its row's result,
+// four v_readlane + three VALU ops combine the rows: ~40 cycles for a 64-lane reduction instead of ~600.
+#define SS_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+#define SS_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xf, 0xf, false)
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7 - i inside each half row
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15 - i inside each row
+
+__device__ __forceinline__ float row_sum(float v) {  // sum over each 16-lane row, result in every lane of the row
+  v += SS_DPP_F(v, DPP_XOR1);
+  v += SS_DPP_F(v, DPP_XOR2);
+  v += SS_DPP_F(v, DPP_HALF_MIRROR);
+  v += SS_DPP_F(v, DPP_MIRROR);
   return v;
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_sum(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  v += (unsigned)SS_DPP_I(v, DPP_XOR1);
+  v += (unsigned)SS_DPP_I(v, DPP_XOR2);
+  v += (unsigned)SS_DPP_I(v, DPP_HALF_MIRROR);
+  v += (unsigned)SS_DPP_I(v, DPP_MIRROR);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
+         (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, SS_DPP_F(v, DPP_XOR1));
+  v = fmaxf(v, SS_DPP_F(v, DPP_XOR2));
+  v = fmaxf(v, SS_DPP_F(v, DPP_HALF_MIRROR));
+  v = fmaxf(v, SS_DPP_F(v, DPP_MIRROR));
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): the gates sit on the recurrence's critical path between two workgroup barriers,

@@ -130,9 +130,7 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
         if (o0 + u < MID) acc[u] += p.w1[(long)(o0 + u) * D + d] * x;
     }
 #pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], sft, 64);
+    for (int u = 0; u < 4; ++u) acc[u] = wave_sum(acc[u]);
     if (lane < 4 && o0 + lane < MID) {
       const int o = o0 + lane;
       const float a = fmaxf((lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]) + p.b1[o], 0.f);
