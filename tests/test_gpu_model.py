@@ -153,6 +153,27 @@ def test_config2_shapes_vs_oracle(ss):
     assert float((after.cpu() - ref_after).abs().max()) < 2e-4
 
 
+@pytest.mark.parametrize("roi,B,T", [((48, 96), 9, 11), ((32, 32), 20, 6), ((64, 64), 130, 5)])
+def test_train_step_other_geometries_vs_oracle(ss, roi, B, T):
+    """The reference's shipped ROI size (48x96), the smallest built one, and a batch whose (slice, direction) count is
+    not a multiple of 8 (write-through granules) next to one that is: one fused step against the oracle's."""
+    sd = W.make_state_dict(11, 84, 5, True)
+    X, Lh, R, y = W.make_inputs(11, B, T, 84, 5, roi)
+    m = ss.BiGRUClassifier(84, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    tr = ss.Trainer(m, dropout=False)
+    loss, _ = tr.step(X.cuda(), Lh.cuda(), R.cuda(), y.cuda())
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    loss_ref, _, _, total = MR.train_step(sd2, {}, X, Lh, R, y, impl="aten")
+    assert abs(float(loss) - float(loss_ref)) < 2e-5
+    assert abs(float(tr.grad_norm()) - total) < 1e-3 * total
+    with torch.no_grad():
+        after = m(X.cuda(), Lh, R.cuda())
+    ref_after = MR.forward(sd2, X, Lh, R, impl="aten")
+    assert float((after.cpu() - ref_after).abs().max()) < 2e-4
+
+
 def test_micro_batch_streams_match_oracle(ss):
     """Two micro-batches on two HIP streams (Trainer(micro_batches=2)) add up to the same step as the oracle's."""
     B, T = 32, 12
