@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
-    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+    ap.add_argument("--mode", choices=["train", "infer", "assemble"], default="train",
                     help="train = the headline metric; infer = BASELINE config 4 (T=60, B=4096 windows, forward-only, hipGraph)")
     ap.add_argument("--micro-batches", type=int, default=1, help="slices of the per-GPU batch kept in flight on separate streams")
     args = ap.parse_args()
@@ -171,6 +171,52 @@ def main():
                           "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True, "dtype": "f32",
                           "data": "synthetic", "config": {"workload": f"BASELINE config 4: {B} sliding windows x T={T}, "
                                                           f"landmark + {roi}x{roi} ROI CNN + BiGRU, forward-only, hipGraph replay"}}))
+        return
+    if args.mode == "assemble":
+        # a training batch gathered out of a clip store that lives in HBM (noise, frame drop, pad / trim)
+        import tempfile
+
+        from silent_speech_amd import data as Dm
+
+        rs = __import__("numpy").random.default_rng(0)
+        with tempfile.TemporaryDirectory() as tmp:
+            files = []
+            for k in range(64):  # 64 distinct clips, visited many times: the store is what matters, not the file count
+                Tk = int(rs.integers(T, T + 8))
+                p_ = os.path.join(tmp, f"c{k}.npz")
+                Dm.save_clip(p_, rs.normal(size=(Tk, D)).astype("float32"), range(Tk), "w%d" % (k % C), "me", range(4),
+                             rs.integers(0, 256, (Tk, roi, roi), dtype="uint8"))
+                files.append(p_)
+            store = ss.DeviceClipStore(files, {"w%d" % c: c for c in range(C)}, max_t=T, device=dev)
+        order = [int(v) for v in rs.integers(0, len(store), B)]
+        gen = __import__("numpy").random.default_rng(1)
+        for _ in range(args.warmup):
+            store.batch(order, augment=True, rng="device", generator=gen)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            Xb, Tb, Rb, yb = store.batch(order, augment=True, rng="device", generator=gen)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        # the two gather launches alone, HIP events on their stream
+        L.PROFILE = {}
+        for _ in range(args.steps):
+            store.batch(order, augment=True, rng="device", generator=gen)
+        torch.cuda.synchronize()
+        prof, L.PROFILE = L.PROFILE, None
+        k_ms = {tag: sum(a.elapsed_time(b) for a, b in evs) / len(evs) for tag, evs in prof.items()}
+        frame_bytes = roi * roi
+        alg = 2 * B * T * frame_bytes + B * T * 4  # ROI gather: read + write + its map
+        u8_ms = k_ms.get("ss_batch_gather_u8", float("nan"))
+        print(json.dumps({"metric": "batches/sec assembled on device (B=%d, T=%d, %dx%d ROI, augment on)" % (B, T, roi, roi),
+                          "value": round(args.steps / el, 1), "unit": "batches/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True,
+                          "dtype": "u8/f32", "data": "synthetic",
+                          "config": {"workload": "SURVEY 8f-1: NPZWordDataset + collate_fn rules on a clip store resident in HBM"},
+                          "roofline": {"kernel": "ss_batch_gather_u8", "bound": "hbm", "achieved": round(alg / u8_ms / 1e6, 1),
+                                       "peak": 8000.0, "unit": "GB/s", "frac": round(alg / u8_ms / 1e6 / 8000.0, 4), "traffic": None,
+                                       "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(u8_ms, 4)},
+                          "kernels_ms": {k: round(v, 4) for k, v in k_ms.items()}}))
         return
     model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).train()
     if world > 1:

@@ -129,6 +129,20 @@ int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const
 /* column sums: out[n] += sum_r A[r*lda + n]  (bias gradients) */
 int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_stream_t stream);
 
+/* ---- a3: batch assembly on the device ----------------------------------------------
+ * replaces NPZWordDataset.__getitem__ + collate_fn (train_model_official.py:122-204) for clips that are
+ * resident in HBM as one ragged frame store: additive feature noise (:143-145), interior frame drop (:146-152,
+ * expressed through the map), zero padding / trimming to max_t (:93-118), stacking (:174-204).
+ * frame_map (rows = B*max_t) int32: row of the store that lands in each destination row, -1 = zero padding.
+ * f32: dst (rows, D) = gathered rows + noise on the rows whose noise_map entry is >= 0 (NULL map: none):
+ *      noise != NULL -> noise[noise_map[r]] (host-drawn, bit-exact with the reference's np.random.normal);
+ *      noise == NULL and noise_std > 0 -> noise_std * N(0,1) from the Philox stream (seed, element index).
+ * u8 : dst (rows, frame_bytes), frame_bytes a multiple of 16 (ROI frames). */
+int ss_batch_gather_f32(const float* src, int D, const int32_t* frame_map, long rows, const float* noise,
+                        const int32_t* noise_map, float noise_std, uint64_t seed, float* dst, ss_stream_t stream);
+int ss_batch_gather_u8(const uint8_t* src, int frame_bytes, const int32_t* frame_map, long rows, uint8_t* dst,
+                       ss_stream_t stream);
+
 /* ---- a7: one bidirectional GRU layer, recurrence only ---------------------------------------
  * replaces pack_padded_sequence -> nn.GRU -> pad_packed_sequence (train_model_official.py:301-305).
  * gi      (2, B*T, 3H): W_ih x + b_ih per direction (forward, reverse), from ss_gemm_f32

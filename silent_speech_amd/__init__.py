@@ -8,6 +8,7 @@ there is no CPU or PyTorch-op fallback.
 """
 from . import checkpoint, data, features
 from .checkpoint import load_classifier, save_checkpoint, topk_from_logits
+from .device_data import DeviceClipStore
 from .engine import Config
 from .features import crop_boxes, extract_features
 from .infer import GraphedInference

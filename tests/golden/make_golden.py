@@ -253,6 +253,51 @@ def gen_crop(rec, live):
     print("wrote crop", rows.shape, "valid frac", rows[:, 6].mean())
 
 
+# ------------------------------------------------------------------ dataset / augmentation / collate
+def gen_dataset(tmo):
+    """Runs the reference's NPZWordDataset(augment=True) + collate_fn on synthetic clips under fixed seeds and stores the
+    clips, the seeds, the visiting order and the batches it produced."""
+    import random
+
+    rng = np.random.default_rng(77)
+    D, H, W, max_t = 12, 16, 16, 24
+    specs = [(30, 31, "yes"), (13, 13, "no"), (40, 38, "yes"), (9, 9, "no"), (24, None, "yes"), (26, 20, "no")]  # (T, Tr, label)
+    out = {"max_t": max_t, "n_clips": len(specs)}
+    label_to_id = {"no": 0, "yes": 1}
+    with tempfile.TemporaryDirectory() as tmp:
+        files = []
+        for k, (T, Tr, lab) in enumerate(specs):
+            X = rng.normal(size=(T, D)).astype(np.float32)
+            save = dict(X=X, ts=np.arange(T), label=lab, speaker="me", idxs=np.arange(4))
+            if Tr is not None:
+                save["roi"] = rng.integers(0, 256, (Tr, H, W), dtype=np.uint8)
+                out[f"clip{k}::roi"] = save["roi"]
+            f = os.path.join(tmp, f"c{k}.npz")
+            np.savez_compressed(f, **save)
+            files.append(f)
+            out[f"clip{k}::X"], out[f"clip{k}::label"] = X, lab
+        old_hw = (tmo.ROI_H, tmo.ROI_W)
+        tmo.ROI_H, tmo.ROI_W = H, W  # collate_fn pads roi-less clips with zeros of the module-level size
+        try:
+            ds = tmo.NPZWordDataset(files, label_to_id, max_t=max_t, augment=True, use_roi=True)
+            orders = [[0, 1, 2, 3, 4, 5], [5, 0, 2], [4, 4, 1, 3]]
+            for b, order in enumerate(orders):
+                random.seed(1000 + b)
+                np.random.seed(2000 + b)
+                Xb, Tb, Rb, yb = tmo.collate_fn([ds[i] for i in order])
+                out[f"batch{b}::order"] = np.asarray(order)
+                out[f"batch{b}::X"], out[f"batch{b}::T"] = Xb.numpy(), Tb.numpy()
+                out[f"batch{b}::R"], out[f"batch{b}::y"] = Rb.numpy(), yb.numpy()
+            ds.augment = False
+            Xb, Tb, Rb, yb = tmo.collate_fn([ds[i] for i in range(len(files))])
+            out["plain::X"], out["plain::T"], out["plain::R"], out["plain::y"] = Xb.numpy(), Tb.numpy(), Rb.numpy(), yb.numpy()
+        finally:
+            tmo.ROI_H, tmo.ROI_W = old_hw
+    out["n_batches"] = 3
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
+    print("wrote dataset: lengths", [out[f"batch{b}::T"].tolist() for b in range(3)])
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -262,6 +307,7 @@ def main():
     gen_kat(tred)
     gen_features(rec, live)
     gen_crop(rec, live)
+    gen_dataset(tmo)
 
 
 if __name__ == "__main__":

@@ -635,3 +635,48 @@ def test_crop_idx_bit_exact(L, golden_dir):
         got = box.cpu().numpy()
         ref = np.array([FR.crop_box(cen[k], sc[k], 640, 480, "record" if variant == 0 else "live") for k in range(n)])
         assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------- batch assembly
+def test_device_clip_store_matches_reference_batches(L, tmp_path):
+    """Clips resident in HBM + two gather launches == the reference's NPZWordDataset(augment=True) + collate_fn,
+    bit for bit, when the host makes the reference's random draws (tests/golden/dataset.npz)."""
+    import random
+
+    from test_host_formats import _golden_clips
+    import silent_speech_amd as ss
+
+    golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d, files = _golden_clips(str(tmp_path), golden_dir)
+    store = ss.DeviceClipStore(files, {"no": 0, "yes": 1}, max_t=int(d["max_t"]))
+    for b in range(int(d["n_batches"])):
+        random.seed(1000 + b)
+        np.random.seed(2000 + b)
+        X, T, R, y = store.batch(d[f"batch{b}::order"].tolist(), augment=True, rng="reference")
+        sync()
+        assert np.array_equal(X.cpu().numpy(), d[f"batch{b}::X"]) and np.array_equal(T.cpu().numpy(), d[f"batch{b}::T"])
+        assert np.array_equal(R.cpu().numpy(), d[f"batch{b}::R"]) and np.array_equal(y.cpu().numpy(), d[f"batch{b}::y"])
+    X, T, R, y = store.batch(range(len(store)), augment=False)
+    sync()
+    assert np.array_equal(X.cpu().numpy(), d["plain::X"]) and np.array_equal(R.cpu().numpy(), d["plain::R"])
+    assert np.array_equal(T.cpu().numpy(), d["plain::T"]) and np.array_equal(y.cpu().numpy(), d["plain::y"])
+    # device-side randomness: same rules, different stream -- lengths within the drop range, ROI untouched, the noise
+    # has the reference's scale, padding stays exactly zero
+    gen = np.random.default_rng(3)
+    seen_noise, seen_drop = [], 0
+    for _ in range(30):
+        X, T, R, y = store.batch(range(len(store)), augment=True, rng="device", generator=gen)
+        sync()
+        Xc, Tc = X.cpu().numpy(), T.cpu().numpy()
+        plain_T = d["plain::T"]
+        assert np.all(Tc <= plain_T) and np.all(Tc >= plain_T - 2)  # at most two interior frames dropped
+        assert np.array_equal(R.cpu().numpy()[:, :1], d["plain::R"][:, :1])
+        for bb in range(len(store)):
+            assert not Xc[bb, Tc[bb]:].any()
+            if Tc[bb] == plain_T[bb] and len(d[f"clip{bb}::X"]) <= int(d["max_t"]):
+                diff = Xc[bb, :Tc[bb]] - d["plain::X"][bb, :Tc[bb]]
+                if np.abs(diff).max() > 0 and np.abs(diff).max() < 0.1:  # noised, nothing dropped
+                    seen_noise.append(diff.std())
+            seen_drop += int(Tc[bb] < plain_T[bb])
+    assert seen_noise and abs(np.mean(seen_noise) - 0.01) < 0.002, seen_noise[:5]
+    assert seen_drop > 0

@@ -66,3 +66,32 @@ def test_checkpoint_round_trip(tmp_path):
         assert torch.equal(a, b), k
     top = ss.topk_from_logits(torch.tensor([[0.1, 2.0, -1.0]]), id_to_label, k=3)
     assert [t[0] for t in top] == ["no", "aura", "yes"] and abs(sum(t[1] for t in top) - 1) < 1e-6
+
+
+def _golden_clips(tmp, golden_dir):
+    """Re-creates the clip files of tests/golden/dataset.npz (made by the reference's own dataset code)."""
+    d = np.load(os.path.join(golden_dir, "dataset.npz"), allow_pickle=True)
+    files = []
+    for k in range(int(d["n_clips"])):
+        X = d[f"clip{k}::X"]
+        roi = d[f"clip{k}::roi"] if f"clip{k}::roi" in d.files else None
+        save = dict(X=X, ts=np.arange(len(X)), label=str(d[f"clip{k}::label"]), speaker="me", idxs=np.arange(4))
+        if roi is not None:
+            save["roi"] = roi
+        p = os.path.join(tmp, f"c{k}.npz")
+        np.savez_compressed(p, **save)
+        files.append(p)
+    return d, files
+
+
+def test_dataset_and_collate_reproduce_the_reference_batches(tmp_path):
+    """Same seeds, same visiting order -> the batches the reference's NPZWordDataset(augment=True) + collate_fn built."""
+    golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d, files = _golden_clips(str(tmp_path), golden_dir)
+    ds = D.NPZWordDataset(files, {"no": 0, "yes": 1}, max_t=int(d["max_t"]), augment=True)
+    for b in range(int(d["n_batches"])):
+        random.seed(1000 + b)
+        np.random.seed(2000 + b)
+        Xb, Tb, Rb, yb = D.collate_fn([ds[i] for i in d[f"batch{b}::order"]], roi_hw=(16, 16))
+        assert np.array_equal(Xb.numpy(), d[f"batch{b}::X"]) and np.array_equal(Tb.numpy(), d[f"batch{b}::T"])
+        assert np.array_equal(Rb.numpy(), d[f"batch{b}::R"]) and np.array_equal(yb.numpy(), d[f"batch{b}::y"])
