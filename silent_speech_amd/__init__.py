@@ -6,7 +6,7 @@ Drop-in surface of the reference's per-clip path:
 All arithmetic runs in ``libss_hotpath.so`` (hand-written HIP, C ABI in ``include/ss_hotpath.h``);
 there is no CPU or PyTorch-op fallback.
 """
-from . import checkpoint, data, features
+from . import checkpoint, data, features, harness
 from .checkpoint import load_classifier, save_checkpoint, topk_from_logits
 from .device_data import DeviceClipStore
 from .engine import Config

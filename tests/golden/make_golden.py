@@ -298,6 +298,30 @@ def gen_dataset(tmo):
     print("wrote dataset: lengths", [out[f"batch{b}::T"].tolist() for b in range(3)])
 
 
+# ------------------------------------------------------------------ harness helpers
+def gen_harness(tmo):
+    import contextlib
+    import io
+
+    rng = np.random.default_rng(5)
+    labels = [str(x) for x in rng.choice(["aura", "no", "yes", "stop", "go"], size=61, p=[0.4, 0.25, 0.2, 0.1, 0.05])]
+    labels += ["solo"]  # a label with a single clip: max(1, ..) then min(.., n - 1) = 0 validation clips
+    files = [f"clips_npz/{k:03d}_{lab}.npz" for k, lab in enumerate(labels)]
+    out = {"files": np.asarray(files), "labels": np.asarray(labels)}
+    for seed, frac in ((42, 0.15), (7, 0.3)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr, va = tmo.split_by_label(list(files), list(labels), frac, seed=seed)
+        out[f"split{seed}::train"], out[f"split{seed}::val"], out[f"split{seed}::frac"] = np.asarray(tr), np.asarray(va), frac
+    y_true = rng.integers(0, 5, 200)
+    y_pred = np.where(rng.random(200) < 0.6, y_true, rng.integers(0, 5, 200))
+    id_to_label = {0: "aura", 1: "go", 2: "no", 3: "stop", 4: "yes"}
+    out["conf::y_true"], out["conf::y_pred"] = y_true, y_pred
+    for k in (3, 6, 8):
+        out[f"conf::top{k}"] = np.asarray(tmo.top_confusions(y_true.tolist(), y_pred.tolist(), id_to_label, k=k))
+    np.savez_compressed(os.path.join(HERE, "harness.npz"), **out)
+    print("wrote harness: val sizes", len(out["split42::val"]), len(out["split7::val"]), "top3", out["conf::top3"])
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -308,6 +332,7 @@ def main():
     gen_features(rec, live)
     gen_crop(rec, live)
     gen_dataset(tmo)
+    gen_harness(tmo)
 
 
 if __name__ == "__main__":

@@ -289,3 +289,42 @@ def test_real_weights_kat_gru(ss, golden_dir):
     torch.cuda.synchronize()
     err = float((out.view(B, T, 2 * H).cpu() - torch.from_numpy(d["gru_out"])).abs().max())
     assert err < 2e-5, err
+
+
+def test_harness_fit_evaluate_checkpoint(ss, tmp_path):
+    """scan -> split -> class-balanced epochs on the device-resident store -> evaluate -> save-best ->
+    reload with the reference's loader schema.  Three separable 'words' (a constant offset per class in a few features)."""
+    from silent_speech_amd import data as Dm
+    from silent_speech_amd import harness as Hn
+
+    rng = np.random.default_rng(0)
+    clip_dir = tmp_path / "clips_npz"
+    clip_dir.mkdir()
+    words = ["aura", "no", "yes"]
+    for k in range(45):
+        lab = words[k % 3]
+        T = int(rng.integers(14, 22))
+        X = (0.05 * rng.normal(size=(T, 20))).astype(np.float32)
+        X[:, (k % 3) * 4:(k % 3) * 4 + 4] += 0.5
+        roi = rng.integers(0, 256, (T, 32, 32), dtype=np.uint8)
+        Dm.save_clip(str(clip_dir / f"{k:03d}.npz"), X, np.arange(T), lab, "me", np.arange(4), roi)
+    out = str(tmp_path / "word_model_points_roi.pt")
+    logs = []
+    best = Hn.fit(str(clip_dir), out, epochs=6, batch_size=16, patience=3, max_t=24, lr=3e-3, log=logs.append)
+    assert best >= 0.8, (best, logs)
+    assert any("saved" in ln for ln in logs) and logs[0].startswith("ep 01 | train loss")
+    model, id_to_label, max_t, use_roi = ss.load_classifier(out)
+    assert max_t == 24 and use_roi and sorted(id_to_label.values()) == words
+    ck = torch.load(out, map_location="cpu", weights_only=False)
+    assert {"model", "x_dim", "max_t", "use_roi", "roi_w", "roi_h", "labels", "label_to_id", "id_to_label", "seed"} <= set(ck)
+    # evaluate() agrees with the CPU oracle's forward + CE on the validation clips
+    info = Hn.scan_clips(str(clip_dir))
+    _, val_files = Hn.split_by_label(info["files"], info["labels"], seed=42)
+    store = ss.DeviceClipStore(val_files, info["label_to_id"], max_t=24)
+    loss, acc, y_true, y_pred = Hn.evaluate(model, store, batch_size=4)
+    X, T, R, y = store.batch(range(len(store)))
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref = MR.forward(sd, X.cpu(), T.cpu(), R.cpu(), impl="aten")
+    ref_loss = float(MR.ce_label_smoothing(ref, y.cpu(), 0.05))
+    assert abs(loss - ref_loss) < 1e-4 and y_pred == ref.argmax(1).tolist() and y_true == y.cpu().tolist()
+    assert abs(acc - best) < 1e-9

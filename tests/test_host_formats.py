@@ -95,3 +95,22 @@ def test_dataset_and_collate_reproduce_the_reference_batches(tmp_path):
         Xb, Tb, Rb, yb = D.collate_fn([ds[i] for i in d[f"batch{b}::order"]], roi_hw=(16, 16))
         assert np.array_equal(Xb.numpy(), d[f"batch{b}::X"]) and np.array_equal(Tb.numpy(), d[f"batch{b}::T"])
         assert np.array_equal(Rb.numpy(), d[f"batch{b}::R"]) and np.array_equal(yb.numpy(), d[f"batch{b}::y"])
+
+
+def test_harness_helpers_match_the_reference():
+    """split_by_label / top_confusions against what the reference's own functions returned (tests/golden/harness.npz)."""
+    from silent_speech_amd import harness as Hn
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "harness.npz"), allow_pickle=True)
+    files, labels = g["files"].tolist(), g["labels"].tolist()
+    for seed in (42, 7):
+        tr, va = Hn.split_by_label(list(files), list(labels), float(g[f"split{seed}::frac"]), seed=seed)
+        assert tr == g[f"split{seed}::train"].tolist() and va == g[f"split{seed}::val"].tolist()
+        assert sorted(tr + va) == sorted(files) and not any(f.endswith("_solo.npz") for f in va)
+    id_to_label = {0: "aura", 1: "go", 2: "no", 3: "stop", 4: "yes"}
+    for k in (3, 6, 8):
+        assert Hn.top_confusions(g["conf::y_true"].tolist(), g["conf::y_pred"].tolist(), id_to_label, k=k) == g[f"conf::top{k}"].tolist()
+    # the sampler: inverse class frequency, with replacement -> rare classes are drawn about as often as common ones
+    idx = Hn.class_balanced_indices(labels, 20000, generator=torch.Generator().manual_seed(0))
+    drawn = np.bincount([sorted(set(labels)).index(labels[i]) for i in idx], minlength=6) / 20000.0
+    assert np.all(np.abs(drawn - 1.0 / 6.0) < 0.02), drawn
