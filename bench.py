@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
-    ap.add_argument("--mode", choices=["train", "infer", "assemble"], default="train",
+    ap.add_argument("--mode", choices=["train", "infer", "assemble", "stream"], default="train",
                     help="train = the headline metric; infer = BASELINE config 4 (T=60, B=4096 windows, forward-only, hipGraph)")
     ap.add_argument("--micro-batches", type=int, default=1, help="slices of the per-GPU batch kept in flight on separate streams")
     args = ap.parse_args()
@@ -171,6 +171,33 @@ def main():
                           "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True, "dtype": "f32",
                           "data": "synthetic", "config": {"workload": f"BASELINE config 4: {B} sliding windows x T={T}, "
                                                           f"landmark + {roi}x{roi} ROI CNN + BiGRU, forward-only, hipGraph replay"}}))
+        return
+    if args.mode == "stream":
+        # S camera streams, one new frame per stream and tick, a prediction per stream every 2nd tick on its
+        # zero-padded sliding window (inactive/live_feed.py:155-213) -- rings, window assembly and forward all on the device
+        S, Ts = (4096, 60) if (args.batch, args.frames) == (256, 30) else (args.batch, args.frames)
+        model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).eval()
+        srv = ss.StreamServer(model, S, Ts, roi_hw=(roi, roi), device=dev)
+        ids = list(range(S))
+        feats = torch.randn(S, D, device=dev)
+        rois = torch.randint(0, 256, (S, roi, roi), device=dev, dtype=torch.uint8)
+        op = torch.rand(S, device=dev) * 0.05
+        for _ in range(Ts + (Ts % 2)):  # fill the rings; ends on an even frame count
+            srv.push(ids, feats, rois, op)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_pred = 0
+        for _ in range(2 * args.steps):
+            got = srv.push(ids, feats, rois, op)
+            n_pred += 0 if got is None else len(got[0])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        print(json.dumps({"metric": "windows/sec (sliding %d-frame windows of %d streams, push + assemble + forward)" % (Ts, S),
+                          "value": round(n_pred / el, 1), "unit": "windows/s", "n_gpus": 1, "steps": args.steps, "warmup": 0,
+                          "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True, "dtype": "f32",
+                          "data": "synthetic", "frames_ingested_per_sec": round(2 * args.steps * S / el, 1),
+                          "config": {"workload": "SURVEY 8f-4: %d streams x T=%d, one frame per stream and tick, prediction every "
+                                                 "2nd tick, landmark + %dx%d ROI CNN + BiGRU forward" % (S, Ts, roi, roi)}}))
         return
     if args.mode == "assemble":
         # a training batch gathered out of a clip store that lives in HBM (noise, frame drop, pad / trim)

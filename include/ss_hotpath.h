@@ -143,6 +143,20 @@ int ss_batch_gather_f32(const float* src, int D, const int32_t* frame_map, long 
 int ss_batch_gather_u8(const uint8_t* src, int frame_bytes, const int32_t* frame_map, long rows, uint8_t* dst,
                        ss_stream_t stream);
 
+/* ---- sliding-window serving of many streams ---------------------------------------
+ * per stream a ring of the last max_t frames (features (S,max_t,D) f32, optional ROI (S,max_t,frame_bytes) u8), a head
+ * and a count: the deque(maxlen=max_t) of inactive/live_feed.py:155.  A push appends one frame for each of n DISTINCT
+ * streams (feats (n,D), rois (n,frame_bytes)) and bumps frames_seen; the window map lists, oldest first, the rows of the
+ * rings of n selected streams (-1 = zero padding; live_feed.py:203-207) for ss_batch_gather_f32/u8, lengths = frames held.
+ * ss_mouth_gate: EMA (alpha) of the mouth openness and its open/close hysteresis (important_landmarks.py:136-144). */
+int ss_ring_push(float* ring_x, uint8_t* ring_r, int n_streams, int max_t, int D, int frame_bytes,
+                 const int32_t* stream_ids, int n, const float* feats, const uint8_t* rois, int32_t* head, int32_t* count,
+                 int32_t* frames_seen, ss_stream_t stream);
+int ss_ring_window_map(const int32_t* stream_ids, int n, int max_t, const int32_t* head, const int32_t* count,
+                       int32_t* frame_map, int64_t* lengths, ss_stream_t stream);
+int ss_mouth_gate(const int32_t* stream_ids, int n, const float* openness, float alpha, float open_thr, float close_thr,
+                  float* ema, uint8_t* state_open, ss_stream_t stream);
+
 /* ---- a7: one bidirectional GRU layer, recurrence only ---------------------------------------
  * replaces pack_padded_sequence -> nn.GRU -> pad_packed_sequence (train_model_official.py:301-305).
  * gi      (2, B*T, 3H): W_ih x + b_ih per direction (forward, reverse), from ss_gemm_f32

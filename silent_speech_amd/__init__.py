@@ -12,6 +12,7 @@ from .device_data import DeviceClipStore
 from .engine import Config
 from .features import crop_boxes, extract_features
 from .infer import GraphedInference
+from .serving import StreamServer
 from .model import AttnPool, BiGRUClassifier, TinyROICNN
 from .train import Trainer, allreduce_flat_grads, shard_range
 

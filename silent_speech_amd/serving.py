@@ -1,0 +1,90 @@
+"""Sliding-window serving of many streams on one GPU (BASELINE config 4's "4 096 concurrent streams").
+
+Per stream the reference keeps ``deque(maxlen=max_t)`` of frame features and, every ``PRED_EVERY`` frames once
+``WARMUP_MIN`` frames are in, zero-pads it to ``(max_t, D)`` and runs the model
+(/root/reference/inactive/live_feed.py:155, :163-164, :201-213); important_landmarks.py:136-144 smooths the mouth openness
+and applies an open/close hysteresis.  ``StreamServer`` holds the rings of S streams in HBM (``ss_ring_push``), builds the
+windows of the streams that are due with one map kernel and the batch-assembly gathers, and runs ONE forward for all of
+them -- the model sees ``lengths`` = frames held, so the padding never reaches the recurrence.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .model import BiGRUClassifier
+
+PRED_EVERY, EMA_ALPHA, OPEN_THR, CLOSE_THR = 2, 0.25, 0.02, 0.02
+
+
+class StreamServer:
+    def __init__(self, model: BiGRUClassifier, n_streams: int, max_t: int, roi_hw=None, pred_every: int = PRED_EVERY,
+                 warmup_min: Optional[int] = None, device="cuda"):
+        L.load()
+        self.model, self.S, self.max_t, self.roi_hw = model.eval(), n_streams, max_t, roi_hw
+        self.D = model.cfg.x_dim
+        self.pred_every = pred_every
+        self.warmup_min = min(10, max_t) if warmup_min is None else warmup_min
+        dev = self.device = torch.device(device)
+        self.ring_x = torch.zeros(n_streams, max_t, self.D, device=dev)
+        self.ring_r = torch.zeros(n_streams, max_t, roi_hw[0], roi_hw[1], device=dev, dtype=torch.uint8) if roi_hw else None
+        self.head = torch.zeros(n_streams, device=dev, dtype=torch.int32)
+        self.count = torch.zeros(n_streams, device=dev, dtype=torch.int32)
+        self.frames_seen = torch.zeros(n_streams, device=dev, dtype=torch.int32)
+        self.ema = torch.zeros(n_streams, device=dev)
+        self.mouth_open = torch.zeros(n_streams, device=dev, dtype=torch.uint8)
+        # host mirrors of the two counters decide who is due without reading the device back
+        self._count = np.zeros(n_streams, np.int64)
+        self._seen = np.zeros(n_streams, np.int64)
+
+    def push(self, stream_ids: Sequence[int], feats: torch.Tensor, rois: Optional[torch.Tensor] = None,
+             openness: Optional[torch.Tensor] = None):
+        """One new frame for each of the (distinct) streams in ``stream_ids``.  Returns None, or
+        ``(ids, logits, lengths)`` for the streams that are due for a prediction this tick."""
+        ids = np.asarray(stream_ids, np.int32)
+        n = len(ids)
+        if len(set(ids.tolist())) != n:
+            raise ValueError("one frame per stream and tick")
+        dev = self.device
+        ids_d = torch.from_numpy(ids).to(dev)
+        feats = feats.to(dev, torch.float32).contiguous()
+        rois = rois.to(dev).contiguous() if rois is not None else None
+        fb = self.roi_hw[0] * self.roi_hw[1] if self.roi_hw else 0
+        L.call("ss_ring_push", self.ring_x.data_ptr(), L.ptr(self.ring_r), self.S, self.max_t, self.D, fb, ids_d.data_ptr(), n,
+               feats.data_ptr(), L.ptr(rois) if self.ring_r is not None else None, self.head.data_ptr(), self.count.data_ptr(),
+               self.frames_seen.data_ptr(), L.stream())
+        if openness is not None:
+            op = openness.to(dev, torch.float32).contiguous()
+            L.call("ss_mouth_gate", ids_d.data_ptr(), n, op.data_ptr(), EMA_ALPHA, OPEN_THR, CLOSE_THR, self.ema.data_ptr(),
+                   self.mouth_open.data_ptr(), L.stream())
+        self._count[ids] = np.minimum(self._count[ids] + 1, self.max_t)
+        self._seen[ids] += 1
+        due = ids[(self._count[ids] >= self.warmup_min) & (self._seen[ids] % self.pred_every == 0)]
+        if len(due) == 0:
+            return None
+        X, T, R = self.windows(due)
+        with torch.no_grad():
+            logits = self.model(X, T, R if self.model.use_roi else None)
+        return due, logits, T
+
+    def windows(self, ids: np.ndarray):
+        """Zero-padded windows (oldest frame first) of the given streams: X (n,max_t,D), lengths (n,), R or None."""
+        dev, n, mt = self.device, len(ids), self.max_t
+        ids_d = torch.from_numpy(np.asarray(ids, np.int32)).to(dev)
+        fmap = torch.empty(n, mt, device=dev, dtype=torch.int32)
+        T = torch.empty(n, device=dev, dtype=torch.int64)
+        L.call("ss_ring_window_map", ids_d.data_ptr(), n, mt, self.head.data_ptr(), self.count.data_ptr(), fmap.data_ptr(),
+               T.data_ptr(), L.stream())
+        X = torch.empty(n, mt, self.D, device=dev)
+        L.call("ss_batch_gather_f32", self.ring_x.data_ptr(), self.D, fmap.data_ptr(), n * mt, None, None, 0.0, 0, X.data_ptr(),
+               L.stream())
+        R = None
+        if self.ring_r is not None:
+            H, W = self.roi_hw
+            R = torch.empty(n, mt, H, W, device=dev, dtype=torch.uint8)
+            L.call("ss_batch_gather_u8", self.ring_r.data_ptr(), H * W, fmap.data_ptr(), n * mt, R.data_ptr(), L.stream())
+        X._ss_keep = (ids_d, fmap)
+        return X, T, R

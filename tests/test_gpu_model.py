@@ -328,3 +328,44 @@ def test_harness_fit_evaluate_checkpoint(ss, tmp_path):
     ref_loss = float(MR.ce_label_smoothing(ref, y.cpu(), 0.05))
     assert abs(loss - ref_loss) < 1e-4 and y_pred == ref.argmax(1).tolist() and y_true == y.cpu().tolist()
     assert abs(acc - best) < 1e-9
+
+
+def test_stream_server_matches_the_restated_loop(ss):
+    """rings of 7 streams fed with random subsets for 45 ticks == one Python deque per stream
+    (oracle/stream_ref.py): who is due, the zero-padded windows (bit-exact), the gate, and the logits of the windows."""
+    from oracle import stream_ref as SR
+
+    rng = np.random.default_rng(4)
+    S, max_t, Dm, hw = 7, 16, 84, (32, 32)
+    sd = W.make_state_dict(3, Dm, 5, True)
+    m = ss.BiGRUClassifier(Dm, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    srv = ss.StreamServer(m, S, max_t, roi_hw=hw)
+    refs = [SR.StreamRef(max_t, Dm, hw) for _ in range(S)]
+    n_pred = 0
+    for tick in range(45):
+        ids = np.flatnonzero(rng.random(S) < 0.8)
+        if len(ids) == 0:
+            continue
+        feats = rng.normal(size=(len(ids), Dm)).astype(np.float32)
+        rois = rng.integers(0, 256, (len(ids),) + hw, dtype=np.uint8)
+        op = (0.02 + 0.02 * rng.normal(size=len(ids))).astype(np.float32)
+        got = srv.push(ids, torch.from_numpy(feats), torch.from_numpy(rois), torch.from_numpy(op))
+        want = {int(s): refs[s].push(feats[k], rois[k], float(op[k])) for k, s in enumerate(ids)}
+        due = [s for s, w in want.items() if w is not None]
+        if not due:
+            assert got is None
+            continue
+        g_ids, logits, T = got
+        assert g_ids.tolist() == due
+        X, T2, R = srv.windows(np.asarray(due))
+        for k, s in enumerate(due):
+            assert np.array_equal(X[k].cpu().numpy(), want[s]["X"]) and int(T[k]) == want[s]["T"] == int(T2[k])
+            assert np.array_equal(R[k].cpu().numpy(), want[s]["R"])
+        ref = MR.forward(sd, X.cpu(), T.cpu(), R.cpu(), impl="aten")
+        assert float((logits.cpu() - ref).abs().max()) < TIGHT
+        n_pred += len(due)
+        assert np.array_equal(srv.ema.cpu().numpy(), np.asarray([r.ema for r in refs], np.float32))
+        assert srv.mouth_open.cpu().numpy().astype(bool).tolist() == [r.open for r in refs]
+    assert n_pred > 40
