@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
-    ap.add_argument("--mode", choices=["train", "infer", "assemble", "stream"], default="train",
+    ap.add_argument("--mode", choices=["train", "infer", "assemble", "stream", "crop"], default="train",
                     help="train = the headline metric; infer = BASELINE config 4 (T=60, B=4096 windows, forward-only, hipGraph)")
     ap.add_argument("--micro-batches", type=int, default=1, help="slices of the per-GPU batch kept in flight on separate streams")
     args = ap.parse_args()
@@ -171,6 +171,43 @@ def main():
                           "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True, "dtype": "f32",
                           "data": "synthetic", "config": {"workload": f"BASELINE config 4: {B} sliding windows x T={T}, "
                                                           f"landmark + {roi}x{roi} ROI CNN + BiGRU, forward-only, hipGraph replay"}}))
+        return
+    if args.mode == "crop":
+        # landmarks -> feature fuse -> crop box -> BGR2GRAY + resize, 640x480 camera frames resident in HBM
+        from silent_speech_amd import features as Fm
+
+        Nf, hh, ww = 512, 480, 640
+        frames = torch.randint(0, 256, (Nf, hh, ww, 3), device=dev, dtype=torch.uint8)
+        lmf = lm.reshape(-1, K, 2)[:Nf].reshape(1, Nf, K, 2).contiguous()
+        Xf = torch.empty(1, Nf, D, device=dev)
+        center = torch.empty(1, Nf, 2, device=dev)
+        fourth = torch.empty(1, Nf, device=dev, dtype=torch.float64)
+        L.call("ss_feature_fuse", lmf.data_ptr(), None, 1, Nf, K, ww, hh, 8, 25, 1, 2, 0, Xf.data_ptr(), D, center.data_ptr(),
+               fourth.data_ptr(), L.stream())
+        boxes = Fm.crop_boxes(center, fourth, ww, hh, "record")
+        out = {}
+        for variant in ("record", "live"):
+            for _ in range(args.warmup):
+                Fm.crop_rois(frames, boxes, (48, 96), variant)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                Fm.crop_rois(frames, boxes, (48, 96), variant)
+            e1.record()
+            torch.cuda.synchronize()
+            out[variant] = e0.elapsed_time(e1) / args.steps
+        bx = boxes.reshape(-1, 5).cpu()
+        crop_bytes = int(((bx[:, 1] - bx[:, 0]) * (bx[:, 3] - bx[:, 2]) * bx[:, 4]).sum()) * 3 + Nf * 48 * 96
+        ms = out["live"]  # INTER_AREA reads every byte of the crop; INTER_LINEAR only four taps per output pixel
+        print(json.dumps({"metric": "frames/sec cropped, greyed and resized to 48x96 (640x480 BGR frames in HBM, INTER_AREA)",
+                          "value": round(Nf / ms * 1e3, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(ms, 4), "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+                          "config": {"workload": "SURVEY 8f-2: crop box -> BGR2GRAY -> resize INTER_AREA (live); INTER_LINEAR "
+                                                 "(recorder) %.4f ms per %d frames" % (out["record"], Nf)},
+                          "roofline": {"kernel": "ss_crop_gray_resize", "bound": "hbm", "achieved": round(crop_bytes / ms / 1e6, 1),
+                                       "peak": 8000.0, "unit": "GB/s", "frac": round(crop_bytes / ms / 1e6 / 8000.0, 4), "traffic": None,
+                                       "algorithmic_bytes_per_launch": crop_bytes, "avg_launch_ms": round(ms, 4)}}))
         return
     if args.mode == "stream":
         # S camera streams, one new frame per stream and tick, a prediction per stream every 2nd tick on its

@@ -59,6 +59,14 @@ int ss_feature_fuse(const float* lm, const uint8_t* reset, int B, int T, int K, 
 int ss_roi_crop_idx(const float* center, const double* scale, int n, int w, int h, int variant, int32_t* box,
                     ss_stream_t stream);
 
+/* ---- a2: crop -> BGR2GRAY -> resize behind the crop box --------------------------
+ * replaces cv2.cvtColor + cv2.resize in crop_roi (record_landmarks_official.py:116-118, INTER_LINEAR: interp 0) and
+ * crop_roi_gray (live_infer_official.py:184-186, INTER_AREA: interp 1).  frames_bgr (N,h,w,3) u8, box (N,5) from
+ * ss_roi_crop_idx, out (N,roi_h,roi_w) u8 (zeros where the box is invalid).  OpenCV's 8-bit algorithms restated;
+ * parity with OpenCV itself is unpinned: +-1 grey level is the contract. */
+int ss_crop_gray_resize(const uint8_t* frames_bgr, int N, int h, int w, const int32_t* box, int roi_h, int roi_w,
+                        int interp, uint8_t* out, ss_stream_t stream);
+
 /* ---- a4+a5(+a6): ROI normalise + TinyROICNN, fused ------------------------------------------
  * replaces train_model_official.py:286-291 and TinyROICNN.forward (:212-229); with
  * standardize = 0 the live variant (live_infer_official.py:126-127).

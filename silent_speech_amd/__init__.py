@@ -10,7 +10,7 @@ from . import checkpoint, data, features, harness
 from .checkpoint import load_classifier, save_checkpoint, topk_from_logits
 from .device_data import DeviceClipStore
 from .engine import Config
-from .features import crop_boxes, extract_features
+from .features import crop_boxes, crop_rois, extract_features
 from .infer import GraphedInference
 from .serving import StreamServer
 from .model import AttnPool, BiGRUClassifier, TinyROICNN

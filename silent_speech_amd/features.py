@@ -69,6 +69,20 @@ def crop_boxes(center: torch.Tensor, scale: torch.Tensor, w: int, h: int, varian
     return box.view(*center.shape[:-1], 5)
 
 
+def crop_rois(frames_bgr: torch.Tensor, boxes: torch.Tensor, roi_hw=(48, 96), variant: str = "record") -> torch.Tensor:
+    """(N,h,w,3) uint8 BGR frames + (N,5) crop boxes -> (N,ROI_H,ROI_W) uint8 mouth ROIs: BGR2GRAY + resize, INTER_LINEAR
+    for the recorder (record_landmarks_official.py:116-118), INTER_AREA for the live script (live_infer_official.py:184-186).
+    Frames with an invalid box come back as zeros (the reference skips them)."""
+    if not frames_bgr.is_cuda:
+        raise RuntimeError("crop_rois runs on the HIP device only")
+    f = frames_bgr.contiguous()
+    N, h, w, _ = f.shape
+    out = torch.empty(N, roi_hw[0], roi_hw[1], device=f.device, dtype=torch.uint8)
+    L.call("ss_crop_gray_resize", f.data_ptr(), N, h, w, boxes.reshape(-1, 5).contiguous().data_ptr(), roi_hw[0], roi_hw[1],
+           0 if variant == "record" else 1, out.data_ptr(), L.stream())
+    return out
+
+
 def in_distance_band(X: torch.Tensor, K: int) -> torch.Tensor:
     """The recorder's keep-frame gate 60 <= mouth_w <= 150 px (record_landmarks_official.py:185) from X's width column."""
     mw = X[..., 2 * K + 2]

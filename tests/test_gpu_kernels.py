@@ -680,3 +680,32 @@ def test_device_clip_store_matches_reference_batches(L, tmp_path):
             seen_drop += int(Tc[bb] < plain_T[bb])
     assert seen_noise and abs(np.mean(seen_noise) - 0.01) < 0.002, seen_noise[:5]
     assert seen_drop > 0
+
+
+# ------------------------------------------------------------------------------------- crop + gray + resize
+@pytest.mark.parametrize("variant", ["record", "live"])
+def test_crop_gray_resize_equals_restatement(L, variant):
+    """ss_crop_gray_resize == oracle/resize_ref.py bit for bit (the restatement of OpenCV's algorithms; parity with
+    OpenCV itself is unpinned): reduced, enlarged, integer-scale and invalid boxes, both interpolations."""
+    from oracle import resize_ref as RR
+    import silent_speech_amd as ss
+
+    rng = np.random.default_rng(7)
+    h, w, RH, RW = 240, 320, 48, 96
+    boxes = np.asarray([[40, 286, 30, 235, 1],     # 246 x 205 -> reduced, fractional scales
+                        [100, 160, 90, 115, 1],    # 60 x 25   -> enlarged
+                        [10, 202, 20, 116, 1],     # 192 x 96  -> integer 2 x 2
+                        [0, 288, 0, 192, 1],       # 288 x 192 -> integer 3 x 4
+                        [50, 50, 60, 90, 0],       # invalid
+                        [300, 320, 200, 240, 1]],  # at the frame's corner, mixed: x enlarged, y reduced
+                       np.int32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames = np.stack([np.clip(np.stack([127 + 90 * np.sin(xx / (9.0 + k) + c) * np.cos(yy / 13.0) for c in range(3)], -1)
+                               + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8) for k in range(len(boxes))])
+    out = ss.crop_rois(dev(torch.from_numpy(frames)), dev(torch.from_numpy(boxes)), (RH, RW), variant)
+    sync()
+    interp = "linear" if variant == "record" else "area"
+    for k, b in enumerate(boxes):
+        want = RR.crop_gray_resize(frames[k], b, RH, RW, interp)
+        got = out[k].cpu().numpy()
+        assert np.array_equal(got, want), f"box {k}: {np.abs(got.astype(int) - want).max()} grey levels off, {(got != want).sum()} pixels"
