@@ -50,8 +50,8 @@ struct CnnFwdParams {
   uint8_t* st_i1;   // [N][8][I1S] (plane stride I1S = H2*W2 + 4 bytes)
   float* st_a2;     // [N][16][P2] haloed LDS image of the pooled-2 map, as is
   uint8_t* st_i2;   // [N][H4][W4][16]  pixel-major: the backward pass consumes it next to its pixel-major da2
-  uint8_t* st_m3;   // [N][24][P]
-  float* st_feat;   // [N][24]
+  uint8_t* st_m3;   // [N][P][32]  pixel-major, channels 24..31 unused: the backward turns 16 bytes into 16 floats of one pixel
+  float* st_feat;   // [N][48]  24 averaged conv3 features, then 24 counts of positive conv3 outputs (for d b3)
 };
 
 template <class G>
@@ -64,6 +64,9 @@ struct FwdLds {
   static constexpr int o_i2 = 16 * G::P2;                       // bytes [P][16]
   static constexpr int u_end1 = o_i1 + 2 * G::I1S, u_end2 = o_i2 + 4 * G::P;
   static constexpr int o_a1 = ((u_end1 > u_end2 ? u_end1 : u_end2) + 3) & ~3;  // [8][P1]
+  static constexpr int o_m3 = o_a1;                      // bytes [P][32] conv3 sign mask, staged for the stash over the
+                                                         // pooled-1 map (dead once conv2 is through)
+  static_assert(8 * G::P <= 8 * G::P1, "mask staging fits the pooled-1 planes");
   static constexpr int o_misc = o_a1 + 8 * G::P1 + 256;  // the 256 floats in front hold the grey-level table
   static constexpr int total = o_misc + 512;
 };
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
   float* a2 = lds + LL::o_a2;
   uint8_t* i1s = reinterpret_cast<uint8_t*>(lds + LL::o_i1);
   uint8_t* i2s = reinterpret_cast<uint8_t*>(lds + LL::o_i2);
+  uint8_t* m3s = reinterpret_cast<uint8_t*>(lds + LL::o_m3);
   float* misc = lds + LL::o_misc;
   float* s_b1 = misc;                       // [8]
   float* s_b2 = misc + 16;                  // [16]
@@ -87,7 +91,8 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
   float* s_feat = misc + 64;                // [24]
   float* s_stat = misc + 96;                // mu, std
   unsigned* s_red = reinterpret_cast<unsigned*>(misc + 104);  // [NWV][2]
-  float* s_fp = misc + 128;                 // [NWV][32] per-wave partial channel sums (256 floats)
+  float* s_fp = misc + 128;                 // [NWV][32] per-wave partial channel sums
+  float* s_cp = misc + 128 + NWV * 32;      // [NWV][32] per-wave counts of positive outputs
   float* s_xn = misc - 256;                 // [256] normalised value of every uint8 level (own 256-float block)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -343,6 +348,7 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
     {
       constexpr int tiles = P / 16;
       float fa = 0.f, fb = 0.f;  // per-lane partial channel sums (tile 0: n=i, tile 1: n=16+i)
+      float ca = 0.f, cb = 0.f;  // and counts of positive outputs
       const float bias_a = s_b3[i], bias_b = (i < 8) ? s_b3[16 + i] : 0.f;
       for (int u = wv; u < tiles; u += NWV) {
         const int pa = 16 * u + i;
@@ -364,32 +370,47 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
           }
           SS_SCHED_FENCE();
         }
-        unsigned ma = 0, mb = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float va = acca[r] + bias_a, vb = accb[r] + bias_b;
-          if (va > 0.f) { fa += va; ma |= 1u << (8 * r); }
-          if (vb > 0.f) { fb += vb; mb |= 1u << (8 * r); }
-        }
-        if (stash) {
-          uint8_t* mp = p.st_m3 + (long)n * 24 * P + 16 * u + 4 * g;
-          *reinterpret_cast<unsigned*>(mp + (long)i * P) = ma;
-          if (i < 8) *reinterpret_cast<unsigned*>(mp + (long)(16 + i) * P) = mb;
+          if (va > 0.f) { fa += va; ca += 1.f; }
+          if (vb > 0.f) { fb += vb; cb += 1.f; }
+          if (stash) {  // D row 4g+r = pixel, column i = channel: pixel-major bytes
+            uint8_t* mp = m3s + (16 * u + 4 * g + r) * 32;
+            mp[i] = va > 0.f;
+            if (i < 8) {
+              mp[16 + i] = vb > 0.f;
+              mp[24 + i] = 0;
+            }
+          }
         }
       }
       // reduce over the 4 lane groups (rows of the tiles), then over waves through LDS
       fa += __shfl_xor(fa, 16, 64); fa += __shfl_xor(fa, 32, 64);
       fb += __shfl_xor(fb, 16, 64); fb += __shfl_xor(fb, 32, 64);
-      if (g == 0) { s_fp[wv * 32 + i] = fa; s_fp[wv * 32 + 16 + i] = fb; }
+      ca += __shfl_xor(ca, 16, 64); ca += __shfl_xor(ca, 32, 64);
+      cb += __shfl_xor(cb, 16, 64); cb += __shfl_xor(cb, 32, 64);
+      if (g == 0) {
+        s_fp[wv * 32 + i] = fa; s_fp[wv * 32 + 16 + i] = fb;
+        s_cp[wv * 32 + i] = ca; s_cp[wv * 32 + 16 + i] = cb;
+      }
     }
     __syncthreads();
     STAMP(4);
+    if (stash)
+      for (int q = tid; q < 2 * P; q += NT)
+        reinterpret_cast<uint4*>(p.st_m3 + (long)n * 32 * P)[q] = reinterpret_cast<const uint4*>(m3s)[q];
     if (tid < 24) {
       float s = 0.f;
       for (int k = 0; k < NWV; ++k) s += s_fp[k * 32 + tid];
       s /= (float)P;
       s_feat[tid] = s;
-      if (stash) p.st_feat[(long)n * 24 + tid] = s;
+      if (stash) {
+        float cnt = 0.f;
+        for (int k = 0; k < NWV; ++k) cnt += s_cp[k * 32 + tid];
+        p.st_feat[(long)n * 48 + tid] = s;
+        p.st_feat[(long)n * 48 + 24 + tid] = cnt;
+      }
     }
     __syncthreads();
     // ---------------- stage 4: fc

@@ -34,7 +34,7 @@ constexpr int NWV = NT / 64;
 template <class G>
 struct BwdLds {
   static constexpr int o_a1h = 0;                         // [8][P1]   haloed pooled-1 map; S4 overwrites it with da1
-  // phase area.  phase 1: a2h | dy3h | da2m | i2 (| w3) ;  phase 2: dy2 | xh (normalised frame, haloed) | i1
+  // phase area.  phase 1: a2h | dy3 (pixel-major [haloed pixel][24 ch]) | da2m | i2 (| w3) ;  phase 2: dy2 | xh | i1
   static constexpr int o_ph = 8 * G::P1;
   static constexpr int o_dy3h = o_ph + 16 * G::P2;
   static constexpr int o_da2m = o_dy3h + 24 * G::P2;
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float* s_stat = misc + 128;    // mu, sd
   unsigned* s_red = reinterpret_cast<unsigned*>(misc + 136);  // [2*NWV]
   float* s_gb3 = misc + 160;     // [32]  accumulated over the frame walk
+  float* s_cnt = misc + 448;     // [24] positive conv3 outputs per channel of this frame (from the forward's stash)
   float* s_xn = misc + 192;      // [256] normalised value of every uint8 level for this frame
   float* s_wfc = da2m;           // [E*24] staged per frame; da2m itself is first written in S2
 
@@ -135,8 +136,28 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
 
   for (int q = tid; q < LL::total; q += NT) lds[q] = 0.f;
   __syncthreads();
-  if (LL::W3_RESIDENT)
-    for (int q = tid; q < 3456; q += NT) w3s[q] = p.w3[q];
+  // S2's B operand, one ds_read_b128 + one ds_read_b64 per tap: the 24 output channels n of conv3 are the K index
+  // (slot (e, g) of the first four k-steps carries n = 4g + e, of the last two n = 16 + 2g + e), column = input channel c:
+  //   [0, 2304)    ((tap*4 + g)*16 + c)*4 + e  = W3[4g+e][c][tap]
+  //   [2304, 3456) ((tap*4 + g)*16 + c)*2 + e  = W3[16+2g+e][c][tap]
+  auto stage_w3 = [&]() {
+    for (int q = tid; q < 3456; q += NT) {
+      int nn, c, tap;
+      if (q < 2304) {
+        const int e = q & 3, r = q >> 2;
+        c = r & 15;
+        nn = 4 * ((r >> 4) & 3) + e;
+        tap = r >> 6;
+      } else {
+        const int q2 = q - 2304, e = q2 & 1, r = q2 >> 1;
+        c = r & 15;
+        nn = 16 + 2 * ((r >> 4) & 3) + e;
+        tap = r >> 6;
+      }
+      w3s[q] = p.w3[nn * 144 + c * 9 + tap];
+    }
+  };
+  if (LL::W3_RESIDENT) stage_w3();
   // S4's B operand: k = (t*3+kx)*16 + n, column j = (c, s): W2[n][c][ky = s+2-t][kx], zero outside the 3x3 window.
   // Stored [tap tk][g][column j][e] with n = 4g + e: lane (j, g) takes its four k-steps of a tap in ONE ds_read_b128
   // (MFMA slot (e, g) carries n = 4g + e for both operands).
@@ -179,18 +200,18 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   // dead) dy3 planes, the d_out row and the averaged features into their misc slots.  No registers are involved, so
   // nothing the compiler does with its own loads can wait on these (a register prefetch cost 2.8 us of serialised HBM
   // round trips per frame: spilled pointers and split destination registers each forced an s_waitcnt vmcnt(0)).
-  constexpr int STG_PX = LL::o_dy3h, STG_M3 = STG_PX + HW / 4, STG_I2 = STG_M3 + 6 * P;   // float offsets
-  static_assert(HW / 4 + 10 * P <= 24 * P2 && HW % 16 == 0 && P % 16 == 0, "staging");
+  constexpr int STG_PX = LL::o_dy3h, STG_M3 = STG_PX + HW / 4, STG_I2 = STG_M3 + 8 * P;   // float offsets
+  static_assert(HW / 4 + 12 * P <= 24 * P2 && HW % 16 == 0 && P % 16 == 0, "staging");
   uint4 px[NCH];
   float wfc_r[3];  // fc weight: the same for every frame
 #pragma unroll
   for (int k = 0; k < 3; ++k) wfc_r[k] = (tid + k * NT < E * 24) ? p.wfc[tid + k * NT] : 0.f;
   auto prefetch_frame = [&](int nf) {
     constexpr int A2_PIECES = (16 * P2 * 4 + 1023) / 1024, PX_PIECES = (HW + 1023) / 1024,
-                  M3_PIECES = (24 * P + 1023) / 1024, I2_PIECES = (16 * P + 1023) / 1024;
+                  M3_PIECES = (32 * P + 1023) / 1024, I2_PIECES = (16 * P + 1023) / 1024;
     const char* a2src = reinterpret_cast<const char*>(p.st_a2 + (long)nf * 16 * P2);
     const char* pxsrc = reinterpret_cast<const char*>(p.R + (long)nf * HW);
-    const char* m3src = reinterpret_cast<const char*>(p.st_m3 + (long)nf * 24 * P);
+    const char* m3src = reinterpret_cast<const char*>(p.st_m3 + (long)nf * 32 * P);
     const char* i2src = reinterpret_cast<const char*>(p.st_i2 + (long)nf * 16 * P);
     for (int piece = wvu; piece < A2_PIECES + PX_PIECES + M3_PIECES + I2_PIECES; piece += NWV) {
       int q = piece;
@@ -208,7 +229,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       q -= PX_PIECES;
       if (q < M3_PIECES) {
         const int off = q * 1024 + lane * 16;
-        if (off < 24 * P) ss_dma16(m3src + off, (unsigned)(STG_M3 * 4 + q * 1024));
+        if (off < 32 * P) ss_dma16(m3src + off, (unsigned)(STG_M3 * 4 + q * 1024));
         continue;
       }
       q -= M3_PIECES;
@@ -217,7 +238,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     }
     if (wvu == NWV - 1) {
       if (lane < E) ss_dma4(p.d_out + (long)nf * p.ld_dout + lane, (unsigned)((LL::o_misc) * 4));
-      if (lane < 24) ss_dma4(p.st_feat + (long)nf * 24 + lane, (unsigned)((LL::o_misc + 64) * 4));
+      if (lane < 24) ss_dma4(p.st_feat + (long)nf * 48 + lane, (unsigned)((LL::o_misc + 64) * 4));
+      if (lane < 24) ss_dma4(p.st_feat + (long)nf * 48 + 24 + lane, (unsigned)((LL::o_misc + 448) * 4));
     }
   };
   if ((int)blockIdx.x < p.N) prefetch_frame(blockIdx.x);
@@ -227,18 +249,19 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // ---------------- L0: the prefetched inputs have landed; pixel statistics
     ss_dma_wait();    // this wave's pieces (issued a frame ago)
     __syncthreads();  // A0: everybody's
-    uint4 m3w = {0, 0, 0, 0};
+    constexpr int NM3 = (2 * P + NT - 1) / NT;  // 16-byte mask items (pixel, channel half) per thread
+    uint4 m3w[NM3];
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
       if ((tid + k * NT) * 16 < HW) px[k] = reinterpret_cast<const uint4*>(lds + STG_PX)[tid + k * NT];
-    if (tid * 16 < 24 * P) m3w = reinterpret_cast<const uint4*>(lds + STG_M3)[tid];
+#pragma unroll
+    for (int k = 0; k < NM3; ++k)
+      m3w[k] = (tid + k * NT < 2 * P) ? reinterpret_cast<const uint4*>(lds + STG_M3)[tid + k * NT] : uint4{0, 0, 0, 0};
     if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = reinterpret_cast<const uint4*>(lds + STG_I2)[tid];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (tid + k * NT < E * 24) s_wfc[tid + k * NT] = wfc_r[k];
-    if (!LL::W3_RESIDENT)
-      for (int q = tid; q < 3456 / 4; q += NT)
-        reinterpret_cast<f32x4*>(w3s)[q] = reinterpret_cast<const f32x4*>(p.w3)[q];
+    if (!LL::W3_RESIDENT) stage_w3();
     {
       unsigned su = 0, sq = 0;
 #pragma unroll
@@ -308,31 +331,33 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     __syncthreads();  // B
     STAMP(1);
 
-    // dy3 = mask3 * dfeat / P into its haloed planes (the halo was re-zeroed at the end of the last frame); db3
-    if (tid * 16 < 24 * P) {
-      const int lin = tid * 16;
-      const int c = lin / P;
-      const float dv = s_dfeat[c];
-      const unsigned wds[4] = {m3w.x, m3w.y, m3w.z, m3w.w};
-      int cnt = 0;
+    // dy3 = mask3 * dfeat / P, pixel-major [haloed pixel][24 channels] (the region was cleared above, so the halo is zero):
+    // an item is 16 mask bytes = 16 channels of one pixel -> four (two for channels 16..23) 16-byte stores
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = lin - c * P + 4 * e;  // 4 | W4: the 4 pixels of a word share a row
-        float* dst = dy3h + c * P2 + (r / W4 + 1) * S2 + (r % W4) + 1;
+    for (int k = 0; k < NM3; ++k) {
+      const int item = tid + k * NT;
+      if (item < 2 * P) {
+        const int pix = item >> 1, half = item & 1;
+        const unsigned wds[4] = {m3w[k].x, m3w[k].y, m3w[k].z, m3w[k].w};
+        float* dst = dy3h + ((pix / W4 + 1) * S2 + (pix % W4) + 1) * 24 + 16 * half;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const bool on = (wds[e] >> (8 * b)) & 1u;
-          dst[b] = on ? dv : 0.f;
-          cnt += on;
+        for (int e = 0; e < 4; ++e) {
+          if (half == 0 || e < 2) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(&s_dfeat[16 * half + 4 * e]);
+            f32x4 v;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) v[bb] = ((wds[e] >> (8 * bb)) & 1u) ? dv[bb] : 0.f;
+            *reinterpret_cast<f32x4*>(dst + 4 * e) = v;
+          }
         }
       }
-      if (cnt) atomicAdd(&s_gb3[c], dv * (float)cnt);
     }
     if (tid < 256) {  // the forward's xn = (u/255 - mu)/sd, once per grey level instead of once per pixel
       const float rr = (float)tid / 255.0f;
       s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
     }
     __syncthreads();  // C
+    if (tid < 24) s_gb3[tid] += s_dfeat[tid] * s_cnt[tid];  // d b3 = d feat x (number of positive conv3 outputs)
     STAMP(2);
 
     // ---------------- S1: dW3
@@ -344,8 +369,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         const int p0 = pbase + 4 * kk;
         const int y = p0 / W4, x = p0 % W4 + g;
         const int hal = (y + 1) * S2 + x + 1;
-        const float a0 = dy3h[i * P2 + hal];
-        const float a1v = (i < 8) ? dy3h[(16 + i) * P2 + hal] : 0.f;
+        const float a0 = dy3h[hal * 24 + i];
+        const float a1v = (i < 8) ? dy3h[hal * 24 + 16 + i] : 0.f;
         const float* bp = a2h + i * P2 + y * S2 + x;
         float b[5];
 #pragma unroll
@@ -379,32 +404,36 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         const int tile2 = tile + NWV;
         const bool two = tile2 < tiles;
         const int pp0 = 16 * tile + i, pp1 = 16 * (two ? tile2 : tile) + i;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0, acc0b = acc0, acc1b = acc0;  // 4 independent MFMA chains
-        const float* ap0 = dy3h + g * P2 + (pp0 / W4 + 2) * S2 + (pp0 % W4 + 2);
-        const float* ap1 = dy3h + g * P2 + (pp1 / W4 + 2) * S2 + (pp1 % W4 + 2);
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-          const int back = (tap / 3) * S2 + (tap % 3);
-          const float* bt = w3s + g * 144 + i * 9 + tap;
-          float b[6], a0[6], a1[6];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0;
+        // per tap and pixel tile: channels 4g..4g+3 in one ds_read_b128 (k-steps 0..3), channels 16+2g, 17+2g in one
+        // ds_read_b64 (k-steps 4, 5); the tap shift is an immediate
+        const float* ap0 = dy3h + ((pp0 / W4 + 2) * S2 + (pp0 % W4 + 2)) * 24;
+        const float* ap1 = dy3h + ((pp1 / W4 + 2) * S2 + (pp1 % W4 + 2)) * 24;
+        int w3off = (LL::o_w3s + (g * 16 + i) * 4) * 4, w3off8 = (LL::o_w3s + 2304 + (g * 16 + i) * 2) * 4;
+        asm volatile("" : "+v"(w3off), "+v"(w3off8));  // W3 may lie beyond the 64 KB reach of a ds_read immediate (see S5)
+        const float* bt16 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + w3off);
+        const float* bt8 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + w3off8);
 #pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            b[j] = bt[4 * j * 144];
-            a0[j] = ap0[4 * j * P2 - back];
-            a1[j] = ap1[4 * j * P2 - back];
-          }
+        for (int tap = 0; tap < 9; ++tap) {
+          const int back = ((tap / 3) * S2 + (tap % 3)) * 24;
+          const f32x4 b16 = *reinterpret_cast<const f32x4*>(bt16 + tap * 256);
+          const float2 b8 = *reinterpret_cast<const float2*>(bt8 + tap * 128);
+          const f32x4 a016 = *reinterpret_cast<const f32x4*>(ap0 - back + 4 * g);
+          const float2 a08 = *reinterpret_cast<const float2*>(ap0 - back + 16 + 2 * g);
+          const f32x4 a116 = *reinterpret_cast<const f32x4*>(ap1 - back + 4 * g);
+          const float2 a18 = *reinterpret_cast<const float2*>(ap1 - back + 16 + 2 * g);
           SS_SCHED_FENCE();
 #pragma unroll
-          for (int j = 0; j < 6; j += 2) {
-            acc0 = mfma16(a0[j], b[j], acc0);
-            acc1x = mfma16(a1[j], b[j], acc1x);
-            acc0b = mfma16(a0[j + 1], b[j + 1], acc0b);
-            acc1b = mfma16(a1[j + 1], b[j + 1], acc1b);
+          for (int e = 0; e < 4; ++e) {
+            acc0 = mfma16(a016[e], b16[e], acc0);
+            acc1x = mfma16(a116[e], b16[e], acc1x);
           }
+          acc0 = mfma16(a08.x, b8.x, acc0);
+          acc1x = mfma16(a18.x, b8.x, acc1x);
+          acc0 = mfma16(a08.y, b8.y, acc0);
+          acc1x = mfma16(a18.y, b8.y, acc1x);
           SS_SCHED_FENCE();
         }
-        acc0 += acc0b;
-        acc1x += acc1b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pq = 16 * tile + 4 * g + r;

@@ -498,8 +498,8 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     st_i1 = torch.empty(N, n_i1, device="cuda", dtype=torch.uint8)
     st_a2 = torch.empty(N, n_a2, device="cuda")
     st_i2 = torch.empty(N, H4, W4, 16, device="cuda", dtype=torch.uint8)  # pixel-major
-    st_m3 = torch.empty(N, 24, H4 * W4, device="cuda", dtype=torch.uint8)
-    st_feat = torch.empty(N, 24, device="cuda")
+    st_m3 = torch.empty(N, H4 * W4, 32, device="cuda", dtype=torch.uint8)  # pixel-major, 24 of 32 channel slots used
+    st_feat = torch.empty(N, 48, device="cuda")  # 24 features + 24 positive-output counts
     st = [st_a1, st_i1, st_a2, st_i2, st_m3, st_feat]
     L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out.data_ptr(), 32,
            *[s.data_ptr() for s in st], L.stream())
@@ -514,7 +514,7 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
 
     assert_close("stash a1", unhalo(st_a1, 8, H2, W2), a1, atol=1e-5, rtol=1e-5)
     assert_close("stash a2", unhalo(st_a2, 16, H4, W4), a2, atol=2e-5, rtol=1e-5)
-    assert_close("stash feat", st_feat, feat, atol=1e-5, rtol=1e-5)
+    assert_close("stash feat", st_feat[:, :24], feat, atol=1e-5, rtol=1e-5)
 
     # argmax: compare where the winner is positive and clearly separated (ties / relu zeros carry no gradient)
     def idx_to_win(idx, w_in):  # flat index in the (2h x 2w) plane -> 0..3 inside its window
@@ -535,7 +535,8 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
         assert torch.equal(got, want), f"{name}: {(got != want).sum()} argmax mismatches of {sure.sum()}"
     m3_ref = (c3.detach() > 0).reshape(N, 24, -1)
     sure3 = (c3.detach().abs() > 1e-4).reshape(N, 24, -1)
-    assert torch.equal(st_m3.cpu().bool()[sure3], m3_ref[sure3])
+    assert torch.equal(st_m3.cpu()[:, :, :24].permute(0, 2, 1).bool()[sure3], m3_ref[sure3])
+    assert int(st_m3[:, :, 24:].sum()) == 0
 
     G = [torch.zeros_like(p) for p in P]
     L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
