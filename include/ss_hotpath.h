@@ -122,7 +122,11 @@ int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const
  *   Linear layer rides on its weight-gradient GEMM instead of a separate reduction pass.
  * flags bit0: accumulate into C; bit1: ReLU epilogue; bit2: accumulate with float atomics even when K is not
  * split (several streams add into one C).  splits > 1 slices K over blockIdx.z and adds with float atomics
- * (atomics require bit0, C pre-initialised, no ReLU). */
+ * (atomics require bit0, C pre-initialised, no ReLU).
+ * flags bit3 (alone; no bias): C is a split-K workspace of ss_gemm_splitk_ws_floats() floats (16-byte aligned) instead of
+ * the result: every workgroup leaves its raw accumulators there with plain stores and ss_gemm_splitk_reduce adds the
+ * slices into the real C afterwards -- the weight-gradient GEMMs (M x N tiny, K = B*T) spend as long in float atomics
+ * as in their K loop otherwise. */
 int ss_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
                 int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
                 float* C, int ldc, const float* bias, float* a_colsum, int flags, int splits, ss_stream_t stream);
@@ -134,6 +138,12 @@ int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const
                         float* C, int ldc, const float* bias, float* a_colsum, int flags, int splits, int batch,
                         long stride_a, long stride_b, long stride_c, long stride_bias, long stride_colsum,
                         ss_stream_t stream);
+
+/* Second half of a split-K GEMM run with flags bit3: C[b][m][n] += sum over the K slices left in ws.  M, N, K, splits and
+ * batch are those of the GEMM call; stride_c = element stride between the problems' C. */
+int ss_gemm_splitk_ws_floats(int M, int N, int K, int splits, int batch, long* floats);
+int ss_gemm_splitk_reduce(const float* ws, int M, int N, int K, int splits, int batch, float* C, int ldc, long stride_c,
+                          ss_stream_t stream);
 
 /* column sums: out[n] += sum_r A[r*lda + n]  (bias gradients) */
 int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_stream_t stream);

@@ -34,6 +34,8 @@ SIGNATURES = {
     "ss_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
     "ss_gemm_f32_batched": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i,
                             _l, _l, _l, _l, _l, _vp],
+    "ss_gemm_splitk_ws_floats": [_i, _i, _i, _i, _i, _vp],
+    "ss_gemm_splitk_reduce": [_vp, _i, _i, _i, _i, _i, _vp, _i, _l, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
     "ss_batch_gather_f32": [_vp, _i, _vp, _l, _vp, _vp, _f, _u64, _vp, _vp],
     "ss_batch_gather_u8": [_vp, _i, _vp, _l, _vp, _vp],
@@ -95,6 +97,14 @@ def gru_sync_bytes(B: int, T: int, H: int) -> int:
     st = load().ss_gru_sync_bytes(B, T, H, C.byref(n))
     if st != 0:
         raise RuntimeError(f"ss_gru_sync_bytes({B}, {T}, {H}) -> {st}")
+    return n.value
+
+
+def gemm_splitk_ws_floats(M: int, N: int, K: int, splits: int, batch: int) -> int:
+    n = C.c_long(0)
+    st = load().ss_gemm_splitk_ws_floats(M, N, K, splits, batch, C.byref(n))
+    if st != 0:
+        raise RuntimeError(f"ss_gemm_splitk_ws_floats -> {st}")
     return n.value
 
 

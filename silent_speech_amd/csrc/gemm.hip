@@ -41,7 +41,9 @@ struct GemmParams {
   int ksplit;  // K elements per blockIdx.z slice (multiple of BK)
   int nz;      // K slices per problem; blockIdx.z = batch * nz + slice
   long sA, sB, sC, sBias, sAsum;  // element strides between the problems of a batch
-  int flags;   // bit0: accumulate into C (plain RMW when nz==1, atomics otherwise); bit1: ReLU; bit2: always atomic
+  int flags;   // bit0: accumulate into C (plain RMW when nz==1, atomics otherwise); bit1: ReLU; bit2: always atomic;
+               // bit3: C is a split-K workspace -- every workgroup leaves its accumulators there as they lie in its
+               // registers (16 bytes per lane, fully coalesced) and splitk_reduce_kernel folds the slices into the real C
 };
 
 // One operand tile, staged global -> registers (fetch) -> LDS (store) so the loads of tile k+1 are in
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
 
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int bi = blockIdx.z / p.nz, zs = blockIdx.z - bi * p.nz;
-  p.A += bi * p.sA; p.B += bi * p.sB; p.C += bi * p.sC;
+  p.A += bi * p.sA; p.B += bi * p.sB;
+  if (!(p.flags & 8)) p.C += bi * p.sC;
   if (p.bias) p.bias += bi * p.sBias;
   if (p.asum) p.asum += bi * p.sAsum;
   const int kbeg = zs * p.ksplit;
@@ -224,6 +227,17 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
     if (want_asum && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) atomicAdd(&p.asum[m0 + threadIdx.x], asum);
   }
 
+  if (p.flags & 8) {
+    // plain 16-byte stores of the raw accumulators instead of 32 float atomics per lane
+    f32x4* w = reinterpret_cast<f32x4*>(p.C) +
+               (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (8 * 256) + threadIdx.x;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) w[(mt * 2 + nt) * 256] = acc[mt][nt];
+    STAMP_WAIT(4);
+    return;
+  }
   const bool accumulate = p.flags & 1, relu = p.flags & 2;
   const bool atomic = p.nz > 1 || (p.flags & 4);
   auto emit = [&](const f32x4& av, int mt, int nt) {
@@ -274,7 +288,60 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
 #endif
 }
 
+// C[bi][row][col] += sum over the nz slices of the accumulators the GEMM workgroups left in `ws` (flags bit3).
+// One thread owns one accumulator quad (mt, nt, lane) of one output tile: nz coalesced 16-byte reads, four read-modify-writes.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restrict__ ws, int nz, int gx, int gy, int M, int N,
+                                                            float* __restrict__ C, int ldc, long sC) {
+  const int q = blockIdx.x & 7, tile = blockIdx.x >> 3;
+  const int bx = tile % gx, by = (tile / gx) % gy, bi = tile / (gx * gy);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1, i = lane & 15, g = lane >> 4;
+  const int mt = q >> 1, nt = q & 1;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  const f32x4* src = ws + ((((long)bi * nz) * gy + by) * gx + bx) * (8 * 256) + q * 256 + tid;
+  const long zstride = (long)gy * gx * (8 * 256);
+  int z = 0;
+  for (; z + 1 < nz; z += 2) {
+    const f32x4 a = src[z * zstride], b = src[(z + 1) * zstride];
+    s0 += a;
+    s1 += b;
+  }
+  if (z < nz) s0 += src[z * zstride];
+  s0 += s1;
+  const int col = bx * BN + wn * 32 + nt * 16 + i;
+  if (col >= N) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = by * BM + wm * 64 + mt * 16 + 4 * g + r;
+    if (row < M) C[bi * sC + (long)row * ldc + col] += s0[r];
+  }
+}
+
+int splitk_slices(int K, int splits, int* per_out) {
+  const int per = ceil_div(ceil_div(K, splits), BK * KSUB) * BK * KSUB;
+  if (per_out) *per_out = per;
+  return ceil_div(K, per);
+}
+
 }  // namespace
+
+// Floats a split-K workspace needs for ss_gemm_f32_batched(flags bit3) + ss_gemm_splitk_reduce on this problem.
+extern "C" int ss_gemm_splitk_ws_floats(int M, int N, int K, int splits, int batch, long* floats) {
+  SS_REQUIRE(M > 0 && N > 0 && K > 0 && splits >= 1 && batch >= 1 && floats, SS_ERR_ARG);
+  *floats = (long)batch * splitk_slices(K, splits, nullptr) * ceil_div(M, BM) * ceil_div(N, BN) * BM * BN;
+  return SS_OK;
+}
+
+// Second half of a split-K GEMM whose slices were left in `ws` (ss_gemm_f32_batched with flags bit3 and C = ws):
+// C[b] += sum of the slices.  Same M, N, K, splits, batch as the GEMM call.
+extern "C" int ss_gemm_splitk_reduce(const float* ws, int M, int N, int K, int splits, int batch, float* C, int ldc,
+                                     long stride_c, ss_stream_t stream) {
+  SS_REQUIRE(ws && C && M > 0 && N > 0 && K > 0 && splits >= 1 && batch >= 1 && ldc >= N, SS_ERR_ARG);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, SS_ERR_ARG);
+  const int nz = splitk_slices(K, splits, nullptr), gx = ceil_div(N, BN), gy = ceil_div(M, BM);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(batch * gx * gy * 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), reinterpret_cast<const f32x4*>(ws), nz, gx, gy, M, N, C, ldc, stride_c);
+  return ss_launch_status();
+}
 
 extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda,
                                    int a_group, int a_gstride, int a_off, const float* B, int ldb, int b_group,
@@ -285,16 +352,16 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
   SS_REQUIRE(!a_colsum || !a_kcontig, SS_ERR_ARG);
   SS_REQUIRE(splits >= 1 && a_group > 0 && b_group > 0, SS_ERR_ARG);
   // split-K accumulates with atomics: C must already hold the value to add to, and ReLU cannot apply
-  SS_REQUIRE((splits == 1 && !(flags & 4)) || ((flags & 1) && !(flags & 2)), SS_ERR_ARG);
+  SS_REQUIRE((flags & 8) || (splits == 1 && !(flags & 4)) || ((flags & 1) && !(flags & 2)), SS_ERR_ARG);
+  // workspace mode: raw accumulators only -- bias, ReLU and accumulation belong to the reduce pass
+  SS_REQUIRE(!(flags & 8) || (!(flags & 7) && !bias && (reinterpret_cast<uintptr_t>(C) & 15) == 0), SS_ERR_ARG);
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.asum = a_colsum;
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.ra = RowMap{a_group, a_gstride, a_off};
   p.rb = RowMap{b_group, b_gstride, b_off};
-  int per = ceil_div(ceil_div(K, splits), BK * KSUB) * BK * KSUB;
-  p.ksplit = per;
-  p.nz = ceil_div(K, per);
+  p.nz = splitk_slices(K, splits, &p.ksplit);
   p.sA = stride_a; p.sB = stride_b; p.sC = stride_c; p.sBias = stride_bias; p.sAsum = stride_colsum;
   p.flags = flags;
   dim3 grid(ceil_div(N, BN), ceil_div(M, BM), p.nz * batch), block(256);

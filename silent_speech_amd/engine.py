@@ -30,6 +30,7 @@ INT_MAX = 2**31 - 1
 JOIN_BEFORE_CNN_BWD = True
 SIDE_AFTER_DX = os.environ.get("SS_SIDE_AFTER_DX", "0") == "1"  # measured: 2.55 vs 2.52 ms/step, off
 USE_SPLIT_GRU = True
+USE_SPLITK_WS = os.environ.get("SS_NO_SPLITK_WS", "0") != "1"  # weight-gradient K slices via scratch + reduce, not atomics
 USE_SIDE_STREAM = os.environ.get("SS_NO_SIDE_STREAM", "0") != "1"
 
 
@@ -54,9 +55,20 @@ class Config:
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, relu=False, splits=1,
          a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0), a_colsum=None, tag="gemm", batch=1, strides=(0, 0, 0, 0, 0),
-         atomic=False):
+         atomic=False, splitk_ws: Optional[torch.Tensor] = None):
     """C[M,N] (+)= opA * opB (+bias)(ReLU); A/B/Cm are ints (device addresses).  ``batch`` problems of one shape
-    share a launch; ``strides`` = element strides of (A, B, C, bias, a_colsum) between them."""
+    share a launch; ``strides`` = element strides of (A, B, C, bias, a_colsum) between them.  With ``splitk_ws`` (a float
+    scratch tensor) the K slices are left there and folded into C by a second, tiny launch instead of float atomics."""
+    if splitk_ws is not None and splits > 1 and accumulate and not relu and bias is None:
+        need = L.gemm_splitk_ws_floats(M, N, K, splits, batch)
+        if splitk_ws.numel() < need:
+            raise RuntimeError(f"split-K workspace too small: {splitk_ws.numel()} < {need}")
+        L.call("ss_gemm_f32_batched", int(a_kc), int(b_kc), M, N, K, A, lda, a_map[0], a_map[1], a_map[2], B, ldb,
+               b_map[0], b_map[1], b_map[2], splitk_ws.data_ptr(), N, None, a_colsum, 8, splits, batch,
+               strides[0], strides[1], 0, 0, strides[4], L.stream(), tag=tag)
+        L.call("ss_gemm_splitk_reduce", splitk_ws.data_ptr(), M, N, K, splits, batch, Cm, ldc, strides[2], L.stream(),
+               tag=tag + "_reduce")
+        return
     flags = (1 if accumulate else 0) | (2 if relu else 0) | (4 if atomic else 0)
     L.call("ss_gemm_f32_batched", int(a_kc), int(b_kc), M, N, K, A, lda, a_map[0], a_map[1], a_map[2], B, ldb,
            b_map[0], b_map[1], b_map[2], Cm, ldc, bias, a_colsum, flags, splits, batch, *strides, L.stream(), tag=tag)
@@ -112,6 +124,16 @@ class Workspace:
             self.d_out = torch.empty(N, 2 * H, **f32)
             # gradient w.r.t. the output of layer l-1 (destination of layer l's d layer_in GEMM, l >= 1): zeroed on the side
             # stream while the top of the backward pass runs, summed into with atomics by both directions
+            # scratch for the K slices of the weight-gradient GEMMs (they run one after another on the side stream)
+            self.splitk_ws = None
+            if USE_SPLITK_WS:
+                need = 0
+                for l in range(cfg.gru_layers):
+                    K = cfg.in_dim if l == 0 else 2 * H
+                    shapes = [(3 * H, K, N)] + ([(2 * H, H, B * (T - 1)), (H, H, B * (T - 1))] if T > 1 else [])
+                    for (m_, n_, k_) in shapes:
+                        need = max(need, L.gemm_splitk_ws_floats(m_, n_, k_, split_k(m_, n_, k_, 2), 2))
+                self.splitk_ws = torch.empty(need, **f32)
             self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
             self.ev_zero = torch.cuda.Event()
             self.xhat = torch.empty(B, 2 * H, **f32)
@@ -257,7 +279,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                 wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
                 # d W_ih = dGi^T . layer_in, both directions in one launch
                 gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
-                     splits=split_k(3 * H, K, N, 2), tag="gemm_gru_dW", batch=2,
+                     splits=split_k(3 * H, K, N, 2), tag="gemm_gru_dW", batch=2, splitk_ws=ws.splitk_ws,
                      strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0, 0))
                 # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse).
                 # With the row remap (group T-1 of stride T, A offset 1, B offset 0) the reverse direction is the same
@@ -268,11 +290,11 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                     gw = G[wh]
                     gemm(0, 0, 2 * H, H, B * (T - 1), dg, 4 * H, ws.out[l].data_ptr(), 2 * H, gw.data_ptr(), H,
                          accumulate=True, atomic=True, splits=split_k(2 * H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2,
-                         strides=st,
+                         strides=st, splitk_ws=ws.splitk_ws,
                          **maps)
                     gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, ws.out[l].data_ptr(), 2 * H, _addr(gw, 2 * H * H), H,
                          accumulate=True, atomic=True, splits=split_k(H, H, B * (T - 1), 2), tag="gemm_gru_dW", batch=2,
-                         strides=st,
+                         strides=st, splitk_ws=ws.splitk_ws,
                          **maps)
         # the weight-gradient GEMMs of the upper layers start only when this layer's d layer_in GEMM is through: two
         # MFMA-bound GEMMs side by side gain nothing and the one on the critical path loses half its rate; beside the
@@ -294,8 +316,11 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                 d_X.zero_()
             torch.cuda.current_stream().wait_event(ws.ev_zero)
             wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
-            gemm(1, 0, N, K, 3 * H, ws.dG[l].data_ptr(), 4 * H, P[wi].data_ptr(), K, dst, ld_dst, accumulate=True,
-                 atomic=True, tag="gemm_gru_dX", batch=2, strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0, 0))
+            # nobody asked for d X: only the ROI-embedding columns of d Z feed the CNN backward
+            c0 = cfg.x_dim if (l == 0 and cfg.use_roi and d_X is None) else 0
+            gemm(1, 0, N, K - c0, 3 * H, ws.dG[l].data_ptr(), 4 * H, _addr(P[wi], c0), K, dst + 4 * c0, ld_dst,
+                 accumulate=True, atomic=True, tag="gemm_gru_dX", batch=2,
+                 strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0, 0))
         if SIDE_AFTER_DX and l > 0:
             side_work()
     # ---- ROI CNN

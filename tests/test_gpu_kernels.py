@@ -116,6 +116,26 @@ def test_gemm_accumulate_relu_splitk_rowmap(L):
     assert_close("a_colsum", cs_d, cs_ref, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,splits,batch", [(576, 116, 1920, 7, 2), (200, 70, 333, 4, 1), (48, 40, 64, 5, 3)])
+def test_gemm_splitk_workspace(L, M, N, K, splits, batch):
+    """K slices left in a scratch buffer + the reduce pass == accumulate with one GEMM (the weight-gradient path)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(batch, K, M, generator=g)
+    Bm = torch.randn(batch, K, N, generator=g)
+    C0 = torch.randn(batch, M, N + 3, generator=g)
+    ref = C0.clone()
+    ref[:, :, :N] += torch.einsum("bkm,bkn->bmn", A.double(), Bm.double()).float()
+    a_d, b_d, c_d = dev(A), dev(Bm), dev(C0)
+    need = L.gemm_splitk_ws_floats(M, N, K, splits, batch)
+    ws = torch.full((need + 8,), float("nan"), device="cuda")
+    L.call("ss_gemm_f32_batched", 0, 0, M, N, K, a_d.data_ptr(), M, INT_MAX, 0, 0, b_d.data_ptr(), N, INT_MAX, 0, 0,
+           ws.data_ptr(), N, None, None, 8, splits, batch, K * M, K * N, 0, 0, 0, L.stream())
+    L.call("ss_gemm_splitk_reduce", ws.data_ptr(), M, N, K, splits, batch, c_d.data_ptr(), N + 3, M * (N + 3), L.stream())
+    sync()
+    assert_close("splitk workspace", c_d, ref, atol=2e-5 * K ** 0.5, rtol=1e-5)
+    assert torch.isnan(ws[need:]).all(), "wrote past the advertised workspace size"
+
+
 # ------------------------------------------------------------------------------------- GRU
 def _gru_case(H, In, B, T, seed, lengths=None):
     g = torch.Generator().manual_seed(seed)

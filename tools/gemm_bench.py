@@ -38,6 +38,10 @@ def main():
         ("dWhh   384x192x7424 s42 atomic", 0, 0, 384, 192, 7424, 42, True),
         ("dWhh   384x192x7424 s14 atomic", 0, 0, 384, 192, 7424, 14, True),
     ]
+    cases += [(f"dWih1  576x384x7680 s{k} ws", 0, 0, 576, 384, 7680, k, "ws") for k in (4, 6, 8, 12, 16, 21)]
+    cases += [(f"dWhh   384x192x7424 s{k} ws", 0, 0, 384, 192, 7424, k, "ws") for k in (8, 14, 21, 42)]
+    cases += [("dX l0  7680x32x576", 1, 0, 7680, 32, 576, 1, False)]
+    scratch = torch.empty(64 << 20, device=dev)
     for name, akc, bkc, M, N, K, splits, atomic in cases:
         A = torch.randn((M, K) if akc else (K, M), device=dev)
         B = torch.randn((N, K) if bkc else (K, N), device=dev)
@@ -46,8 +50,9 @@ def main():
         ldb = K if bkc else N
 
         def run():
-            E.gemm(akc, bkc, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, Cm.data_ptr(), N, accumulate=atomic or splits > 1,
-                   atomic=atomic, splits=splits)
+            E.gemm(akc, bkc, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, Cm.data_ptr(), N,
+                   accumulate=bool(atomic) or splits > 1, atomic=atomic is True, splits=splits,
+                   splitk_ws=scratch if atomic == "ws" else None)
 
         t = timed(run)
         print(f"{name:34s} {t * 1e6:8.1f} us  {2.0 * M * N * K / t / 1e12:6.1f} TFLOP/s", flush=True)
