@@ -10,6 +10,8 @@
 // four k-steps, an operand whose M/N index is contiguous is kept [k][row] and read with ds_read_b32.
 // Inside a 16-wide k tile the MFMA slot (kk, g) carries k = 4g + kk for BOTH operands, which is
 // what lets the [row][k] form use a single 16-byte read.
+#include <stdlib.h>
+
 #include "ss_common.h"
 
 STAMP_TABLE(ss_debug_stamps_gemm)
@@ -45,6 +47,62 @@ struct GemmParams {
                // bit3: C is a split-K workspace -- every workgroup leaves its accumulators there as they lie in its
                // registers (16 bytes per lane, fully coalesced) and splitk_reduce_kernel folds the slices into the real C
 };
+
+// Shared epilogue: acc[mt][nt] of the wave's 64x32 sub-tile -> C (plain / accumulate / ReLU / float atomics) or, with
+// flags bit3, into the split-K workspace as the accumulators lie in the registers.
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][2], int m0, int n0, int zs, int wm, int wn,
+                                              int i, int g) {
+  if (p.flags & 8) {
+    // plain 16-byte stores of the raw accumulators instead of 32 float atomics per lane
+    f32x4* w = reinterpret_cast<f32x4*>(p.C) +
+               (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (8 * 256) + threadIdx.x;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) w[(mt * 2 + nt) * 256] = acc[mt][nt];
+    return;
+  }
+  const bool accumulate = p.flags & 1, relu = p.flags & 2;
+  const bool atomic = p.nz > 1 || (p.flags & 4);
+  auto emit = [&](const f32x4& av, int mt, int nt) {
+    int col = n0 + wn * 32 + nt * 16 + i;
+    if (col >= p.N) return;
+    float bv = (p.bias && zs == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = m0 + wm * 64 + mt * 16 + 4 * g + r;
+      if (row >= p.M) continue;
+      float v = av[r] + bv;
+      float* dst = p.C + (long)row * p.ldc + col;
+      if (atomic) {
+        atomicAdd(dst, v);
+      } else {
+        if (accumulate) v += *dst;
+        if (relu) v = fmaxf(v, 0.f);
+        *dst = v;
+      }
+    }
+  };
+  if (p.nz > 1) {
+    // split-K slices of one tile reach their epilogues together: each starts at a different row group so that their
+    // atomics meet on different lines (wave-uniform rotation; costs a register-indexed read of the accumulators)
+    const int rot = zs & 3;
+#pragma unroll
+    for (int mt_ = 0; mt_ < 4; ++mt_) {
+      const int mt = (mt_ + rot) & 3;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 av = mt == 0 ? acc[0][nt] : mt == 1 ? acc[1][nt] : mt == 2 ? acc[2][nt] : acc[3][nt];
+        emit(av, mt, nt);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) emit(acc[mt][nt], mt, nt);
+  }
+}
 
 // One operand tile, staged global -> registers (fetch) -> LDS (store) so the loads of tile k+1 are in
 // flight while tile k is multiplied.  ROWS = BM or BN.
@@ -227,57 +285,7 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
     if (want_asum && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) atomicAdd(&p.asum[m0 + threadIdx.x], asum);
   }
 
-  if (p.flags & 8) {
-    // plain 16-byte stores of the raw accumulators instead of 32 float atomics per lane
-    f32x4* w = reinterpret_cast<f32x4*>(p.C) +
-               (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (8 * 256) + threadIdx.x;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) w[(mt * 2 + nt) * 256] = acc[mt][nt];
-    STAMP_WAIT(4);
-    return;
-  }
-  const bool accumulate = p.flags & 1, relu = p.flags & 2;
-  const bool atomic = p.nz > 1 || (p.flags & 4);
-  auto emit = [&](const f32x4& av, int mt, int nt) {
-    int col = n0 + wn * 32 + nt * 16 + i;
-    if (col >= p.N) return;
-    float bv = (p.bias && zs == 0) ? p.bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int row = m0 + wm * 64 + mt * 16 + 4 * g + r;
-      if (row >= p.M) continue;
-      float v = av[r] + bv;
-      float* dst = p.C + (long)row * p.ldc + col;
-      if (atomic) {
-        atomicAdd(dst, v);
-      } else {
-        if (accumulate) v += *dst;
-        if (relu) v = fmaxf(v, 0.f);
-        *dst = v;
-      }
-    }
-  };
-  if (p.nz > 1) {
-    // split-K slices of one tile reach their epilogues together: each starts at a different row group so that their
-    // atomics meet on different lines (wave-uniform rotation; costs a register-indexed read of the accumulators)
-    const int rot = zs & 3;
-#pragma unroll
-    for (int mt_ = 0; mt_ < 4; ++mt_) {
-      const int mt = (mt_ + rot) & 3;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const f32x4 av = mt == 0 ? acc[0][nt] : mt == 1 ? acc[1][nt] : mt == 2 ? acc[2][nt] : acc[3][nt];
-        emit(av, mt, nt);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) emit(acc[mt][nt], mt, nt);
-  }
+  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g);
   STAMP_WAIT(4);
 #ifdef SS_STAMP
   {  // the first 256 workgroups in dispatch order report
@@ -286,6 +294,206 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
       for (int k_ = 0; k_ < SS_STAMP_SLOTS; ++k_) ss_stamp_buf[lin * SS_STAMP_SLOTS + k_] = st_acc[k_];
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same 128x64x16 tile fed by LDS-DMA through a ring of DSTAGES k tiles.
+//
+// Measured on the shapes of the path (K slices of 16..120 k tiles, 1..3 workgroups per CU): the register-staged kernel
+// above spends ~2800 cycles per k tile on a CU it has to itself -- one full memory latency per tile, prefetch distance 1 --
+// against 1024 cycles of MFMA work.  Here global_load_lds_dwordx4 writes the tiles straight into LDS, DSTAGES - 1 tiles
+// ahead, with no VGPRs and no LDS store instruction on the way; the wave waits with vmcnt(3 * (DSTAGES - 2)), so only
+// the oldest tile in flight has to have landed.
+//
+// The DMA puts lane l's 16 bytes at (wave-uniform base) + 16 l, so the LDS image is fixed and the SOURCE addresses carry the
+// swizzle that keeps the MFMA operand reads conflict-free without padding:
+//   [k][row] operand  : image [16 k][ROWS] floats; 16-byte unit u of k row k holds row unit (u - 4 * ((k >> 2) & 1)):
+//                       the ds_read_b32 of lane groups g and g + 1 (k rows 4 apart) land 16 banks apart
+//   [row][k] operand  : image [ROWS][16 k]; unit s of row r holds k unit s ^ ((r >> 2) & 3): the ds_read_b128 of 16
+//                       consecutive rows covers all 16 bank groups
+// Rows past M / N are clamped to the last valid ones (they only feed accumulators nobody stores); a ragged last k tile goes
+// through registers with zero fill.
+constexpr int DSTAGES = 4;
+constexpr int D_A = BM * BK, D_B = BN * BK, D_STAGE = D_A + D_B;  // floats per stage: 12 KB
+
+template <int ROWS, bool KC>
+struct DmaOperand {
+  static constexpr int U = ROWS / 4;    // 16-byte units per k row of the [k][row] image
+  static constexpr int NL = ROWS / 64;  // 1 KB wave loads per wave and k tile
+  const float* src[NL];  // KC: this lane's source for the current tile; else: P + its (clamped) row unit
+  int q[NL], r[NL];      // [k][row] operand: storage k row of the current tile = q * rm.S + r + rm.off, r < rm.G
+  RowMap rm;
+  int ld;
+
+  __device__ __forceinline__ void init(const float* P, int ld_, const RowMap& rm_, int row0, int nrows, int kbeg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    rm = rm_;
+    ld = ld_;
+#pragma unroll
+    for (int n = 0; n < NL; ++n) {
+      const int sl = 64 * (wave + 4 * n) + lane;  // this lane's 16-byte slot of the stage image
+      if (KC) {
+        const int rr = sl >> 2, ku = (sl & 3) ^ ((rr >> 2) & 3);
+        const int gr = min(row0 + rr, nrows - 1);
+        src[n] = P + rm(gr) * ld + kbeg + 4 * ku;
+        q[n] = r[n] = 0;
+      } else {
+        const int k = sl / U, u = sl % U, ru = (u - 4 * ((k >> 2) & 1)) & (U - 1);
+        src[n] = P + min(row0 + 4 * ru, nrows - 4);
+        const int gk = kbeg + k;
+        q[n] = rm.G == 0x7fffffff ? 0 : gk / rm.G;
+        r[n] = gk - q[n] * rm.G;
+      }
+    }
+  }
+  __device__ __forceinline__ const float* cur(int n) const {
+    return KC ? src[n] : src[n] + ((long)q[n] * rm.S + r[n] + rm.off) * ld;
+  }
+  __device__ __forceinline__ void issue(unsigned lds_byte) const {
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < NL; ++n) ss_dma16(cur(n), lds_byte + (wave + 4 * n) * 1024);
+  }
+  __device__ __forceinline__ void advance() {
+#pragma unroll
+    for (int n = 0; n < NL; ++n) {
+      if (KC) {
+        src[n] += BK;
+      } else {
+        r[n] += BK;
+        while (r[n] >= rm.G) { r[n] -= rm.G; ++q[n]; }
+      }
+    }
+  }
+  // ragged last tile (kvalid < 16 k left): same image, through registers, zeros past the end
+  __device__ __forceinline__ void tail(float* img, int kvalid) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < NL; ++n) {
+      const int sl = 64 * (wave + 4 * n) + lane;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (KC) {
+        const int rr = sl >> 2, ku = (sl & 3) ^ ((rr >> 2) & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * ku + e < kvalid) v[e] = src[n][e];
+      } else {
+        if (sl / U < kvalid) v = *reinterpret_cast<const f32x4*>(cur(n));
+      }
+      *reinterpret_cast<f32x4*>(img + 4 * sl) = v;
+    }
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void ss_vmcnt_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void ss_raw_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dlds[];  // DSTAGES x (A image, B image), at LDS address 0
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int bi = blockIdx.z / p.nz, zs = blockIdx.z - bi * p.nz;
+  p.A += bi * p.sA; p.B += bi * p.sB;
+  if (!(p.flags & 8)) p.C += bi * p.sC;
+  if (p.bias) p.bias += bi * p.sBias;
+  const int kbeg = zs * p.ksplit;
+  const int kend = min(p.K, kbeg + p.ksplit);
+  const int nfull = (kend - kbeg) / BK, rem = (kend - kbeg) - nfull * BK;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int i = lane & 15, g = lane >> 4;
+
+  DmaOperand<BM, A_KC> da;
+  DmaOperand<BN, B_KC> db;
+  da.init(p.A, p.lda, p.ra, m0, p.M, kbeg);
+  db.init(p.B, p.ldb, p.rb, n0, p.N, kbeg);
+  constexpr int LPW = DmaOperand<BM, A_KC>::NL + DmaOperand<BN, B_KC>::NL;  // DMA instructions per wave and k tile
+
+  // this lane's operand read offsets inside a stage (floats); the rest of every address is an immediate
+  int offA[4], offB[2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+    offA[mt] = A_KC ? (wm * 64 + mt * 16 + i) * BK + 4 * (g ^ ((i >> 2) & 3))
+                    : 4 * g * BM + (((16 * wm + 4 * mt + (i >> 2) + 4 * (g & 1)) & 31) << 2) + (i & 3);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+    offB[nt] = D_A + (B_KC ? (wn * 32 + nt * 16 + i) * BK + 4 * (g ^ ((i >> 2) & 3))
+                           : 4 * g * BN + (((8 * wn + 4 * nt + (i >> 2) + 4 * (g & 1)) & 15) << 2) + (i & 3));
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int buf) {
+    da.issue((unsigned)(buf * D_STAGE * 4));
+    db.issue((unsigned)((buf * D_STAGE + D_A) * 4));
+    da.advance();
+    db.advance();
+  };
+  auto compute = [&](const float* st) {
+    float a[4][4], b[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (A_KC) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(st + offA[mt]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[mt][kk] = v[kk];
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[mt][kk] = st[offA[mt] + kk * BM];
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      if (B_KC) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(st + offB[nt]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b[nt][kk] = v[kk];
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b[nt][kk] = st[offB[nt] + kk * BN];
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(a[mt][kk], b[nt][kk], acc[mt][nt]);
+  };
+
+#pragma unroll
+  for (int s_ = 0; s_ < DSTAGES - 1; ++s_)
+    if (s_ < nfull) issue(s_);
+  for (int t0 = 0; t0 < nfull; t0 += DSTAGES) {
+#pragma unroll
+    for (int s_ = 0; s_ < DSTAGES; ++s_) {
+      const int t = t0 + s_;
+      if (t < nfull) {
+        // tile t has landed once at most the DSTAGES - 2 younger tiles are still in flight (the pipeline tail just drains)
+        if (t + DSTAGES - 2 < nfull) ss_vmcnt_wait<(DSTAGES - 2) * LPW>();
+        else ss_vmcnt_wait<0>();
+        ss_raw_barrier();  // everybody's share of tile t is in LDS, and everybody is done reading tile t - 1 ...
+        if (t + DSTAGES - 1 < nfull) issue((s_ + DSTAGES - 1) % DSTAGES);  // ... whose buffer the new tile takes
+        compute(dlds + s_ * D_STAGE);
+      }
+    }
+  }
+  if (rem) {
+    __syncthreads();
+    da.tail(dlds, rem);
+    db.tail(dlds + D_A, rem);
+    __syncthreads();
+    compute(dlds);
+  }
+  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g);
 }
 
 // C[bi][row][col] += sum over the nz slices of the accumulators the GEMM workgroups left in `ws` (flags bit3).
@@ -343,6 +551,8 @@ extern "C" int ss_gemm_splitk_reduce(const float* ws, int M, int N, int K, int s
   return ss_launch_status();
 }
 
+static const bool ss_gemm_no_dma = getenv("SS_GEMM_NO_DMA") != nullptr;  // diagnostic: force the register-staged kernel
+
 extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda,
                                    int a_group, int a_gstride, int a_off, const float* B, int ldb, int b_group,
                                    int b_gstride, int b_off, float* C, int ldc, const float* bias, float* a_colsum,
@@ -367,6 +577,20 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
   dim3 grid(ceil_div(N, BN), ceil_div(M, BM), p.nz * batch), block(256);
   SS_REQUIRE(grid.z <= 65535, SS_ERR_UNSUPPORTED);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // the DMA-fed kernel wants 16-byte aligned operands whose [k][row] row counts are multiples of 4; the rest (the head's
+  // tiny GEMMs, column sums riding along) stays on the register-staged kernel
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool dma_ok = !a_colsum && al16(A) && al16(B) && (lda & 3) == 0 && (ldb & 3) == 0 && (stride_a & 3) == 0 &&
+                      (stride_b & 3) == 0 && (a_kcontig || (M >= 4 && (M & 3) == 0)) && (b_kcontig || (N >= 4 && (N & 3) == 0)) &&
+                      p.ksplit >= 4 * BK && !ss_gemm_no_dma;
+  if (dma_ok) {
+    constexpr size_t lds_bytes = (size_t)DSTAGES * D_STAGE * sizeof(float);
+    if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, block, lds_bytes, s, p);
+    else if (a_kcontig && !b_kcontig) hipLaunchKernelGGL((gemm_dma_kernel<true, false>), grid, block, lds_bytes, s, p);
+    else if (!a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_dma_kernel<false, true>), grid, block, lds_bytes, s, p);
+    else hipLaunchKernelGGL((gemm_dma_kernel<false, false>), grid, block, lds_bytes, s, p);
+    return ss_launch_status();
+  }
   if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p);
   else if (a_kcontig && !b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
   else if (!a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);

@@ -30,6 +30,28 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // (left alone, hipcc sinks every read next to its MFMA and waits lgkmcnt(0) in between: one LDS latency per MFMA).
 #define SS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to lds_byte_addr + lane*16 (wave-uniform base), no VGPRs.
+// Inline asm on purpose: hipcc does not track it, so the workgroup barriers between issue and use do not drain it;
+// the consumer waits with ss_dma_wait() before its barrier (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void ss_dma16(const void* gsrc_lane, unsigned lds_byte_addr) {
+  lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);  // wave-uniform by contract: make it an SGPR
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc_lane), "s"(lds_byte_addr)
+               : "memory");
+}
+// same with 4 bytes per lane (lane l -> lds_byte_addr + 4 l)
+__device__ __forceinline__ void ss_dma4(const void* gsrc_lane, unsigned lds_byte_addr) {
+  lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc_lane), "s"(lds_byte_addr)
+               : "memory");
+}
+__device__ __forceinline__ void ss_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Wave-wide reductions on the DPP crossbar instead of __shfl_xor (which lowers to ds_bpermute_b32: one LDS round
 // trip, ~100 cycles, per butterfly level).  Four DPP levels leave every lane of a 16-lane row with its row's result,
 // four v_readlane + three VALU ops combine the rows: ~40 cycles for a 64-lane reduction instead of ~600.
