@@ -320,15 +320,22 @@ template <int ROWS, bool KC>
 struct DmaOperand {
   static constexpr int U = ROWS / 4;    // 16-byte units per k row of the [k][row] image
   static constexpr int NL = ROWS / 64;  // 1 KB wave loads per wave and k tile
-  const float* src[NL];  // KC: this lane's source for the current tile; else: P + its (clamped) row unit
-  int q[NL], r[NL];      // [k][row] operand: storage k row of the current tile = q * rm.S + r + rm.off, r < rm.G
+  // Running source pointer of this lane's slot.  linear (wave-uniform): the next tile is `step` floats further on -- always
+  // for a [row][k] operand, and for a [k][row] operand whose k rows are stored in order.  Otherwise (the (b,t) -> (b,t-1)
+  // pairing of d W_hh) the storage k row of the current tile is q * rm.S + r (+ rm.off, folded into src), r < rm.G.
+  const float* src[NL];
+  int q[NL], r[NL];
   RowMap rm;
+  long step;
   int ld;
+  bool linear;
 
   __device__ __forceinline__ void init(const float* P, int ld_, const RowMap& rm_, int row0, int nrows, int kbeg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     rm = rm_;
     ld = ld_;
+    linear = KC || rm.G == 0x7fffffff;
+    step = KC ? BK : (long)BK * ld;
 #pragma unroll
     for (int n = 0; n < NL; ++n) {
       const int sl = 64 * (wave + 4 * n) + lane;  // this lane's 16-byte slot of the stage image
@@ -339,15 +346,16 @@ struct DmaOperand {
         q[n] = r[n] = 0;
       } else {
         const int k = sl / U, u = sl % U, ru = (u - 4 * ((k >> 2) & 1)) & (U - 1);
-        src[n] = P + min(row0 + 4 * ru, nrows - 4);
         const int gk = kbeg + k;
-        q[n] = rm.G == 0x7fffffff ? 0 : gk / rm.G;
+        src[n] = P + min(row0 + 4 * ru, nrows - 4) + (long)rm.off * ld;
+        q[n] = linear ? 0 : gk / rm.G;
         r[n] = gk - q[n] * rm.G;
+        if (linear) src[n] += (long)gk * ld;
       }
     }
   }
   __device__ __forceinline__ const float* cur(int n) const {
-    return KC ? src[n] : src[n] + ((long)q[n] * rm.S + r[n] + rm.off) * ld;
+    return linear ? src[n] : src[n] + ((long)q[n] * rm.S + r[n]) * ld;
   }
   __device__ __forceinline__ void issue(unsigned lds_byte) const {
     const int wave = threadIdx.x >> 6;
@@ -355,11 +363,12 @@ struct DmaOperand {
     for (int n = 0; n < NL; ++n) ss_dma16(cur(n), lds_byte + (wave + 4 * n) * 1024);
   }
   __device__ __forceinline__ void advance() {
+    if (linear) {
 #pragma unroll
-    for (int n = 0; n < NL; ++n) {
-      if (KC) {
-        src[n] += BK;
-      } else {
+      for (int n = 0; n < NL; ++n) src[n] += step;
+    } else {
+#pragma unroll
+      for (int n = 0; n < NL; ++n) {
         r[n] += BK;
         while (r[n] >= rm.G) { r[n] -= rm.G; ++q[n]; }
       }
@@ -437,7 +446,10 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
     da.advance();
     db.advance();
   };
-  auto compute = [&](const float* st) {
+  // `refill`: buffer to start the next DMA into (-1: none), issued between the two halves of the MFMA block -- a wave
+  // alone on its SIMD has nothing else to cover the ~100 cycles of address arithmetic and M0 traffic
+  auto compute = [&](const float* st, int refill) {
+    if (refill >= 0) issue(refill);
     float a[4][4], b[2][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -462,11 +474,12 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
       }
     }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(a[mt][kk], b[nt][kk], acc[mt][nt]);
+    }
   };
 
 #pragma unroll
@@ -481,8 +494,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
         if (t + DSTAGES - 2 < nfull) ss_vmcnt_wait<(DSTAGES - 2) * LPW>();
         else ss_vmcnt_wait<0>();
         ss_raw_barrier();  // everybody's share of tile t is in LDS, and everybody is done reading tile t - 1 ...
-        if (t + DSTAGES - 1 < nfull) issue((s_ + DSTAGES - 1) % DSTAGES);  // ... whose buffer the new tile takes
-        compute(dlds + s_ * D_STAGE);
+        compute(dlds + s_ * D_STAGE, t + DSTAGES - 1 < nfull ? (s_ + DSTAGES - 1) % DSTAGES : -1);  // ... whose buffer the new tile takes
       }
     }
   }
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
     da.tail(dlds, rem);
     db.tail(dlds + D_A, rem);
     __syncthreads();
-    compute(dlds);
+    compute(dlds, -1);
   }
   gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g);
 }
