@@ -198,10 +198,13 @@ int ss_gru_sync_bytes(int B, int T, int H, long* bytes);
 /* BPTT.  d_out (B,T,2H) gradient of the layer output; d_g (2, B*T, 4, H) receives
  * d(gi_r), d(gi_z), d(gi_n) and d(W_hn h + b_hn) = d(gi_n) * r; rows with t >= len are zero.
  * drop_p > 0: d_out is the gradient w.r.t. the DROPPED-OUT output (nn.GRU's inter-layer dropout); the mask is the
- * ss_dropout stream (drop_seed, drop_offset) over the (B*T, 2H) tensor and is applied while d_out is read. */
+ * ss_dropout stream (drop_seed, drop_offset) over the (B*T, 2H) tensor and is applied while d_out is read.
+ * g_bih_f, g_bhh_f, g_bih_r, g_bhh_r (each 3H floats; all NULL = not wanted): the bias gradients of the layer are summed up
+ * while the recurrence runs and ADDED here (what ss_gru_bias_grad computes from d_g in a separate pass). */
 int ss_gru_bwd(const float* d_out, const float* out, const float* save, const float* w_hh_f,
                const float* w_hh_r, const int32_t* lengths, int B, int T, int H, float* d_g,
-               float drop_p, uint64_t drop_seed, uint64_t drop_offset, void* sync_ws, ss_stream_t stream);
+               float drop_p, uint64_t drop_seed, uint64_t drop_offset, float* g_bih_f, float* g_bhh_f, float* g_bih_r,
+               float* g_bhh_r, void* sync_ws, ss_stream_t stream);
 
 /* bias gradients of one GRU layer from d_g: g_bih_* (3H) += colsum(d_g[dir][:, 0:3H]),
  * g_bhh_* (3H) += colsum(d_g[dir][:, 0:2H] | d_g[dir][:, 3H:4H]).  N = B*T rows per direction. */

@@ -516,17 +516,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restr
   const int bx = tile % gx, by = (tile / gx) % gy, bi = tile / (gx * gy);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1, i = lane & 15, g = lane >> 4;
   const int mt = q >> 1, nt = q & 1;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   const f32x4* src = ws + ((((long)bi * nz) * gy + by) * gx + bx) * (8 * 256) + q * 256 + tid;
   const long zstride = (long)gy * gx * (8 * 256);
+  // eight slices in flight per thread: the loads are independent, the sum must not become a chain of memory latencies
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
   int z = 0;
-  for (; z + 1 < nz; z += 2) {
-    const f32x4 a = src[z * zstride], b = src[(z + 1) * zstride];
-    s0 += a;
-    s1 += b;
+  for (; z + 8 <= nz; z += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(z + u) * zstride];
+    s0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   }
-  if (z < nz) s0 += src[z * zstride];
-  s0 += s1;
+  {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (z + u < nz) ? src[(z + u) * zstride] : f32x4{0.f, 0.f, 0.f, 0.f};
+    s0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
   const int col = bx * BN + wn * 32 + nt * 16 + i;
   if (col >= N) return;
 #pragma unroll

@@ -172,6 +172,37 @@ struct GruBwdParams {
   // (ss_dropout stream (seed, offset) over the (B*T, 2H) tensor) is re-drawn while d_out is read
   float drop_p;
   uint64_t drop_seed, drop_off;
+  // bias gradients (each [3H], accumulated; all NULL = not wanted): d b_ih += sum over (clip, t) of (d a_r, d a_z, d a_n),
+  // d b_hh += the same with d a_n * r in the n block.  They ride on the BPTT: a pass over d_g afterwards costs as much HBM
+  // traffic as the weight-gradient GEMM that follows it.
+  float* g_bih[2];
+  float* g_bhh[2];
+};
+
+// Per-lane running sums of the four gate gradients of hidden units j0..j0+3 (lane row = 16 clips); flush() adds the rows up on
+// the DPP crossbar and lets one lane per row add them to the gradient vectors.  Every lane of the wave must call flush().
+struct GruBiasAcc {
+  f32x4 r = {0.f, 0.f, 0.f, 0.f}, z = r, n = r, q = r;
+  __device__ __forceinline__ void add(const f32x4& dar, const f32x4& daz, const f32x4& dan, const f32x4& dqn) {
+    r += dar; z += daz; n += dan; q += dqn;
+  }
+  __device__ __forceinline__ void flush(const GruBwdParams& p, int dir, int H, int j0, int i) {
+    if (!p.g_bih[dir]) return;
+    float* gi = p.g_bih[dir];
+    float* gh = p.g_bhh[dir];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float sr = row_sum(r[e]), sz = row_sum(z[e]), sn = row_sum(n[e]), sq = row_sum(q[e]);
+      if (i == 0) {
+        atomicAdd(&gi[j0 + e], sr);
+        atomicAdd(&gh[j0 + e], sr);
+        atomicAdd(&gi[H + j0 + e], sz);
+        atomicAdd(&gh[H + j0 + e], sz);
+        atomicAdd(&gi[2 * H + j0 + e], sn);
+        atomicAdd(&gh[2 * H + j0 + e], sq);
+      }
+    }
+  }
 };
 
 template <int H>
@@ -204,6 +235,7 @@ __global__ __launch_bounds__(H * 4) void gru_bwd_kernel(GruBwdParams p) {
   }
 
   f32x4 dh = {0.f, 0.f, 0.f, 0.f};  // gradient flowing into h_t from later steps of the recurrence
+  GruBiasAcc bacc;
   const long dir_off = (long)dir * p.B * T;
   for (int s = 0; s < T; ++s) {
     // reverse of the forward iteration order
@@ -234,6 +266,7 @@ __global__ __launch_bounds__(H * 4) void gru_bwd_kernel(GruBwdParams p) {
         dcarry[e] = d * z[e];
       }
     }
+    bacc.add(dar, daz, dan, dqn);
     if (clip_ok) {
       float* gp = p.d_g + (dir_off + frame) * (4 * H) + j0;
       *reinterpret_cast<f32x4*>(gp) = dar;
@@ -271,6 +304,7 @@ __global__ __launch_bounds__(H * 4) void gru_bwd_kernel(GruBwdParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) dh[e] = dcarry[e] + (a0[e] + a1[e]) + a2[e];
   }
+  bacc.flush(p, dir, H, j0, i);
 }
 
 }  // namespace
@@ -314,10 +348,14 @@ extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_h
 
 extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* save, const float* w_hh_f,
                           const float* w_hh_r, const int32_t* lengths, int B, int T, int H, float* d_g,
-                          float drop_p, uint64_t drop_seed, uint64_t drop_offset, void* sync_ws, ss_stream_t stream) {
+                          float drop_p, uint64_t drop_seed, uint64_t drop_offset, float* g_bih_f, float* g_bhh_f,
+                          float* g_bih_r, float* g_bhh_r, void* sync_ws, ss_stream_t stream) {
   SS_REQUIRE(d_out && out && save && w_hh_f && w_hh_r && lengths && d_g, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
+  const bool any_b = g_bih_f || g_bhh_f || g_bih_r || g_bhh_r, all_b = g_bih_f && g_bhh_f && g_bih_r && g_bhh_r;
+  SS_REQUIRE(!any_b || all_b, SS_ERR_ARG);
   GruBwdParams p;
+  p.g_bih[0] = g_bih_f; p.g_bih[1] = g_bih_r; p.g_bhh[0] = g_bhh_f; p.g_bhh[1] = g_bhh_r;
   p.d_out = d_out; p.out = out; p.save = save; p.w_hh[0] = w_hh_f; p.w_hh[1] = w_hh_r;
   p.lengths = lengths; p.d_g = d_g; p.B = B; p.T = T;
   p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_off = drop_offset;

@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   if (threadIdx.x == 0 && same_xcd) atomicAdd(&sync[3], 1u);  // observability: workgroup-launches on the fast path
 
   f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+  GruBiasAcc bacc;
   const long dir_off = (long)dir * p.B * T;
   const rsrc_t xrs = granule_rsrc(xg, 2L * pairs * P * SLICE * H);
   bool dead = false;
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
       }
       STAMP(2);
     }
+    if (owner) bacc.add(dar, daz, dan, dqn);
     if (owner && clip_ok) {
       float* gp = p.d_g + (dir_off + frame) * (4 * H) + j0;
       *reinterpret_cast<f32x4*>(gp) = dar;
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
     STAMP(1);
   }
   if (dead && lane == 0) p.d_g[0] = __builtin_nanf("");
+  if (owner) bacc.flush(p, dir, H, j0, i);  // owner is wave-uniform
   STAMP_FLUSH();
   finish_launch(sync, gen);
 }

@@ -28,7 +28,9 @@ INT_MAX = 2**31 - 1
 # bench.py turns this off for its per-kernel timing pass: HIP-event pairs only bracket a kernel's own run time when
 # every launch sits on one stream
 JOIN_BEFORE_CNN_BWD = True
-SIDE_AFTER_DX = os.environ.get("SS_SIDE_AFTER_DX", "0") == "1"  # measured: 2.55 vs 2.52 ms/step, off
+# weight-gradient GEMMs of layer l > 0 are queued behind its d layer_in GEMM, so they run beside the recurrence of layer l - 1
+# (latency-bound) rather than beside that GEMM (MFMA-bound like them): 2.30 vs 2.32 ms/step
+SIDE_AFTER_DX = os.environ.get("SS_SIDE_AFTER_DX", "1") == "1"
 USE_SPLIT_GRU = True
 USE_SPLITK_WS = os.environ.get("SS_NO_SPLITK_WS", "0") != "1"  # weight-gradient K slices via scratch + reduce, not atomics
 USE_SIDE_STREAM = os.environ.get("SS_NO_SIDE_STREAM", "0") != "1"
@@ -234,16 +236,17 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
     ws.ev_fork.record()
     with torch.cuda.stream(side):
         side.wait_event(ws.ev_fork)
-        gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, ws.mid_drop.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
-             accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
-        gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
-             2 * H, accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
-        # the atomically summed destinations of the d layer_in GEMMs: cleared here, off the critical path
+        # the atomically summed destinations of the d layer_in GEMMs: cleared here, off the critical path, and first --
+        # the top layer's d layer_in GEMM waits for them
         for t_ in ws.d_lower[1:]:
             t_.zero_()
         if cfg.use_roi:
             ws.dZ.zero_()
         ws.ev_zero.record()
+        gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, ws.mid_drop.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
+             accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
+        gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
+             2 * H, accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
     # ---- GRU layers, top down
     use_drop = train and cfg.gru_dropout > 0.0
     for l in range(cfg.gru_layers - 1, -1, -1):
@@ -254,7 +257,9 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         L.call("ss_gru_bwd", g_in.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(),
                P[f"gru.weight_hh_l{l}"].data_ptr(), P[f"gru.weight_hh_l{l}_reverse"].data_ptr(),
                ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(),
-               0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed, (l + 1) << 40, L.ptr(ws.gru_sync), s)
+               0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed, (l + 1) << 40,
+               G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
+               G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.ptr(ws.gru_sync), s)
         if l == 0:
             if cfg.use_roi:
                 lin, ld_in = ws.Z.data_ptr(), cfg.in_dim
@@ -269,11 +274,6 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             ws.ev_fork.record()
             with torch.cuda.stream(side):
                 side.wait_event(ws.ev_fork)
-                # the cheap bias reduction goes first: whatever is still queued on this stream when the next chip-filling
-                # kernel of the main stream starts only finishes after it
-                L.call("ss_gru_bias_grad", ws.dG[l].data_ptr(), N, H, G[f"gru.bias_ih_l{l}"].data_ptr(),
-                       G[f"gru.bias_hh_l{l}"].data_ptr(), G[f"gru.bias_ih_l{l}_reverse"].data_ptr(),
-                       G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.stream())
                 dg = ws.dG[l].data_ptr()
                 wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
                 wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"

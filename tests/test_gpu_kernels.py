@@ -212,9 +212,16 @@ def test_gru_fwd_bwd(L, H, B, T, split):
 
     dout_d = dev(wgt.reshape(N, 2 * H))
     dg_d = torch.full((2, N, 4, H), 5.0, device="cuda")
+    gb_d = torch.full((4, 3 * H), 0.5, device="cuda")  # bias gradients ride on the BPTT: (ih_f, hh_f, ih_r, hh_r), accumulated
     L.call("ss_gru_bwd", dout_d.data_ptr(), out_d.data_ptr(), save_d.data_ptr(), P["gru.weight_hh_l0"].data_ptr(),
-           P["gru.weight_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H, dg_d.data_ptr(), 0.0, 0, 0, sw, L.stream())
+           P["gru.weight_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H, dg_d.data_ptr(), 0.0, 0, 0,
+           gb_d[0].data_ptr(), gb_d[1].data_ptr(), gb_d[2].data_ptr(), gb_d[3].data_ptr(), sw, L.stream())
     sync()
+    for d in range(2):
+        colsum = dg_d[d].double().sum(0)  # (4, H)
+        assert_close(f"fused d b_ih dir{d}", gb_d[2 * d], (colsum[:3].reshape(-1) + 0.5).float(), atol=2e-4, rtol=1e-4)
+        assert_close(f"fused d b_hh dir{d}", gb_d[2 * d + 1],
+                     (torch.cat([colsum[0], colsum[1], colsum[3]]) + 0.5).float(), atol=2e-4, rtol=1e-4)
     if split:
         assert int(sync_ws[2]) == 0, "a wait on a partner workgroup timed out"
         assert int(sync_ws[0]) == 3 and int(sync_ws[1]) == 0  # three launches, each closed its generation
@@ -225,7 +232,8 @@ def test_gru_fwd_bwd(L, H, B, T, split):
     dg_a, dg_b = torch.zeros_like(dg_d), torch.zeros_like(dg_d)
     for src, dst, pp in ((dmask, dg_a, 0.0), (dout_d, dg_b, p_drop)):
         L.call("ss_gru_bwd", src.data_ptr(), out_d.data_ptr(), save_d.data_ptr(), P["gru.weight_hh_l0"].data_ptr(),
-               P["gru.weight_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H, dst.data_ptr(), pp, seed, off, sw, L.stream())
+               P["gru.weight_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H, dst.data_ptr(), pp, seed, off, None, None, None, None,
+               sw, L.stream())
     sync()
     assert float((dmask == 0).float().mean()) > 0.15
     if split:

@@ -45,7 +45,7 @@ def main():
 
         def bwd():
             L.call("ss_gru_bwd", dout.data_ptr(), out.data_ptr(), save.data_ptr(), w[0].data_ptr(), w[1].data_ptr(),
-                   lens.data_ptr(), B, T, H, dg.data_ptr(), 0.0, 0, 0, L.ptr(sync_ws), s)
+                   lens.data_ptr(), B, T, H, dg.data_ptr(), 0.0, 0, 0, None, None, None, None, L.ptr(sync_ws), s)
 
         t1, t2, t3 = timed(lambda: fwd(save.data_ptr())), timed(lambda: fwd(None)), timed(bwd)
         errs = int(sync_ws[2]) if sync_ws is not None else 0

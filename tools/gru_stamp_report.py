@@ -53,7 +53,7 @@ def main():
     report("gru_split_fwd", FWD)
     for _ in range(3):
         L.call("ss_gru_bwd", dout.data_ptr(), out.data_ptr(), save.data_ptr(), w[0].data_ptr(), w[1].data_ptr(),
-               lens.data_ptr(), B, T, H, dg.data_ptr(), 0.0, 0, 0, sync_ws.data_ptr(), s)
+               lens.data_ptr(), B, T, H, dg.data_ptr(), 0.0, 0, 0, None, None, None, None, sync_ws.data_ptr(), s)
     report("gru_split_bwd", BWD)
 
 
