@@ -76,7 +76,10 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=Fal
            b_map[0], b_map[1], b_map[2], Cm, ldc, bias, a_colsum, flags, splits, batch, *strides, L.stream(), tag=tag)
 
 
-def split_k(M, N, K, batch=1, target_wgs=768):
+_SPLITK_TARGET = int(os.environ.get("SS_SPLITK_TARGET", "768"))
+
+
+def split_k(M, N, K, batch=1, target_wgs=_SPLITK_TARGET):
     """K slices for a weight-gradient GEMM (tiny M x N, huge K): enough workgroups to fill the chip ~3x over."""
     tiles = -(-M // 128) * -(-N // 64) * batch
     return max(1, min(K // 128, target_wgs // tiles))
