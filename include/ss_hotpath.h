@@ -145,6 +145,14 @@ int ss_gemm_splitk_ws_floats(int M, int N, int K, int splits, int batch, long* f
 int ss_gemm_splitk_reduce(const float* ws, int M, int N, int K, int splits, int batch, float* C, int ldc, long stride_c,
                           ss_stream_t stream);
 
+/* What a training step does before its first real kernel, in one launch: grads[0:n_grads] = 0 (the flat gradient bucket of
+ * optimizer.zero_grad, train_model_official.py:433), scalars[0:n_scalars] = 0 and correct[0] = 0 (loss / sum of squares /
+ * hit counter; correct may be NULL), lengths32[b] = lengths64[b] (NULL: skipped), Z[r][0:cols] = X[r][0:cols] for `rows`
+ * rows (the landmark half of torch.cat((X, roi_emb)), train_model_official.py:297; X NULL: skipped). */
+int ss_train_prologue(float* grads, long n_grads, float* scalars, int n_scalars, int32_t* correct,
+                      const int64_t* lengths64, int32_t* lengths32, int B, const float* X, int ld_x, float* Z, int ld_z,
+                      int rows, int cols, ss_stream_t stream);
+
 /* column sums: out[n] += sum_r A[r*lda + n]  (bias gradients) */
 int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_stream_t stream);
 

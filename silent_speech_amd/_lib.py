@@ -37,6 +37,7 @@ SIGNATURES = {
     "ss_gemm_splitk_ws_floats": [_i, _i, _i, _i, _i, _vp],
     "ss_gemm_splitk_reduce": [_vp, _i, _i, _i, _i, _i, _vp, _i, _l, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
+    "ss_train_prologue": [_vp, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "ss_batch_gather_f32": [_vp, _i, _vp, _l, _vp, _vp, _f, _u64, _vp, _vp],
     "ss_batch_gather_u8": [_vp, _i, _vp, _l, _vp, _vp],
     "ss_crop_gray_resize": [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp],

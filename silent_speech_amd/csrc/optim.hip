@@ -59,6 +59,37 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
   }
 }
 
+// Everything a training step does before its first real kernel, in ONE launch (six tiny launches cost ~6 us each on the
+// step's critical path): clear the gradient bucket, clear the loss / sum-of-squares scalars and the hit counter, narrow the
+// int64 lengths to the int32 the kernels read, and copy the landmark features into their columns of the GRU input.
+struct ProloguePar {
+  float* grads; long n_grads;
+  float* scal; int n_scal;
+  int32_t* correct;
+  const int64_t* len64; int32_t* len32; int B;
+  const float* X; int ld_x; float* Z; int ld_z; int rows, cols;
+};
+__global__ __launch_bounds__(256) void train_prologue_kernel(ProloguePar a) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x, nthreads = (long)gridDim.x * 256;
+  f32x4* g4 = reinterpret_cast<f32x4*>(a.grads);
+  const long n4 = a.n_grads >> 2;
+  for (long q = tid; q < n4; q += nthreads) g4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long q = (n4 << 2) + tid; q < a.n_grads; q += nthreads) a.grads[q] = 0.f;
+  if (a.X) {
+    const long total = (long)a.rows * a.cols;
+    for (long q = tid; q < total; q += nthreads) {
+      const int r = (int)(q / a.cols), c = (int)(q - (long)r * a.cols);
+      a.Z[(long)r * a.ld_z + c] = a.X[(long)r * a.ld_x + c];
+    }
+  }
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < a.n_scal) a.scal[threadIdx.x] = 0.f;
+    if (threadIdx.x == 0 && a.correct) a.correct[0] = 0;
+    if (a.len64)
+      for (int b = threadIdx.x; b < a.B; b += 256) a.len32[b] = (int32_t)a.len64[b];
+  }
+}
+
 // grid (ceil(cols/64), row chunks); thread (c = tid&63, rr = tid>>6) strides rows by 4
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int rows, int cols, int lda,
                                                      int rows_per_block, float* __restrict__ out) {
@@ -154,6 +185,24 @@ extern "C" int ss_copy_rows_f32(const float* src, int ld_src, float* dst, int ld
   blocks = blocks > 2048 ? 2048 : blocks;
   hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld_src, dst,
                      ld_dst, rows, cols);
+  return ss_launch_status();
+}
+
+extern "C" int ss_train_prologue(float* grads, long n_grads, float* scalars, int n_scalars, int32_t* correct,
+                                 const int64_t* lengths64, int32_t* lengths32, int B, const float* X, int ld_x, float* Z,
+                                 int ld_z, int rows, int cols, ss_stream_t stream) {
+  SS_REQUIRE(grads && n_grads > 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0, SS_ERR_ARG);
+  SS_REQUIRE(n_scalars >= 0 && n_scalars <= 256 && (n_scalars == 0 || scalars), SS_ERR_ARG);
+  SS_REQUIRE(!lengths64 || (lengths32 && B > 0), SS_ERR_ARG);
+  SS_REQUIRE(!X || (Z && rows > 0 && cols > 0 && ld_x >= cols && ld_z >= cols), SS_ERR_ARG);
+  ProloguePar a;
+  a.grads = grads; a.n_grads = n_grads; a.scal = scalars; a.n_scal = n_scalars; a.correct = correct;
+  a.len64 = lengths64; a.len32 = lengths32; a.B = B;
+  a.X = X; a.ld_x = ld_x; a.Z = Z; a.ld_z = ld_z; a.rows = rows; a.cols = cols;
+  long work = (n_grads >> 2) > (X ? (long)rows * cols : 0) ? (n_grads >> 2) : (long)rows * cols;
+  int blocks = (int)((work + 255) / 256);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(train_prologue_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return ss_launch_status();
 }
 

@@ -160,7 +160,7 @@ class Workspace:
 
 
 def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Tensor, R: Optional[torch.Tensor], *,
-            train: bool, stash: bool = False, seed: int = 0, ce=None) -> torch.Tensor:
+            train: bool, stash: bool = False, seed: int = 0, ce=None, x_in_place: bool = False) -> torch.Tensor:
     """Runs the forward kernels; returns ws.logits (B,C).  ``ws.lengths`` must already hold the int32 lengths.
     ``train`` turns the two dropouts on (p from cfg); ``stash`` keeps what ``backward`` needs (needs a
     Workspace built with train=True).  ``ce = (y_ptr, label_smoothing, denom, loss_ptr, correct_ptr)`` makes the
@@ -173,7 +173,8 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
     if cfg.use_roi:
         Hh, Ww = ws.roi_hw
         ws_Z = ws.Z
-        L.call("ss_copy_rows_f32", X.data_ptr(), cfg.x_dim, ws_Z.data_ptr(), cfg.in_dim, N, cfg.x_dim, s)
+        if not x_in_place:  # (the trainer's prologue kernel has already put X there)
+            L.call("ss_copy_rows_f32", X.data_ptr(), cfg.x_dim, ws_Z.data_ptr(), cfg.in_dim, N, cfg.x_dim, s)
         cw = [P[k].data_ptr() for k in ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight",
                                         "roi_cnn.net.3.bias", "roi_cnn.net.6.weight", "roi_cnn.net.6.bias",
                                         "roi_cnn.fc.weight", "roi_cnn.fc.bias")]

@@ -80,14 +80,25 @@ class Trainer:
         model, cfg = self.model, self.model.cfg
         B = X.shape[0]
         self.step_count += 1
-        model.flat_grads.zero_()
-        self.scal.zero_()
-        self.correct.zero_()
         train = self.dropout and model.training
         denom = float(B * self.world)
         M = self.micro_batches if (self.micro_batches > 1 and B % self.micro_batches == 0 and B // self.micro_batches >= 16) else 1
+        fused_prologue = (M == 1 and lengths.dtype == torch.int64 and lengths.is_cuda and lengths.is_contiguous()
+                          and X.is_contiguous())
+        if fused_prologue:
+            # zero_grad, the scalars, the int32 lengths and the landmark half of the GRU input: one launch instead of six
+            ws = model._workspace(X, R, train=True, slot=0)
+            T = X.shape[1]
+            L.call("ss_train_prologue", model.flat_grads.data_ptr(), model.flat_grads.numel(), self.scal.data_ptr(), 2,
+                   self.correct.data_ptr(), lengths.data_ptr(), ws.lengths.data_ptr(), B,
+                   X.data_ptr() if cfg.use_roi else None, cfg.x_dim, L.ptr(ws.Z), cfg.in_dim, B * T, cfg.x_dim, L.stream())
+        else:
+            model.flat_grads.zero_()
+            self.scal.zero_()
+            self.correct.zero_()
         if M == 1:
-            self._fwd_bwd(X, lengths, R, y, denom, train, seed=self.step_count, slot=0, phase="both")
+            self._fwd_bwd(X, lengths, R, y, denom, train, seed=self.step_count, slot=0, phase="both",
+                          prologue_done=fused_prologue)
         else:
             n = B // M
             cur = torch.cuda.current_stream()
@@ -123,14 +134,15 @@ class Trainer:
                self.betas[1], self.eps, self.step_count, s)
         return self.scal[0], self.correct[0]
 
-    def _fwd_bwd(self, X, lengths, R, y, denom, train, seed, slot, phase):
+    def _fwd_bwd(self, X, lengths, R, y, denom, train, seed, slot, phase, prologue_done=False):
         """Forward + CE ("fwd"), backward ("bwd") or both of one micro-batch on the current stream."""
         model, cfg = self.model, self.model.cfg
         ws = model._workspace(X, R, train=True, slot=slot)
         P = model._param_dict()
         if phase in ("fwd", "both"):
-            ws.lengths.copy_(lengths.to(torch.int32), non_blocking=True)
-            E.forward(P, cfg, ws, X, R, train=train, stash=True, seed=seed,
+            if not prologue_done:
+                ws.lengths.copy_(lengths.to(torch.int32), non_blocking=True)
+            E.forward(P, cfg, ws, X, R, train=train, stash=True, seed=seed, x_in_place=prologue_done,
                       ce=(y.data_ptr(), self.ls, denom, self.scal.data_ptr(), self.correct.data_ptr()))
         if phase in ("bwd", "both"):
             E.backward(P, self.G, cfg, ws, X, R, ws.d_logits, train=train, seed=seed)
