@@ -113,6 +113,7 @@ class Workspace:
         self.ev_fork = torch.cuda.Event() if train else None
         self.ev_join = torch.cuda.Event() if train else None
         self.ev_cnn_fwd = torch.cuda.Event() if train else None  # recorded after the ROI-CNN forward (micro-batch stagger)
+        self.stagger = False  # set by the trainer when another micro-batch waits for ev_cnn_fwd
         self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
         self.gi = [torch.empty(2, N, 3 * H, **f32) for _ in range(cfg.gru_layers)]
         self.out = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers)]
@@ -182,7 +183,7 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
                ws.st_m3.data_ptr(), ws.st_feat.data_ptr()] if stash else [None] * 6)
         L.call("ss_roi_cnn_fwd_stash", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
                _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, s)
-        if ws.train:
+        if ws.train and ws.stagger:  # an event record is a barrier packet on this stream (~6 us): only when somebody waits for it
             ws.ev_cnn_fwd.record()
         layer_in, ld_in = ws_Z.data_ptr(), cfg.in_dim
     else:
@@ -253,6 +254,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
              2 * H, accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
     # ---- GRU layers, top down
     use_drop = train and cfg.gru_dropout > 0.0
+    zero_waited = False
     for l in range(cfg.gru_layers - 1, -1, -1):
         K = cfg.in_dim if l == 0 else 2 * H
         # layers below the top read the gradient w.r.t. their DROPPED-OUT output; the kernel re-draws the mask
@@ -318,7 +320,9 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             else:
                 dst, ld_dst = d_X.data_ptr(), cfg.x_dim
                 d_X.zero_()
-            torch.cuda.current_stream().wait_event(ws.ev_zero)
+            if not zero_waited:  # once per backward pass: every cleared buffer is behind the same event
+                torch.cuda.current_stream().wait_event(ws.ev_zero)
+                zero_waited = True
             wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
             # nobody asked for d X: only the ROI-embedding columns of d Z feed the CNN backward
             c0 = cfg.x_dim if (l == 0 and cfg.use_roi and d_X is None) else 0
@@ -328,6 +332,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         if SIDE_AFTER_DX and l > 0:
             side_work()
     # ---- ROI CNN
+    side_joined = False  # nothing is queued on the side stream after the join in front of the CNN backward
     if cfg.use_roi:
         Hh, Ww = ws.roi_hw
         if d_X is not None:
@@ -338,6 +343,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             # they run beside the d layer_in GEMM above and cost the critical path a few tens of microseconds
             ws.ev_join.record(ws.side)
             torch.cuda.current_stream().wait_event(ws.ev_join)
+            side_joined = True
         names = ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight", "roi_cnn.net.3.bias",
                  "roi_cnn.net.6.weight", "roi_cnn.net.6.bias", "roi_cnn.fc.weight", "roi_cnn.fc.bias")
         L.call("ss_roi_cnn_bwd", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
@@ -345,6 +351,6 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
                *[G[k].data_ptr() for k in names], s)
     # join the side stream: the caller's next kernels (all-reduce, clip, Adam) read every gradient
-    if USE_SIDE_STREAM:
+    if USE_SIDE_STREAM and not side_joined:
         ws.ev_join.record(ws.side)
         torch.cuda.current_stream().wait_event(ws.ev_join)

@@ -112,6 +112,7 @@ class Trainer:
                     with torch.cuda.stream(self.streams[m]):
                         if phase == "fwd":
                             self.streams[m].wait_event(self.ev_start)
+                            model._workspace(Xm, Rm, train=True, slot=m + 1).stagger = True  # the next slice waits for its CNN
                             if m > 0 and cfg.use_roi:
                                 # stagger: slice m starts its ROI-CNN when slice m-1 has left it for the recurrence, so the
                                 # chip-filling kernels of one slice run beside the 16-CU recurrence of the other
