@@ -51,7 +51,7 @@ struct GemmParams {
 // Shared epilogue: acc[mt][nt] of the wave's 64x32 sub-tile -> C (plain / accumulate / ReLU / float atomics) or, with
 // flags bit3, into the split-K workspace as the accumulators lie in the registers.
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][2], int m0, int n0, int zs, int wm, int wn,
-                                              int i, int g) {
+                                              int i, int g, float* stage /* BM x (BN + 4) floats of LDS, or NULL */) {
   if (p.flags & 8) {
     // plain 16-byte stores of the raw accumulators instead of 32 float atomics per lane
     f32x4* w = reinterpret_cast<f32x4*>(p.C) +
@@ -83,6 +83,39 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
     }
   };
+  // Plain stores of a tile whose 64 columns are all there: through LDS, so that a row leaves as one 256-byte run (16 lanes x
+  // 16 bytes) instead of 64-byte pieces from the MFMA layout -- the input projections write 70 MB per launch and were bound
+  // by exactly that.
+  if (stage && !atomic && n0 + BN <= p.N && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {
+    constexpr int LDS_C = BN + 4;
+    __syncthreads();  // the last k tile has been read by everybody
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = wn * 32 + nt * 16 + i;
+        const float bv = (p.bias && zs == 0) ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(wm * 64 + mt * 16 + 4 * g + r) * LDS_C + col] = acc[mt][nt][r] + bv;
+      }
+    __syncthreads();
+    const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int it = 0; it < BM / 16; ++it) {
+      const int row = r0 + 16 * it;
+      if (m0 + row < p.M) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * LDS_C + c4]);
+        f32x4* dst = reinterpret_cast<f32x4*>(p.C + (long)(m0 + row) * p.ldc + n0 + c4);
+        if (accumulate) v += *dst;
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *dst = v;
+      }
+    }
+    return;
+  }
   if (p.nz > 1) {
     // split-K slices of one tile reach their epilogues together: each starts at a different row group so that their
     // atomics meet on different lines (wave-uniform rotation; costs a register-indexed read of the accumulators)
@@ -285,7 +318,7 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
     if (want_asum && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) atomicAdd(&p.asum[m0 + threadIdx.x], asum);
   }
 
-  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g);
+  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g, nullptr);
   STAMP_WAIT(4);
 #ifdef SS_STAMP
   {  // the first 256 workgroups in dispatch order report
@@ -505,7 +538,8 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
     __syncthreads();
     compute(dlds, -1);
   }
-  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g);
+  static_assert(BM * (BN + 4) <= DSTAGES * D_STAGE, "the output tile is staged in the k-tile ring");
+  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g, dlds);
 }
 
 // C[bi][row][col] += sum over the nz slices of the accumulators the GEMM workgroups left in `ws` (flags bit3).
