@@ -123,6 +123,8 @@ int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const
  * flags bit0: accumulate into C; bit1: ReLU epilogue; bit2: accumulate with float atomics even when K is not
  * split (several streams add into one C).  splits > 1 slices K over blockIdx.z and adds with float atomics
  * (atomics require bit0, C pre-initialised, no ReLU).
+ * flags bit4 (ss_gemm_f32_batched only): the `batch` problems are SUMMED into one C (stride_c ignored) -- the K loop of a
+ * workgroup runs through all (A, B) pairs, so e.g. d layer_in = dG_fwd W_fwd + dG_rev W_rev needs neither atomics nor a cleared C.
  * flags bit3 (alone; no bias): C is a split-K workspace of ss_gemm_splitk_ws_floats() floats (16-byte aligned) instead of
  * the result: every workgroup leaves its raw accumulators there with plain stores and ss_gemm_splitk_reduce adds the
  * slices into the real C afterwards -- the weight-gradient GEMMs (M x N tiny, K = B*T) spend as long in float atomics

@@ -43,6 +43,8 @@ struct GemmParams {
   int ksplit;  // K elements per blockIdx.z slice (multiple of BK)
   int nz;      // K slices per problem; blockIdx.z = batch * nz + slice
   long sA, sB, sC, sBias, sAsum;  // element strides between the problems of a batch
+  int kcat;    // >1 (flags bit4): that many (A, B) pairs, strides sA / sB apart, are multiplied into ONE C -- the K loop runs
+               // through them one after the other (d layer_in = dG_f W_f + dG_r W_r without atomics or a cleared C)
   int flags;   // bit0: accumulate into C (plain RMW when nz==1, atomics otherwise); bit1: ReLU; bit2: always atomic;
                // bit3: C is a split-K workspace -- every workgroup leaves its accumulators there as they lie in its
                // registers (16 bytes per lane, fully coalesced) and splitk_reduce_kernel folds the slices into the real C
@@ -439,7 +441,7 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float dlds[];  // DSTAGES x (A image, B image), at LDS address 0
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int bi = blockIdx.z / p.nz, zs = blockIdx.z - bi * p.nz;
+  const int bi = blockIdx.z / p.nz, zs = blockIdx.z - bi * p.nz;  // (kcat > 1: the launch has one problem, bi == 0)
   p.A += bi * p.sA; p.B += bi * p.sB;
   if (!(p.flags & 8)) p.C += bi * p.sC;
   if (p.bias) p.bias += bi * p.sBias;
@@ -452,8 +454,6 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
 
   DmaOperand<BM, A_KC> da;
   DmaOperand<BN, B_KC> db;
-  da.init(p.A, p.lda, p.ra, m0, p.M, kbeg);
-  db.init(p.B, p.ldb, p.rb, n0, p.N, kbeg);
   constexpr int LPW = DmaOperand<BM, A_KC>::NL + DmaOperand<BN, B_KC>::NL;  // DMA instructions per wave and k tile
 
   // this lane's operand read offsets inside a stage (floats); the rest of every address is an immediate
@@ -515,6 +515,10 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
     }
   };
 
+  for (int kc = 0; kc < p.kcat; ++kc) {
+  if (kc) ss_raw_barrier();  // the ring is about to be refilled: everybody is done with the previous pair's last tiles
+  da.init(p.A + kc * p.sA, p.lda, p.ra, m0, p.M, kbeg);
+  db.init(p.B + kc * p.sB, p.ldb, p.rb, n0, p.N, kbeg);
 #pragma unroll
   for (int s_ = 0; s_ < DSTAGES - 1; ++s_)
     if (s_ < nfull) issue(s_);
@@ -538,6 +542,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
     __syncthreads();
     compute(dlds, -1);
   }
+  }  // kcat
   static_assert(BM * (BN + 4) <= DSTAGES * D_STAGE, "the output tile is staged in the k-tile ring");
   gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g, dlds);
 }
@@ -625,7 +630,8 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
   p.rb = RowMap{b_group, b_gstride, b_off};
   p.nz = splitk_slices(K, splits, &p.ksplit);
   p.sA = stride_a; p.sB = stride_b; p.sC = stride_c; p.sBias = stride_bias; p.sAsum = stride_colsum;
-  p.flags = flags;
+  p.flags = flags & 15;
+  p.kcat = 1;
   dim3 grid(ceil_div(N, BN), ceil_div(M, BM), p.nz * batch), block(256);
   SS_REQUIRE(grid.z <= 65535, SS_ERR_UNSUPPORTED);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -635,6 +641,21 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
   const bool dma_ok = !a_colsum && al16(A) && al16(B) && (lda & 3) == 0 && (ldb & 3) == 0 && (stride_a & 3) == 0 &&
                       (stride_b & 3) == 0 && (a_kcontig || (M >= 4 && (M & 3) == 0)) && (b_kcontig || (N >= 4 && (N & 3) == 0)) &&
                       p.ksplit >= 4 * BK && !ss_gemm_no_dma;
+  if (flags & 16) {
+    // the batch is summed into one C
+    SS_REQUIRE(!(flags & 8) && !a_colsum, SS_ERR_ARG);
+    if (!dma_ok) {  // register-staged kernel: one launch per pair, the later ones accumulate (stream order)
+      for (int b = 0; b < batch; ++b) {
+        const int st = ss_gemm_f32_batched(a_kcontig, b_kcontig, M, N, K, A + b * stride_a, lda, a_group, a_gstride, a_off,
+                                           B + b * stride_b, ldb, b_group, b_gstride, b_off, C, ldc, b ? nullptr : bias, nullptr,
+                                           (flags & 15) | (b ? 1 : 0), splits, 1, 0, 0, 0, 0, 0, stream);
+        if (st != SS_OK) return st;
+      }
+      return SS_OK;
+    }
+    p.kcat = batch;
+    grid.z = p.nz;
+  }
   if (dma_ok) {
     constexpr size_t lds_bytes = (size_t)DSTAGES * D_STAGE * sizeof(float);
     if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, block, lds_bytes, s, p);

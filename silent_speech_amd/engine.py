@@ -57,7 +57,7 @@ class Config:
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, relu=False, splits=1,
          a_map=(INT_MAX, 0, 0), b_map=(INT_MAX, 0, 0), a_colsum=None, tag="gemm", batch=1, strides=(0, 0, 0, 0, 0),
-         atomic=False, splitk_ws: Optional[torch.Tensor] = None):
+         atomic=False, splitk_ws: Optional[torch.Tensor] = None, sum_batch=False):
     """C[M,N] (+)= opA * opB (+bias)(ReLU); A/B/Cm are ints (device addresses).  ``batch`` problems of one shape
     share a launch; ``strides`` = element strides of (A, B, C, bias, a_colsum) between them.  With ``splitk_ws`` (a float
     scratch tensor) the K slices are left there and folded into C by a second, tiny launch instead of float atomics."""
@@ -71,7 +71,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=Fal
         L.call("ss_gemm_splitk_reduce", splitk_ws.data_ptr(), M, N, K, splits, batch, Cm, ldc, strides[2], L.stream(),
                tag=tag + "_reduce")
         return
-    flags = (1 if accumulate else 0) | (2 if relu else 0) | (4 if atomic else 0)
+    flags = (1 if accumulate else 0) | (2 if relu else 0) | (4 if atomic else 0) | (16 if sum_batch else 0)
     L.call("ss_gemm_f32_batched", int(a_kc), int(b_kc), M, N, K, A, lda, a_map[0], a_map[1], a_map[2], B, ldb,
            b_map[0], b_map[1], b_map[2], Cm, ldc, bias, a_colsum, flags, splits, batch, *strides, L.stream(), tag=tag)
 
@@ -312,7 +312,9 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
         if need_dx:
             # both directions in ONE launch (twice the workgroups: the N=116 case alone leaves half the CUs idle),
-            # summed with float atomics into a destination that was zeroed on the side stream
+            # summed with float atomics into a destination that was zeroed on the side stream.  (Measured alternative:
+            # sum_batch=True -- one workgroup per tile running its K loop through both directions, plain stores, nothing
+            # to clear -- is 0.8 % slower on the step: half the workgroups, and layer 0 has only 60 tiles.)
             if l > 0:
                 dst, ld_dst = ws.d_lower[l].data_ptr(), 2 * H
             elif cfg.use_roi:

@@ -136,6 +136,25 @@ def test_gemm_splitk_workspace(L, M, N, K, splits, batch):
     assert torch.isnan(ws[need:]).all(), "wrote past the advertised workspace size"
 
 
+@pytest.mark.parametrize("M,N,K,ldb_extra", [(7680, 384, 576, 0), (300, 32, 200, 84), (130, 70, 50, 3)])
+def test_gemm_summed_batch(L, M, N, K, ldb_extra):
+    """flags bit4: C = bias + A0 B0 + A1 B1 in one launch (the d layer_in GEMM of both GRU directions); the last case is
+    unaligned and takes the one-launch-per-pair fallback."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(2, M, K, generator=g)                 # [row][k]
+    Bm = torch.randn(2, K, N + ldb_extra, generator=g)    # [k][n], only the last N columns are used
+    bias = torch.randn(N, generator=g)
+    ref = (torch.einsum("bmk,bkn->mn", A.double(), Bm[:, :, ldb_extra:].double()) + bias.double()).float()
+    a_d, b_d, bias_d = dev(A), dev(Bm), dev(bias)
+    c_d = torch.full((M, N + 5), 7.0, device="cuda")
+    L.call("ss_gemm_f32_batched", 1, 0, M, N, K, a_d.data_ptr(), K, INT_MAX, 0, 0, b_d.data_ptr() + 4 * ldb_extra,
+           N + ldb_extra, INT_MAX, 0, 0, c_d.data_ptr(), N + 5, bias_d.data_ptr(), None, 16, 1, 2, M * K, K * (N + ldb_extra), 0,
+           0, 0, L.stream())
+    sync()
+    assert_close("summed batch", c_d[:, :N], ref, atol=2e-5 * (2 * K) ** 0.5, rtol=1e-5)
+    assert torch.all(c_d[:, N:] == 7.0)
+
+
 # ------------------------------------------------------------------------------------- GRU
 def _gru_case(H, In, B, T, seed, lengths=None):
     g = torch.Generator().manual_seed(seed)
