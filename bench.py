@@ -44,6 +44,19 @@ def algorithmic_gflop(tag, B, T, D, E, H, C, roi):
     }.get(tag)
 
 
+def step_gflop_per_clip(T, D, E, H, C, roi, mid=128):
+    """Algorithmic FLOPs (2 per MAC) of one clip's forward + backward, SURVEY.md section 8(d): backward = 2 x forward minus the
+    input gradient of conv1.  0.591 GFLOP at config 2."""
+    Hh, Ww = roi
+    px1, px2, px3 = Hh * Ww, (Hh // 2) * (Ww // 2), (Hh // 4) * (Ww // 4)
+    conv1 = px1 * 8 * 9
+    cnn = conv1 + px2 * 16 * 72 + px3 * 24 * 144 + 24 * E
+    gru = 2 * (3 * H * (D + E) + 3 * H * H) + 2 * (3 * H * 2 * H + 3 * H * H)  # both directions, two layers, per frame
+    head = 2 * H * mid + mid * C
+    fwd = T * (cnn + gru) + head
+    return 2.0 * (3 * fwd - T * conv1) / 1e9
+
+
 def pmc_traffic(kernel_tag):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (profiles/round1_e_pmc_traffic.json,
     made by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
@@ -346,6 +359,12 @@ def main():
     }
     if roof:
         out["roofline"] = roof
+    # whole-step figure of SURVEY.md 8(d): clips/s x algorithmic GFLOP per clip against the dense f32-MFMA peak of the GPUs used
+    gpc = step_gflop_per_clip(T, D, E, H, C, (roi, roi))
+    tf = out["value"] * gpc / 1e3
+    out["step_roofline"] = {"bound": "mfma", "gflop_per_clip": round(gpc, 4), "achieved": round(tf, 2),
+                            "peak": round(F32_MFMA_PEAK_TFLOPS * world, 1), "unit": "TFLOP/s",
+                            "frac": round(tf / (F32_MFMA_PEAK_TFLOPS * world), 4)}
     if kernels:
         out["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
