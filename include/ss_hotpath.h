@@ -155,6 +155,23 @@ int ss_train_prologue(float* grads, long n_grads, float* scalars, int n_scalars,
                       const int64_t* lengths64, int32_t* lengths32, int B, const float* X, int ld_x, float* Z, int ld_z,
                       int rows, int cols, ss_stream_t stream);
 
+/* Several split-K problems C_j (ldc_j, stride_c_j between the batch members) += op(A_j) op(B_j) in ONE GEMM launch plus ONE
+ * reduce launch (the three weight-gradient GEMMs of a GRU layer; every launch boundary on a stream costs the tail of one
+ * kernel and the ramp of the next).  Fields as the arguments of ss_gemm_f32_batched; n <= 4; all problems of one operand
+ * layout.  ws: ss_gemm_splitk_group_ws_floats() floats, 16-byte aligned, contents irrelevant. */
+typedef struct ss_gemm_problem {
+  int a_kcontig, b_kcontig, M, N, K;
+  const float* A;
+  int lda, a_group, a_gstride, a_off;
+  const float* B;
+  int ldb, b_group, b_gstride, b_off;
+  float* C;
+  int ldc, splits, batch;
+  long stride_a, stride_b, stride_c;
+} ss_gemm_problem;
+int ss_gemm_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats);
+int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream);
+
 /* column sums: out[n] += sum_r A[r*lda + n]  (bias gradients) */
 int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_stream_t stream);
 

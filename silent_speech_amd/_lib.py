@@ -36,6 +36,8 @@ SIGNATURES = {
                             _l, _l, _l, _l, _l, _vp],
     "ss_gemm_splitk_ws_floats": [_i, _i, _i, _i, _i, _vp],
     "ss_gemm_splitk_reduce": [_vp, _i, _i, _i, _i, _i, _vp, _i, _l, _vp],
+    "ss_gemm_splitk_group_ws_floats": [_vp, _i, _vp],
+    "ss_gemm_f32_splitk_group": [_vp, _i, _vp, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
     "ss_train_prologue": [_vp, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "ss_batch_gather_f32": [_vp, _i, _vp, _l, _vp, _vp, _f, _u64, _vp, _vp],
@@ -99,6 +101,30 @@ def gru_sync_bytes(B: int, T: int, H: int) -> int:
     if st != 0:
         raise RuntimeError(f"ss_gru_sync_bytes({B}, {T}, {H}) -> {st}")
     return n.value
+
+
+class GemmProblem(C.Structure):
+    """ss_gemm_problem of include/ss_hotpath.h."""
+    _fields_ = [("a_kcontig", C.c_int), ("b_kcontig", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("a_group", C.c_int), ("a_gstride", C.c_int), ("a_off", C.c_int),
+                ("B", C.c_void_p), ("ldb", C.c_int), ("b_group", C.c_int), ("b_gstride", C.c_int), ("b_off", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int), ("splits", C.c_int), ("batch", C.c_int),
+                ("stride_a", C.c_long), ("stride_b", C.c_long), ("stride_c", C.c_long)]
+
+
+def gemm_group(problems):
+    """-> (ctypes array, n) for ss_gemm_f32_splitk_group / ss_gemm_splitk_group_ws_floats."""
+    arr = (GemmProblem * len(problems))(*problems)
+    return arr, len(problems)
+
+
+def gemm_group_ws_floats(problems) -> int:
+    arr, n = gemm_group(problems)
+    out = C.c_long(0)
+    st = load().ss_gemm_splitk_group_ws_floats(arr, n, C.byref(out))
+    if st != 0:
+        raise RuntimeError(f"ss_gemm_splitk_group_ws_floats -> {st}")
+    return out.value
 
 
 def gemm_splitk_ws_floats(M: int, N: int, K: int, splits: int, batch: int) -> int:

@@ -50,14 +50,17 @@ struct GemmParams {
                // registers (16 bytes per lane, fully coalesced) and splitk_reduce_kernel folds the slices into the real C
 };
 
+// Which tile of which launch grid a workgroup works on: blockIdx / gridDim for a plain launch, looked up for a grouped one.
+struct TileId { int bx, by, bz, gx, gy; };
+
 // Shared epilogue: acc[mt][nt] of the wave's 64x32 sub-tile -> C (plain / accumulate / ReLU / float atomics) or, with
 // flags bit3, into the split-K workspace as the accumulators lie in the registers.
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][2], int m0, int n0, int zs, int wm, int wn,
-                                              int i, int g, float* stage /* BM x (BN + 4) floats of LDS, or NULL */) {
+                                              int i, int g, float* stage /* BM x (BN + 4) floats of LDS, or NULL */,
+                                              const TileId& id) {
   if (p.flags & 8) {
     // plain 16-byte stores of the raw accumulators instead of 32 float atomics per lane
-    f32x4* w = reinterpret_cast<f32x4*>(p.C) +
-               (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (8 * 256) + threadIdx.x;
+    f32x4* w = reinterpret_cast<f32x4*>(p.C) + (((long)id.bz * id.gy + id.by) * id.gx + id.bx) * (8 * 256) + threadIdx.x;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -320,7 +323,8 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
     if (want_asum && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) atomicAdd(&p.asum[m0 + threadIdx.x], asum);
   }
 
-  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g, nullptr);
+  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g, nullptr,
+                TileId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y});
   STAMP_WAIT(4);
 #ifdef SS_STAMP
   {  // the first 256 workgroups in dispatch order report
@@ -438,10 +442,9 @@ __device__ __forceinline__ void ss_raw_barrier() {
 }
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) float dlds[];  // DSTAGES x (A image, B image), at LDS address 0
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int bi = blockIdx.z / p.nz, zs = blockIdx.z - bi * p.nz;  // (kcat > 1: the launch has one problem, bi == 0)
+__device__ __forceinline__ void gemm_dma_body(GemmParams p, const TileId id, float* dlds /* the ring, at LDS address 0 */) {
+  const int m0 = id.by * BM, n0 = id.bx * BN;
+  const int bi = id.bz / p.nz, zs = id.bz - bi * p.nz;  // (kcat > 1: the launch has one problem, bi == 0)
   p.A += bi * p.sA; p.B += bi * p.sB;
   if (!(p.flags & 8)) p.C += bi * p.sC;
   if (p.bias) p.bias += bi * p.sBias;
@@ -544,23 +547,56 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
   }
   }  // kcat
   static_assert(BM * (BN + 4) <= DSTAGES * D_STAGE, "the output tile is staged in the k-tile ring");
-  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g, dlds);
+  gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g, dlds, id);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 3) void gemm_dma_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dlds[];  // DSTAGES x (A image, B image), at LDS address 0
+  gemm_dma_body<A_KC, B_KC>(p, TileId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, dlds);
+}
+
+// Several split-K problems of one operand layout in ONE launch (the three weight-gradient GEMMs of a GRU layer): every launch
+// boundary on a stream costs the tail of one kernel and the ramp of the next, and these are 30 us kernels.
+constexpr int GEMM_GROUP_MAX = 4;
+struct GemmGroup {
+  GemmParams p[GEMM_GROUP_MAX];
+  int first[GEMM_GROUP_MAX + 1];  // workgroups [first[j], first[j+1]) belong to problem j
+  int gx[GEMM_GROUP_MAX], gy[GEMM_GROUP_MAX];
+  int n;
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 3) void gemm_dma_group_kernel(GemmGroup gg) {
+  extern __shared__ __attribute__((aligned(16))) float dlds[];
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+    if (q < gg.n && (int)blockIdx.x >= gg.first[q]) j = q;
+  const int local = blockIdx.x - gg.first[j], gx = gg.gx[j], gy = gg.gy[j];
+  const int bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);
+  gemm_dma_body<A_KC, B_KC>(gg.p[j], TileId{bx, by, bz, gx, gy}, dlds);
 }
 
 // C[bi][row][col] += sum over the nz slices of the accumulators the GEMM workgroups left in `ws` (flags bit3).
 // One thread owns one accumulator quad (mt, nt, lane) of one output tile: nz coalesced 16-byte reads, four read-modify-writes.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restrict__ ws, int nz, int gx, int gy, int M, int N,
-                                                            float* __restrict__ C, int ldc, long sC) {
-  const int q = blockIdx.x & 7, tile = blockIdx.x >> 3;
-  const int bx = tile % gx, by = (tile / gx) % gy, bi = tile / (gx * gy);
+struct ReduceItem { const f32x4* ws; int nz, gx, gy, M, N; float* C; int ldc; long sC; };
+struct ReduceGroup {
+  ReduceItem it[GEMM_GROUP_MAX];
+  int first[GEMM_GROUP_MAX + 1];
+  int n;
+};
+__device__ __forceinline__ void splitk_reduce_body(const ReduceItem& r, int block) {
+  const int q = block & 7, tile = block >> 3;
+  const int bx = tile % r.gx, by = (tile / r.gx) % r.gy, bi = tile / (r.gx * r.gy);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1, i = lane & 15, g = lane >> 4;
   const int mt = q >> 1, nt = q & 1;
-  const f32x4* src = ws + ((((long)bi * nz) * gy + by) * gx + bx) * (8 * 256) + q * 256 + tid;
-  const long zstride = (long)gy * gx * (8 * 256);
+  const f32x4* src = r.ws + ((((long)bi * r.nz) * r.gy + by) * r.gx + bx) * (8 * 256) + q * 256 + tid;
+  const long zstride = (long)r.gy * r.gx * (8 * 256);
   // eight slices in flight per thread: the loads are independent, the sum must not become a chain of memory latencies
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
   int z = 0;
-  for (; z + 8 <= nz; z += 8) {
+  for (; z + 8 <= r.nz; z += 8) {
     f32x4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = src[(z + u) * zstride];
@@ -569,16 +605,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restr
   {
     f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (z + u < nz) ? src[(z + u) * zstride] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 8; ++u) v[u] = (z + u < r.nz) ? src[(z + u) * zstride] : f32x4{0.f, 0.f, 0.f, 0.f};
     s0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   }
   const int col = bx * BN + wn * 32 + nt * 16 + i;
-  if (col >= N) return;
+  if (col >= r.N) return;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = by * BM + wm * 64 + mt * 16 + 4 * g + r;
-    if (row < M) C[bi * sC + (long)row * ldc + col] += s0[r];
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = by * BM + wm * 64 + mt * 16 + 4 * g + rr;
+    if (row < r.M) r.C[bi * r.sC + (long)row * r.ldc + col] += s0[rr];
   }
+}
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ReduceItem r) { splitk_reduce_body(r, blockIdx.x); }
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup rg) {
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+    if (q < rg.n && (int)blockIdx.x >= rg.first[q]) j = q;
+  splitk_reduce_body(rg.it[j], blockIdx.x - rg.first[j]);
 }
 
 int splitk_slices(int K, int splits, int* per_out) {
@@ -603,18 +647,23 @@ extern "C" int ss_gemm_splitk_reduce(const float* ws, int M, int N, int K, int s
   SS_REQUIRE(ws && C && M > 0 && N > 0 && K > 0 && splits >= 1 && batch >= 1 && ldc >= N, SS_ERR_ARG);
   SS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, SS_ERR_ARG);
   const int nz = splitk_slices(K, splits, nullptr), gx = ceil_div(N, BN), gy = ceil_div(M, BM);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(batch * gx * gy * 8)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), reinterpret_cast<const f32x4*>(ws), nz, gx, gy, M, N, C, ldc, stride_c);
+  const ReduceItem r{reinterpret_cast<const f32x4*>(ws), nz, gx, gy, M, N, C, ldc, stride_c};
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(batch * gx * gy * 8)), dim3(256), 0, static_cast<hipStream_t>(stream), r);
   return ss_launch_status();
 }
 
 static const bool ss_gemm_no_dma = getenv("SS_GEMM_NO_DMA") != nullptr;  // diagnostic: force the register-staged kernel
 
-extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda,
-                                   int a_group, int a_gstride, int a_off, const float* B, int ldb, int b_group,
-                                   int b_gstride, int b_off, float* C, int ldc, const float* bias, float* a_colsum,
-                                   int flags, int splits, int batch, long stride_a, long stride_b, long stride_c,
-                                   long stride_bias, long stride_colsum, ss_stream_t stream) {
+// Argument checks and kernel parameters shared by the plain and the grouped entry points.
+struct GemmLaunch {
+  GemmParams p;
+  dim3 grid;
+  bool dma_ok;
+};
+static int gemm_prepare(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group, int a_gstride,
+                        int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off, float* C, int ldc,
+                        const float* bias, float* a_colsum, int flags, int splits, int batch, long stride_a, long stride_b,
+                        long stride_c, long stride_bias, long stride_colsum, GemmLaunch* out) {
   SS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && batch >= 1, SS_ERR_ARG);
   SS_REQUIRE(!a_colsum || !a_kcontig, SS_ERR_ARG);
   SS_REQUIRE(splits >= 1 && a_group > 0 && b_group > 0, SS_ERR_ARG);
@@ -622,7 +671,7 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
   SS_REQUIRE((flags & 8) || (splits == 1 && !(flags & 4)) || ((flags & 1) && !(flags & 2)), SS_ERR_ARG);
   // workspace mode: raw accumulators only -- bias, ReLU and accumulation belong to the reduce pass
   SS_REQUIRE(!(flags & 8) || (!(flags & 7) && !bias && (reinterpret_cast<uintptr_t>(C) & 15) == 0), SS_ERR_ARG);
-  GemmParams p;
+  GemmParams& p = out->p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.asum = a_colsum;
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -632,24 +681,40 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
   p.sA = stride_a; p.sB = stride_b; p.sC = stride_c; p.sBias = stride_bias; p.sAsum = stride_colsum;
   p.flags = flags & 15;
   p.kcat = 1;
-  dim3 grid(ceil_div(N, BN), ceil_div(M, BM), p.nz * batch), block(256);
-  SS_REQUIRE(grid.z <= 65535, SS_ERR_UNSUPPORTED);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  out->grid = dim3(ceil_div(N, BN), ceil_div(M, BM), p.nz * batch);
+  SS_REQUIRE(out->grid.z <= 65535, SS_ERR_UNSUPPORTED);
   // the DMA-fed kernel wants 16-byte aligned operands whose [k][row] row counts are multiples of 4; the rest (the head's
   // tiny GEMMs, column sums riding along) stays on the register-staged kernel
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  const bool dma_ok = !a_colsum && al16(A) && al16(B) && (lda & 3) == 0 && (ldb & 3) == 0 && (stride_a & 3) == 0 &&
-                      (stride_b & 3) == 0 && (a_kcontig || (M >= 4 && (M & 3) == 0)) && (b_kcontig || (N >= 4 && (N & 3) == 0)) &&
-                      p.ksplit >= 4 * BK && !ss_gemm_no_dma;
+  out->dma_ok = !a_colsum && al16(A) && al16(B) && (lda & 3) == 0 && (ldb & 3) == 0 && (stride_a & 3) == 0 &&
+                (stride_b & 3) == 0 && (a_kcontig || (M >= 4 && (M & 3) == 0)) && (b_kcontig || (N >= 4 && (N & 3) == 0)) &&
+                p.ksplit >= 4 * BK && !ss_gemm_no_dma;
+  return SS_OK;
+}
+
+extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda,
+                                   int a_group, int a_gstride, int a_off, const float* B, int ldb, int b_group,
+                                   int b_gstride, int b_off, float* C, int ldc, const float* bias, float* a_colsum,
+                                   int flags, int splits, int batch, long stride_a, long stride_b, long stride_c,
+                                   long stride_bias, long stride_colsum, ss_stream_t stream) {
+  GemmLaunch gl;
+  const int st = gemm_prepare(a_kcontig, b_kcontig, M, N, K, A, lda, a_group, a_gstride, a_off, B, ldb, b_group, b_gstride, b_off,
+                              C, ldc, bias, a_colsum, flags, splits, batch, stride_a, stride_b, stride_c, stride_bias,
+                              stride_colsum, &gl);
+  if (st != SS_OK) return st;
+  GemmParams& p = gl.p;
+  dim3 grid = gl.grid, block(256);
+  const bool dma_ok = gl.dma_ok;
+  hipStream_t s = static_cast<hipStream_t>(stream);
   if (flags & 16) {
     // the batch is summed into one C
     SS_REQUIRE(!(flags & 8) && !a_colsum, SS_ERR_ARG);
     if (!dma_ok) {  // register-staged kernel: one launch per pair, the later ones accumulate (stream order)
       for (int b = 0; b < batch; ++b) {
-        const int st = ss_gemm_f32_batched(a_kcontig, b_kcontig, M, N, K, A + b * stride_a, lda, a_group, a_gstride, a_off,
-                                           B + b * stride_b, ldb, b_group, b_gstride, b_off, C, ldc, b ? nullptr : bias, nullptr,
-                                           (flags & 15) | (b ? 1 : 0), splits, 1, 0, 0, 0, 0, 0, stream);
-        if (st != SS_OK) return st;
+        const int st2 = ss_gemm_f32_batched(a_kcontig, b_kcontig, M, N, K, A + b * stride_a, lda, a_group, a_gstride, a_off,
+                                            B + b * stride_b, ldb, b_group, b_gstride, b_off, C, ldc, b ? nullptr : bias, nullptr,
+                                            (flags & 15) | (b ? 1 : 0), splits, 1, 0, 0, 0, 0, 0, stream);
+        if (st2 != SS_OK) return st2;
       }
       return SS_OK;
     }
@@ -668,6 +733,77 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
   else if (a_kcontig && !b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
   else if (!a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
+  return ss_launch_status();
+}
+
+// ---- grouped split-K: C_j += A_j^T-ish . B_j for up to GEMM_GROUP_MAX problems, one GEMM launch + one reduce launch
+static long group_ws_offset(const ss_gemm_problem* pr, int j) {  // floats in front of problem j's slices
+  long off = 0;
+  for (int q = 0; q < j; ++q)
+    off += (long)pr[q].batch * splitk_slices(pr[q].K, pr[q].splits, nullptr) * ceil_div(pr[q].M, BM) * ceil_div(pr[q].N, BN) * BM * BN;
+  return off;
+}
+
+extern "C" int ss_gemm_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats) {
+  SS_REQUIRE(problems && floats && n >= 1 && n <= GEMM_GROUP_MAX, SS_ERR_ARG);
+  for (int j = 0; j < n; ++j)
+    SS_REQUIRE(problems[j].M > 0 && problems[j].N > 0 && problems[j].K > 0 && problems[j].splits >= 1 && problems[j].batch >= 1,
+               SS_ERR_ARG);
+  *floats = group_ws_offset(problems, n);
+  return SS_OK;
+}
+
+extern "C" int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream) {
+  SS_REQUIRE(problems && ws && n >= 1 && n <= GEMM_GROUP_MAX, SS_ERR_ARG);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, SS_ERR_ARG);
+  GemmGroup gg;
+  ReduceGroup rg;
+  gg.n = rg.n = n;
+  gg.first[0] = rg.first[0] = 0;
+  bool grouped = true;
+  for (int j = 0; j < n; ++j) {
+    const ss_gemm_problem& q = problems[j];
+    GemmLaunch gl;
+    float* wsj = ws + group_ws_offset(problems, j);
+    const int st = gemm_prepare(q.a_kcontig, q.b_kcontig, q.M, q.N, q.K, q.A, q.lda, q.a_group, q.a_gstride, q.a_off, q.B, q.ldb,
+                                q.b_group, q.b_gstride, q.b_off, wsj, q.N, nullptr, nullptr, 8, q.splits, q.batch, q.stride_a,
+                                q.stride_b, 0, 0, 0, &gl);
+    if (st != SS_OK) return st;
+    SS_REQUIRE(q.C && q.ldc >= q.N, SS_ERR_ARG);
+    grouped = grouped && gl.dma_ok && q.a_kcontig == problems[0].a_kcontig && q.b_kcontig == problems[0].b_kcontig;
+    gg.p[j] = gl.p;
+    gg.gx[j] = gl.grid.x; gg.gy[j] = gl.grid.y;
+    gg.first[j + 1] = gg.first[j] + (int)(gl.grid.x * gl.grid.y * gl.grid.z);
+    rg.it[j] = ReduceItem{reinterpret_cast<const f32x4*>(wsj), gl.p.nz, (int)gl.grid.x, (int)gl.grid.y, q.M, q.N, q.C, q.ldc, q.stride_c};
+    rg.first[j + 1] = rg.first[j] + (int)(q.batch * gl.grid.x * gl.grid.y * 8);
+  }
+  for (int j = n; j < GEMM_GROUP_MAX; ++j) {
+    gg.p[j] = gg.p[0]; gg.gx[j] = gg.gy[j] = 1; gg.first[j + 1] = gg.first[n];
+    rg.it[j] = rg.it[0]; rg.first[j + 1] = rg.first[n];
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!grouped) {  // an operand the DMA-fed kernel cannot take: the same work, problem by problem
+    for (int j = 0; j < n; ++j) {
+      const ss_gemm_problem& q = problems[j];
+      float* wsj = ws + group_ws_offset(problems, j);
+      int st = ss_gemm_f32_batched(q.a_kcontig, q.b_kcontig, q.M, q.N, q.K, q.A, q.lda, q.a_group, q.a_gstride, q.a_off, q.B,
+                                   q.ldb, q.b_group, q.b_gstride, q.b_off, wsj, q.N, nullptr, nullptr, 8, q.splits, q.batch,
+                                   q.stride_a, q.stride_b, 0, 0, 0, stream);
+      if (st != SS_OK) return st;
+      st = ss_gemm_splitk_reduce(wsj, q.M, q.N, q.K, q.splits, q.batch, q.C, q.ldc, q.stride_c, stream);
+      if (st != SS_OK) return st;
+    }
+    return SS_OK;
+  }
+  constexpr size_t lds_bytes = (size_t)DSTAGES * D_STAGE * sizeof(float);
+  const dim3 ggrid((unsigned)gg.first[n]), block(256);
+  const bool akc = problems[0].a_kcontig, bkc = problems[0].b_kcontig;
+  if (akc && bkc) hipLaunchKernelGGL((gemm_dma_group_kernel<true, true>), ggrid, block, lds_bytes, s, gg);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_dma_group_kernel<true, false>), ggrid, block, lds_bytes, s, gg);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_dma_group_kernel<false, true>), ggrid, block, lds_bytes, s, gg);
+  else hipLaunchKernelGGL((gemm_dma_group_kernel<false, false>), ggrid, block, lds_bytes, s, gg);
+  if (ss_launch_status() != SS_OK) return SS_ERR_LAUNCH;
+  hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)rg.first[n]), dim3(256), 0, s, rg);
   return ss_launch_status();
 }
 

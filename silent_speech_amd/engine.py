@@ -32,7 +32,6 @@ JOIN_BEFORE_CNN_BWD = True
 # (latency-bound) rather than beside that GEMM (MFMA-bound like them): 2.30 vs 2.32 ms/step
 SIDE_AFTER_DX = os.environ.get("SS_SIDE_AFTER_DX", "1") == "1"
 USE_SPLIT_GRU = True
-USE_SPLITK_WS = os.environ.get("SS_NO_SPLITK_WS", "0") != "1"  # weight-gradient K slices via scratch + reduce, not atomics
 # K slices of the d W_hh GEMMs (18 / 12 output tiles): fewer, longer slices than for d W_ih halve the scratch traffic of
 # their reduce passes (measured 512: -0.3 % on the step against 768; 384 and 256: +0.4 %)
 _HH_TARGET = int(os.environ.get("SS_SPLITK_TARGET_HH", "512"))
@@ -88,6 +87,45 @@ def split_k(M, N, K, batch=1, target_wgs=_SPLITK_TARGET):
     return max(1, min(K // 128, target_wgs // tiles))
 
 
+def dw_shapes(cfg, B, T, l):
+    """(M, N, K, K slices) of the weight-gradient GEMMs of GRU layer ``l``: d W_ih, then the r|z and the n rows of d W_hh."""
+    H, N = cfg.hidden, B * T
+    K = cfg.in_dim if l == 0 else 2 * H
+    out = [(3 * H, K, N, split_k(3 * H, K, N, 2))]
+    if T > 1:
+        Kh = B * (T - 1)
+        out += [(2 * H, H, Kh, split_k(2 * H, H, Kh, 2, _HH_TARGET)), (H, H, Kh, split_k(H, H, Kh, 2, _HH_TARGET))]
+    return out
+
+
+def dw_problems(ws, G, cfg, l, lin, ld_in):
+    """The weight-gradient GEMMs of GRU layer ``l`` as ss_gemm_problem records (one grouped launch, both directions each):
+    d W_ih = dGi^T . layer_in;  d W_hh = dGh^T . h_prev in two pieces (rows r|z from columns [0, 2H) of dG, rows n from
+    columns [3H, 4H) = d(W_hn h + b_hn)).  Rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse): with the
+    row remap (group T-1 of stride T, A offset 1, B offset 0) the reverse direction is the same pairing seen from one row
+    earlier in dG and one row later in out, i.e. two pointer shifts."""
+    B, T, H = ws.B, ws.T, cfg.hidden
+    N, K = B * T, (cfg.in_dim if l == 0 else 2 * H)
+    dg = ws.dG[l].data_ptr()
+    wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
+    wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
+    ident = (INT_MAX, 0, 0)
+
+    def prob(M, Nn, Kk, A, B_, Cm, ldc, splits, a_map, b_map, sa, sb, sc):
+        return L.GemmProblem(0, 0, M, Nn, Kk, A, 4 * H, a_map[0], a_map[1], a_map[2], B_, ld_in if b_map is ident else 2 * H,
+                             b_map[0], b_map[1], b_map[2], Cm, ldc, splits, 2, sa, sb, sc)
+
+    shapes = dw_shapes(cfg, B, T, l)
+    out = [prob(*shapes[0][:3], dg, lin, G[wi].data_ptr(), K, shapes[0][3], ident, ident, N * 4 * H, 0, _pstride(G, wi, wir))]
+    if T > 1:
+        am, bm = (T - 1, T, 1), (T - 1, T, 0)
+        sa, sb, sc = N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr)
+        gw, hp = G[wh], ws.out[l].data_ptr()
+        out.append(prob(*shapes[1][:3], dg, hp, gw.data_ptr(), H, shapes[1][3], am, bm, sa, sb, sc))
+        out.append(prob(*shapes[2][:3], dg + 3 * H * 4, hp, _addr(gw, 2 * H * H), H, shapes[2][3], am, bm, sa, sb, sc))
+    return out
+
+
 def _pstride(P, a: str, b: str) -> int:
     """Element stride between two tensors of the flat parameter (or gradient) bucket."""
     return (P[b].data_ptr() - P[a].data_ptr()) // 4
@@ -133,16 +171,13 @@ class Workspace:
             self.d_out = torch.empty(N, 2 * H, **f32)
             # gradient w.r.t. the output of layer l-1 (destination of layer l's d layer_in GEMM, l >= 1): zeroed on the side
             # stream while the top of the backward pass runs, summed into with atomics by both directions
-            # scratch for the K slices of the weight-gradient GEMMs (they run one after another on the side stream)
-            self.splitk_ws = None
-            if USE_SPLITK_WS:
-                need = 0
-                for l in range(cfg.gru_layers):
-                    K = cfg.in_dim if l == 0 else 2 * H
-                    shapes = [(3 * H, K, N)] + ([(2 * H, H, B * (T - 1)), (H, H, B * (T - 1))] if T > 1 else [])
-                    for (m_, n_, k_) in shapes:
-                        need = max(need, L.gemm_splitk_ws_floats(m_, n_, k_, split_k(m_, n_, k_, 2), 2))
-                self.splitk_ws = torch.empty(need, **f32)
+            # scratch for the K slices of one layer's weight-gradient GEMMs (the layers follow each other on the side stream)
+            need = 0
+            for l in range(cfg.gru_layers):
+                probs = [L.GemmProblem(0, 0, m_, n_, k_, None, 0, 1, 0, 0, None, 0, 1, 0, 0, None, 0, sp_, 2, 0, 0, 0)
+                         for (m_, n_, k_, sp_) in dw_shapes(cfg, B, T, l)]
+                need = max(need, L.gemm_group_ws_floats(probs))
+            self.splitk_ws = torch.empty(need, **f32)
             self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
             self.ev_zero = torch.cuda.Event()
             self.xhat = torch.empty(B, 2 * H, **f32)
@@ -283,28 +318,8 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             ws.ev_fork.record()
             with torch.cuda.stream(side):
                 side.wait_event(ws.ev_fork)
-                dg = ws.dG[l].data_ptr()
-                wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
-                wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
-                # d W_ih = dGi^T . layer_in, both directions in one launch
-                gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
-                     splits=split_k(3 * H, K, N, 2), tag="gemm_gru_dW", batch=2, splitk_ws=ws.splitk_ws,
-                     strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0, 0))
-                # d W_hh = dGh^T . h_prev: rows (b,t) of dG pair with out rows (b,t-1) (forward) / (b,t+1) (reverse).
-                # With the row remap (group T-1 of stride T, A offset 1, B offset 0) the reverse direction is the same
-                # pairing seen from one row earlier in dG and one row later in out, i.e. two pointer shifts.
-                if T > 1:
-                    maps = dict(a_map=(T - 1, T, 1), b_map=(T - 1, T, 0))
-                    st = (N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr), 0, 0)
-                    gw = G[wh]
-                    gemm(0, 0, 2 * H, H, B * (T - 1), dg, 4 * H, ws.out[l].data_ptr(), 2 * H, gw.data_ptr(), H,
-                         accumulate=True, atomic=True, splits=split_k(2 * H, H, B * (T - 1), 2, _HH_TARGET), tag="gemm_gru_dW", batch=2,
-                         strides=st, splitk_ws=ws.splitk_ws,
-                         **maps)
-                    gemm(0, 0, H, H, B * (T - 1), dg + 3 * H * 4, 4 * H, ws.out[l].data_ptr(), 2 * H, _addr(gw, 2 * H * H), H,
-                         accumulate=True, atomic=True, splits=split_k(H, H, B * (T - 1), 2, _HH_TARGET), tag="gemm_gru_dW", batch=2,
-                         strides=st, splitk_ws=ws.splitk_ws,
-                         **maps)
+                L.call("ss_gemm_f32_splitk_group", *L.gemm_group(dw_problems(ws, G, cfg, l, lin, ld_in)), ws.splitk_ws.data_ptr(),
+                       L.stream(), tag="gemm_gru_dW")
         # the weight-gradient GEMMs of the upper layers start only when this layer's d layer_in GEMM is through: two
         # MFMA-bound GEMMs side by side gain nothing and the one on the critical path loses half its rate; beside the
         # latency-bound recurrence of the layer below they fill idle matrix pipes.  Layer 0 has no recurrence left to

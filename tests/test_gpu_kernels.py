@@ -136,6 +136,46 @@ def test_gemm_splitk_workspace(L, M, N, K, splits, batch):
     assert torch.isnan(ws[need:]).all(), "wrote past the advertised workspace size"
 
 
+@pytest.mark.parametrize("aligned", [True, False])
+def test_gemm_splitk_group(L, aligned):
+    """Three split-K problems of different shapes, K and row maps in one grouped launch == each alone (fp64 reference).
+    ``aligned=False`` gives one problem an odd leading dimension: the whole group then takes the problem-by-problem fallback."""
+    g = torch.Generator().manual_seed(11)
+    Bc, T = 40, 9  # K slices of >= 64 rows, or the DMA-fed kernel (and with it the grouped launch) is not taken
+    Nrows = Bc * T
+    specs = [(96, 116, Nrows, 5, None), (128, 64, Bc * (T - 1), 4, (T - 1, T)), (64, 64, Bc * (T - 1), 3, (T - 1, T))]
+    probs, refs, outs, keep = [], [], [], []
+    for j, (M, N, K, splits, rmap) in enumerate(specs):
+        lda = M + (0 if (aligned or j != 1) else 1)
+        A = torch.randn(2, Nrows, lda, generator=g)
+        Bm = torch.randn(2, Nrows, N, generator=g)
+        C0 = torch.randn(2, M, N + 2, generator=g)
+        ref = C0.clone().double()
+        for b in range(2):
+            if rmap is None:
+                ref[b, :, :N] += A[b, :, :M].double().t() @ Bm[b].double()
+            else:  # rows (clip, t>=1) of A pair with rows (clip, t-1) of B
+                a = A[b, :, :M].view(Bc, T, M)[:, 1:].reshape(-1, M).double()
+                bb = Bm[b].view(Bc, T, N)[:, :-1].reshape(-1, N).double()
+                ref[b, :, :N] += a.t() @ bb
+        a_d, b_d, c_d = dev(A), dev(Bm), dev(C0)
+        keep += [a_d, b_d]
+        am = (INT_MAX, 0, 0) if rmap is None else (rmap[0], rmap[1], 1)
+        bm = (INT_MAX, 0, 0) if rmap is None else (rmap[0], rmap[1], 0)
+        probs.append(L.GemmProblem(0, 0, M, N, K, a_d.data_ptr(), lda, am[0], am[1], am[2], b_d.data_ptr(), N, bm[0], bm[1], bm[2],
+                                   c_d.data_ptr(), N + 2, splits, 2, Nrows * lda, Nrows * N, M * (N + 2)))
+        refs.append(ref.float())
+        outs.append(c_d)
+    need = L.gemm_group_ws_floats(probs)
+    ws = torch.full((need + 8,), float("nan"), device="cuda")
+    arr, n = L.gemm_group(probs)
+    L.call("ss_gemm_f32_splitk_group", arr, n, ws.data_ptr(), L.stream())
+    sync()
+    for j in range(3):
+        assert_close(f"group problem {j}", outs[j], refs[j], atol=3e-4, rtol=1e-5)
+    assert torch.isnan(ws[need:]).all(), "wrote past the advertised workspace size"
+
+
 @pytest.mark.parametrize("M,N,K,ldb_extra", [(7680, 384, 576, 0), (300, 32, 200, 84), (130, 70, 50, 3)])
 def test_gemm_summed_batch(L, M, N, K, ldb_extra):
     """flags bit4: C = bias + A0 B0 + A1 B1 in one launch (the d layer_in GEMM of both GRU directions); the last case is
