@@ -20,7 +20,7 @@ def short(name):
 
 
 def stats(src, dst):
-    f = glob.glob(src + "/*/*_kernel_stats.csv")[0]
+    f = (glob.glob(src + "/*/*_kernel_stats.csv") + glob.glob(src + "/*_kernel_stats.csv"))[0]
     rows = list(csv.reader(open(f)))
     with open(dst, "w", newline="") as out:
         w = csv.writer(out)
@@ -33,7 +33,7 @@ def stats(src, dst):
 def pmc(fetch_dir, write_dir, dst):
     res = collections.defaultdict(dict)
     for key, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
-        f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+        f = (glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"))[0]
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == key:
