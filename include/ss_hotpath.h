@@ -93,8 +93,8 @@ int ss_roi_cnn_stash_size(int H, int W, int* a1_floats, int* a2_floats, int* i1_
  *   streams it back with linear 16-byte copies; st_i1 (N, i1_bytes) u8: its 2x2 argmax (0..3, row-major window),
  *   8 planes of H/2*W/2 + 4 bytes;
  * st_a2 (N, a2_floats) f32 and st_i2 (N,H/4,W/4,16) u8 (pixel-major): the same for conv2;
- * st_m3 (N,H/4*W/4,32) u8, pixel-major, channels 24..31 zero: conv3 output > 0; st_feat (N,48): globally averaged conv3 features, then the
- * per-channel counts of positive conv3 outputs. */
+ * st_m3 (N,H/4*W/4,32) u8, pixel-major, channels 24..31 zero: conv3 output > 0; st_feat (N,52): globally averaged conv3 features, then the
+ * per-channel counts of positive conv3 outputs, then the mean and the standard deviation of the frame (the backward kernel reuses them). */
 int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
                          const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
                          const float* bfc, int E, float* out, int ld_out, float* st_a1, uint8_t* st_i1,

@@ -51,7 +51,7 @@ struct CnnFwdParams {
   float* st_a2;     // [N][16][P2] haloed LDS image of the pooled-2 map, as is
   uint8_t* st_i2;   // [N][H4][W4][16]  pixel-major: the backward pass consumes it next to its pixel-major da2
   uint8_t* st_m3;   // [N][P][32]  pixel-major, channels 24..31 unused: the backward turns 16 bytes into 16 floats of one pixel
-  float* st_feat;   // [N][48]  24 averaged conv3 features, then 24 counts of positive conv3 outputs (for d b3)
+  float* st_feat;   // [N][ST_FEAT]  24 averaged conv3 features, 24 counts of positive conv3 outputs (for d b3), mean, std
 };
 
 template <class G>
@@ -174,6 +174,10 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       }
       s_stat[0] = mu;
       s_stat[1] = sd;
+      if (stash) {
+        p.st_feat[(long)n * ST_FEAT + 48] = mu;
+        p.st_feat[(long)n * ST_FEAT + 49] = sd;
+      }
     }
     __syncthreads();
     if (tid < 256) {  // xn = (u/255 - mu)/sd once per grey level; pixels then look their value up
@@ -408,8 +412,8 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       if (stash) {
         float cnt = 0.f;
         for (int k = 0; k < NWV; ++k) cnt += s_cp[k * 32 + tid];
-        p.st_feat[(long)n * 48 + tid] = s;
-        p.st_feat[(long)n * 48 + 24 + tid] = cnt;
+        p.st_feat[(long)n * ST_FEAT + tid] = s;
+        p.st_feat[(long)n * ST_FEAT + 24 + tid] = cnt;
       }
     }
     __syncthreads();

@@ -100,8 +100,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float* s_dout = misc;          // [64]
   float* s_feat = misc + 64;     // [32]
   float* s_dfeat = misc + 96;    // [32]  d feat[c] / P
-  float* s_stat = misc + 128;    // mu, sd
-  unsigned* s_red = reinterpret_cast<unsigned*>(misc + 136);  // [2*NWV]
+  float* s_stat = misc + 128;    // mu, sd of this frame (prefetched: dead after the grey-level table is built)
   float* s_gb3 = misc + 160;     // [32]  accumulated over the frame walk
   float* s_cnt = misc + 448;     // [24] positive conv3 outputs per channel of this frame (from the forward's stash)
   float* s_xn = misc + 192;      // [256] normalised value of every uint8 level for this frame
@@ -216,15 +215,16 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     }
     if (wvu == NWV - 1) {
       if (lane < E) ss_dma4(p.d_out + (long)nf * p.ld_dout + lane, (unsigned)((LL::o_misc) * 4));
-      if (lane < 24) ss_dma4(p.st_feat + (long)nf * 48 + lane, (unsigned)((LL::o_misc + 64) * 4));
-      if (lane < 24) ss_dma4(p.st_feat + (long)nf * 48 + 24 + lane, (unsigned)((LL::o_misc + 448) * 4));
+      if (lane < 24) ss_dma4(p.st_feat + (long)nf * ST_FEAT + lane, (unsigned)((LL::o_misc + 64) * 4));
+      if (lane < 24) ss_dma4(p.st_feat + (long)nf * ST_FEAT + 24 + lane, (unsigned)((LL::o_misc + 448) * 4));
+      if (lane < 2) ss_dma4(p.st_feat + (long)nf * ST_FEAT + 48 + lane, (unsigned)((LL::o_misc + 128) * 4));  // mean, std
     }
   };
   if ((int)blockIdx.x < p.N) prefetch_frame(blockIdx.x);
 
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     STAMP(15);
-    // ---------------- L0: the prefetched inputs have landed; pixel statistics
+    // ---------------- L0: the prefetched inputs have landed (the frame's mean / std come with them, from the forward's stash)
     ss_dma_wait();    // this wave's pieces (issued a frame ago)
     __syncthreads();  // A0: everybody's
     constexpr int NM3 = (2 * P + NT - 1) / NT;  // 16-byte mask items (pixel, channel half) per thread
@@ -240,26 +240,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     for (int k = 0; k < 3; ++k)
       if (tid + k * NT < E * 24) s_wfc[tid + k * NT] = wfc_r[k];
     if (!LL::W3_RESIDENT) stage_w3();
-    {
-      unsigned su = 0, sq = 0;
-#pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        if ((tid + k * NT) * 16 < HW) {
-          const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const unsigned u = (wds[e] >> (8 * b)) & 255u;
-              su += u;
-              sq += u * u;
-            }
-        }
-      }
-      su = wave_sum_u32(su);
-      sq = wave_sum_u32(sq);
-      if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
-    }
     {  // pooled-1 map: LDS-DMA, 1 KB per wave instruction, issued after every compiler-tracked load of this phase
        // has been consumed and waited for only before S3 (it flies under S1/S2)
       constexpr int BYTES = 8 * P1 * 4;
@@ -282,20 +262,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       for (int e = sub; e < E; e += 16) s += s_dout[e] * s_wfc[e * 24 + c];
       s = row_sum(s);  // the 16 lanes of a channel are one DPP row
       if (sub == 0) s_dfeat[c] = s / (float)P;
-    }
-    if (tid == 32) {
-      unsigned long long tsu = 0, tsq = 0;
-      for (int k = 0; k < NWV; ++k) { tsu += s_red[2 * k]; tsq += s_red[2 * k + 1]; }
-      float mu = 0.f, sd = 1.f;
-      if (p.standardize) {
-        const double nn = (double)HW;
-        mu = (float)((double)tsu / nn) / 255.0f;
-        double var = ((double)tsq - (double)tsu * (double)tsu / nn) / (nn - 1.0);
-        sd = (float)(sqrt(var > 0.0 ? var : 0.0) / 255.0);
-        sd = fmaxf(sd, 1e-6f);
-      }
-      s_stat[0] = mu;
-      s_stat[1] = sd;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

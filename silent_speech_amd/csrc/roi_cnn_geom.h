@@ -10,6 +10,10 @@ constexpr int plane_stride(int n) {  // smallest >= n that is == 18 (mod 32): co
   return n + (18 - n % 32 + 32) % 32;  // both when lanes walk pixels (stride 1) and when they walk planes
 }
 
+// one row of the st_feat stash: 24 averaged conv3 features, 24 counts of positive conv3 outputs, the frame's mean and
+// standard deviation (the backward kernel would otherwise redo the pixel statistics and their f64 arithmetic per frame), pad
+constexpr int ST_FEAT = 52;
+
 template <int H_, int W_>
 struct Geom {
   static constexpr int H = H_, W = W_, H2 = H_ / 2, W2 = W_ / 2, H4 = H_ / 4, W4 = W_ / 4;

@@ -195,7 +195,7 @@ class Workspace:
                 self.st_a2 = torch.empty(N, n_a2, **f32)
                 self.st_i2 = torch.empty(N, Hh // 4, Ww // 4, 16, **u8)
                 self.st_m3 = torch.empty(N, (Hh // 4) * (Ww // 4), 32, **u8)
-                self.st_feat = torch.empty(N, 48, **f32)
+                self.st_feat = torch.empty(N, 52, **f32)  # 24 features, 24 counts, mean, std, pad
 
 
 def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Tensor, R: Optional[torch.Tensor], *,

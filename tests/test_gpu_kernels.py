@@ -586,7 +586,7 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     st_a2 = torch.empty(N, n_a2, device="cuda")
     st_i2 = torch.empty(N, H4, W4, 16, device="cuda", dtype=torch.uint8)  # pixel-major
     st_m3 = torch.empty(N, H4 * W4, 32, device="cuda", dtype=torch.uint8)  # pixel-major, 24 of 32 channel slots used
-    st_feat = torch.empty(N, 48, device="cuda")  # 24 features + 24 positive-output counts
+    st_feat = torch.empty(N, 52, device="cuda")  # 24 features, 24 positive-output counts, frame mean / std, pad
     st = [st_a1, st_i1, st_a2, st_i2, st_m3, st_feat]
     L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out.data_ptr(), 32,
            *[s.data_ptr() for s in st], L.stream())
