@@ -61,13 +61,37 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
   const int len = p.lengths[b];
   const float* hb = p.h + (long)b * T * D;
 
+  // Linear(D -> MID) weights of this wave's rows, fetched NOW: the loop that consumed them straight from memory (one L2 round
+  // trip per 64 columns, twelve in a row) was 20 of the kernel's 33 us; here the loads fly under the attention phases.
+  // Wave wv owns rows 4 wv + u of each 64-row pass; PF_PASS x PF_IT covers MID <= 128, D <= 384, the rest takes the loop.
+  constexpr int PF_PASS = 2, PF_IT = 6;
+  float wreg[PF_PASS][4][PF_IT];
+#pragma unroll
+  for (int ps = 0; ps < PF_PASS; ++ps)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int it = 0; it < PF_IT; ++it) {
+        const int o = 4 * wv + u + 4 * NWT * ps, d = lane + 64 * it;
+        wreg[ps][u][it] = (o < MID && d < D) ? p.w1[(long)o * D + d] : 0.f;
+      }
+
   // ---- AttnPool: scores, masked softmax over t, weighted sum
   const float bsc = p.b_score[0];
   for (int t = wv; t < T; t += NWT) {
     float s = -1e9f;  // masked_fill(~mask, -1e9), train_model_official.py:245
     if (t < len) {
       s = 0.f;
-      for (int d = lane; d < D; d += 64) s += hb[(long)t * D + d] * p.w_score[d];
+      float hv[PF_IT], sw[PF_IT];  // all loads of a row first
+#pragma unroll
+      for (int it = 0; it < PF_IT; ++it) {
+        const int d = lane + 64 * it;
+        hv[it] = d < D ? hb[(long)t * D + d] : 0.f;
+        sw[it] = d < D ? p.w_score[d] : 0.f;
+      }
+#pragma unroll
+      for (int it = 0; it < PF_IT; ++it) s += hv[it] * sw[it];
+      for (int d = lane + 64 * PF_IT; d < D; d += 64) s += hb[(long)t * D + d] * p.w_score[d];
       s = wave_sum(s) + bsc;
     }
     if (lane == 0) sc[t] = s;
@@ -121,9 +145,19 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
   __syncthreads();
   // ---- Linear(D -> MID) + ReLU + Dropout: a wave per output row, lanes across the row (coalesced weight reads);
   // four rows at a time so the four shuffle-reduction chains interleave
-  for (int o0 = 4 * wv; o0 < MID; o0 += 4 * NWT) {
+  float xv[PF_IT];
+#pragma unroll
+  for (int it = 0; it < PF_IT; ++it) xv[it] = (lane + 64 * it < D) ? lnv[lane + 64 * it] : 0.f;
+  int ps = 0;
+  for (int o0 = 4 * wv; o0 < MID; o0 += 4 * NWT, ++ps) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int d = lane; d < D; d += 64) {
+    if (ps < PF_PASS) {
+#pragma unroll
+      for (int it = 0; it < PF_IT; ++it)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += (ps == 0 ? wreg[0][u][it] : wreg[1][u][it]) * xv[it];
+    }
+    for (int d = lane + (ps < PF_PASS ? 64 * PF_IT : 0); d < D; d += 64) {
       const float x = lnv[d];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
