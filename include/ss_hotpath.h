@@ -272,13 +272,15 @@ int ss_tail_fwd(const float* h, const int32_t* lengths, const float* w_score, co
                 float label_smoothing, float denom, float* attn, float* xhat, float* rstd, float* ln, float* mid,
                 float* mid_d, float* logits, float* d_logits, float* loss_sum, int32_t* correct, ss_stream_t stream);
 /* Backward of the tail from d_logits (B,C) down to d_h (B,T,D) (written) and d_mid (B,MID) (written: the input of the
- * first Linear's weight-gradient GEMM); g_gamma, g_beta (D), g_wscore (D), g_bscore (1) are accumulated.  The two
+ * first Linear's weight-gradient GEMM); g_gamma, g_beta (D), g_wscore (D), g_bscore (1) are accumulated -- unless
+ * col_part (B,3,D) is given: then every clip STORES its terms of g_gamma | g_beta | g_wscore there and the caller adds the
+ * column sums (ss_colsum_f32, lda = 3 D) to the three gradients; 256 clips' float atomics on the same D addresses serialise.  The two
  * Linear weight/bias gradients are ss_gemm_f32 calls on (d_logits, mid_d) and (d_mid, ln). */
 int ss_tail_bwd(const float* h, const int32_t* lengths, const float* w_score, const float* gamma, const float* w1,
                 const float* w4, const float* attn, const float* xhat, const float* rstd, const float* mid,
                 const float* d_logits, int B, int T, int D, int MID, int C, float drop_p, uint64_t seed,
                 uint64_t offset, float* d_mid, float* d_h, float* g_gamma, float* g_beta, float* g_wscore,
-                float* g_bscore, ss_stream_t stream);
+                float* g_bscore, float* col_part, ss_stream_t stream);
 
 /* ---- a10: loss, clip, Adam -------------------------------------------------------------------
  * CrossEntropyLoss(label_smoothing) mean-reduced over `denom` clips (the GLOBAL batch under data

@@ -53,7 +53,7 @@ SIGNATURES = {
     "ss_attn_pool_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "ss_attn_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "ss_tail_fwd": [_vp] * 11 + [_i] * 5 + [_f, _f, _u64, _u64, _f, _f] + [_vp] * 10 + [_vp],
-    "ss_tail_bwd": [_vp] * 11 + [_i] * 5 + [_f, _u64, _u64] + [_vp] * 6 + [_vp],
+    "ss_tail_bwd": [_vp] * 11 + [_i] * 5 + [_f, _u64, _u64] + [_vp] * 7 + [_vp],
     "ss_layernorm_fwd": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
     "ss_layernorm_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "ss_dropout": [_vp, _vp, _l, _f, _u64, _u64, _vp, _vp],

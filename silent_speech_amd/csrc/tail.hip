@@ -231,6 +231,7 @@ struct TailBwdParams {
   float drop_p;
   uint64_t seed, offset;
   float *d_mid, *d_h, *g_gamma, *g_beta, *g_wscore, *g_bscore;
+  float* col_part;  // NULL, or [B][3][D]: this clip's terms of g_gamma | g_beta | g_wscore, stored instead of added atomically
 };
 
 // dynamic LDS: dmid[MID] | dp[D] | ds[T] | wt[T] | dl[C]
@@ -266,8 +267,15 @@ __global__ __launch_bounds__(TNT) void tail_bwd_kernel(TailBwdParams p) {
     float acc = 0.f;
     for (int o = 0; o < MID; ++o) acc += dmid[o] * p.w1[(long)o * D + d];
     const float xh = p.xhat[(long)b * D + d];
-    atomicAdd(&p.g_gamma[d], acc * xh);
-    atomicAdd(&p.g_beta[d], acc);
+    // 256 clips adding to the same D addresses serialise at the memory side (~30 ns per add: 8 us of this kernel); with a
+    // scratch row per clip the sums are taken by a column-sum pass off the critical path
+    if (p.col_part) {
+      p.col_part[((long)b * 3 + 0) * D + d] = acc * xh;
+      p.col_part[((long)b * 3 + 1) * D + d] = acc;
+    } else {
+      atomicAdd(&p.g_gamma[d], acc * xh);
+      atomicAdd(&p.g_beta[d], acc);
+    }
     const float dxh = acc * p.gamma[d];
     dp[d] = dxh;
     s1 += dxh;
@@ -304,7 +312,8 @@ __global__ __launch_bounds__(TNT) void tail_bwd_kernel(TailBwdParams p) {
       }
       p.d_h[((long)b * T + t) * D + d] = v;
     }
-    atomicAdd(&p.g_wscore[d], gw);
+    if (p.col_part) p.col_part[((long)b * 3 + 2) * D + d] = gw;
+    else atomicAdd(&p.g_wscore[d], gw);
   }
   if (tid == 0) {
     float gb = 0.f;
@@ -341,7 +350,7 @@ extern "C" int ss_tail_bwd(const float* h, const int32_t* lengths, const float* 
                            const float* w1, const float* w4, const float* attn, const float* xhat, const float* rstd,
                            const float* mid, const float* d_logits, int B, int T, int D, int MID, int C, float drop_p,
                            uint64_t seed, uint64_t offset, float* d_mid, float* d_h, float* g_gamma, float* g_beta,
-                           float* g_wscore, float* g_bscore, ss_stream_t stream) {
+                           float* g_wscore, float* g_bscore, float* col_part, ss_stream_t stream) {
   SS_REQUIRE(h && lengths && w_score && gamma && w1 && w4 && attn && xhat && rstd && mid && d_logits, SS_ERR_ARG);
   SS_REQUIRE(d_mid && d_h && g_gamma && g_beta && g_wscore && g_bscore, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0 && D > 0 && MID > 0 && C > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
@@ -352,6 +361,7 @@ extern "C" int ss_tail_bwd(const float* h, const int32_t* lengths, const float* 
   p.attn = attn; p.xhat = xhat; p.rstd = rstd; p.mid = mid; p.d_logits = d_logits;
   p.B = B; p.T = T; p.D = D; p.MID = MID; p.C = C; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
   p.d_mid = d_mid; p.d_h = d_h; p.g_gamma = g_gamma; p.g_beta = g_beta; p.g_wscore = g_wscore; p.g_bscore = g_bscore;
+  p.col_part = col_part;
   hipLaunchKernelGGL(tail_bwd_kernel, dim3(B), dim3(TNT), lds, static_cast<hipStream_t>(stream), p);
   return ss_launch_status();
 }

@@ -184,6 +184,7 @@ class Workspace:
             self.rstd = torch.empty(B, **f32)
             self.d_logits = torch.empty(B, cfg.num_classes, **f32)
             self.d_mid = torch.empty(B, cfg.head_mid, **f32)
+            self.tail_part = torch.empty(B, 3, 2 * H, **f32)  # per-clip terms of d gamma | d beta | d w_score (tail_bwd)
             self.d_ln = torch.empty(B, 2 * H, **f32)
             self.d_pooled = torch.empty(B, 2 * H, **f32)
             self.dZ = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
@@ -273,7 +274,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
            ws.attn.data_ptr(), ws.xhat.data_ptr(), ws.rstd.data_ptr(), ws.mid.data_ptr(), d_logits.data_ptr(), B, T,
            2 * H, MID, C, p_drop, seed, 7 << 40, ws.d_mid.data_ptr(), ws.d_out.data_ptr(),
            G["head.0.weight"].data_ptr(), G["head.0.bias"].data_ptr(), G["pool.score.weight"].data_ptr(),
-           G["pool.score.bias"].data_ptr(), s)
+           G["pool.score.bias"].data_ptr(), ws.tail_part.data_ptr(), s)
     # ... while the two Linear weight gradients (batched over the clips) go to the side stream
     side = ws.side if USE_SIDE_STREAM else torch.cuda.current_stream()
     ws.ev_fork.record()
@@ -286,6 +287,9 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         if cfg.use_roi:
             ws.dZ.zero_()
         ws.ev_zero.record()
+        # LayerNorm gamma / beta and score-weight gradients: column sums of the rows the tail kernel left per clip
+        for k_, name_ in enumerate(("head.0.weight", "head.0.bias", "pool.score.weight")):
+            L.call("ss_colsum_f32", _addr(ws.tail_part, k_ * 2 * H), B, 2 * H, 3 * 2 * H, G[name_].data_ptr(), L.stream())
         gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, ws.mid_drop.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
              accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
         gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),

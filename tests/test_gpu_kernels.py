@@ -420,8 +420,22 @@ def test_fused_tail_fwd_bwd(L, B, T, C):
     L.call("ss_tail_bwd", h_d.data_ptr(), len_d.data_ptr(), P["pool.score.weight"].data_ptr(), P["head.0.weight"].data_ptr(),
            P["head.1.weight"].data_ptr(), P["head.4.weight"].data_ptr(), attn.data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
            mid.data_ptr(), d_logits.data_ptr(), B, T, D, MID, C, 0.0, 0, 0, d_mid.data_ptr(), d_h.data_ptr(), gg.data_ptr(),
-           gb.data_ptr(), gw.data_ptr(), gs.data_ptr(), L.stream())
+           gb.data_ptr(), gw.data_ptr(), gs.data_ptr(), None, L.stream())
+    # the same with the per-clip scratch rows + column sums instead of float atomics on the three D-vectors
+    part = torch.full((B, 3, D), 9.0, device="cuda")
+    g3 = torch.zeros(3, D, device="cuda")
+    gs2, d_h2, d_mid2 = torch.zeros(1, device="cuda"), torch.empty(B, T, D, device="cuda"), f(B, MID)
+    L.call("ss_tail_bwd", h_d.data_ptr(), len_d.data_ptr(), P["pool.score.weight"].data_ptr(), P["head.0.weight"].data_ptr(),
+           P["head.1.weight"].data_ptr(), P["head.4.weight"].data_ptr(), attn.data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+           mid.data_ptr(), d_logits.data_ptr(), B, T, D, MID, C, 0.0, 0, 0, d_mid2.data_ptr(), d_h2.data_ptr(), g3[0].data_ptr(),
+           g3[1].data_ptr(), g3[2].data_ptr(), gs2.data_ptr(), part.data_ptr(), L.stream())
+    for k in range(3):
+        L.call("ss_colsum_f32", part.data_ptr() + 4 * k * D, B, D, 3 * D, g3[k].data_ptr(), L.stream())
     sync()
+    assert torch.equal(d_h2, d_h) and torch.equal(d_mid2, d_mid)
+    for k, ref_t in enumerate((gg, gb, gw)):
+        assert_close(f"col_part {k}", g3[k], ref_t, atol=2e-5 * float(ref_t.abs().max()) + 1e-8, rtol=1e-4)
+    assert_close("col_part b_score", gs2, gs, atol=1e-6, rtol=1e-5)
     mask = (torch.arange(T).unsqueeze(0) < lengths.unsqueeze(1)).unsqueeze(-1)
     scale = float(hg.grad.abs().max())
     assert_close("tail d_h", d_h, hg.grad * mask, atol=2e-5 * scale, rtol=1e-4)
