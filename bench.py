@@ -58,9 +58,9 @@ def step_gflop_per_clip(T, D, E, H, C, roi, mid=128):
 
 
 def pmc_traffic(kernel_tag):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (profiles/round1_f_pmc_traffic.json,
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (profiles/round1_g_pmc_traffic.json,
     made by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
-    path = os.path.join(ROOT, "profiles", "round1_f_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "round1_g_pmc_traffic.json")
     stem = {"ss_roi_cnn_bwd": "roi_cnn_bwd_kernel", "ss_roi_cnn_fwd_stash": "roi_cnn_fwd_kernel", "ss_gru_fwd": "gru_split_fwd_kernel",
             "ss_gru_bwd": "gru_split_bwd_kernel"}.get(kernel_tag)
     if not stem or not os.path.exists(path):
