@@ -5,11 +5,15 @@
 // (/root/reference/train_model_official.py:261-267, 271-277) and their autograd.
 //
 // 128x64x16 block tile, 256 threads = 4 waves as 2(M) x 2(N), wave tile 64x32 = 4x2 tiles of
-// v_mfma_f32_16x16x4_f32 (exact f32).  Operands are staged global -> registers -> LDS; an operand
-// whose K index is contiguous in memory is kept [row][k] and read back with one ds_read_b128 per
-// four k-steps, an operand whose M/N index is contiguous is kept [k][row] and read with ds_read_b32.
-// Inside a 16-wide k tile the MFMA slot (kk, g) carries k = 4g + kk for BOTH operands, which is
-// what lets the [row][k] form use a single 16-byte read.
+// v_mfma_f32_16x16x4_f32 (exact f32).  An operand whose K index is contiguous in memory is kept [row][k] in
+// LDS and read back with one ds_read_b128 per four k-steps, an operand whose M/N index is contiguous is kept
+// [k][row] and read with ds_read_b32.  Inside a 16-wide k tile the MFMA slot (kk, g) carries k = 4g + kk for
+// BOTH operands, which is what lets the [row][k] form use a single 16-byte read.
+//
+// Two mainloops share the epilogue: gemm_f32_kernel stages global -> registers -> LDS (any alignment, ragged
+// shapes, column sums of A riding along: the head's small GEMMs); gemm_dma_kernel feeds a ring of four k
+// tiles by LDS-DMA (every GEMM of the GRU layers; see the comment above it).  Split-K goes through a scratch
+// buffer and a reduce pass; several split-K problems can share one launch (gemm_dma_group_kernel).
 #include <stdlib.h>
 
 #include "ss_common.h"
