@@ -140,6 +140,7 @@ class Workspace:
 
     def __init__(self, cfg: Config, B: int, T: int, roi_hw, device, train: bool):
         self.cfg, self.B, self.T, self.roi_hw, self.train = cfg, B, T, roi_hw, train
+        self.stash_gen, self.stash_live = 0, False  # model._Fn: which autograd node the stashed activations belong to
         N, H = B * T, cfg.hidden
         f32 = dict(device=device, dtype=torch.float32)
         u8 = dict(device=device, dtype=torch.uint8)

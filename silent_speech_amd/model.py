@@ -103,24 +103,36 @@ class _Fn(torch.autograd.Function):
     """Whole-model autograd node: forward = the fused forward kernels, backward = the fused backward kernels."""
 
     @staticmethod
-    def forward(ctx, model, X, R, seed, *params):
-        ws = model._workspace(X, R, train=True)
+    def forward(ctx, model, X, R, seed, ws, *params):
         P = model._param_dict()
         logits = E.forward(P, model.cfg, ws, X, R, train=model.training, stash=True, seed=seed)
         ctx.model, ctx.ws, ctx.X, ctx.R, ctx.seed, ctx.train = model, ws, X, R, seed, model.training
         ctx.need_dx = X.requires_grad
+        # the stash of this forward lives in ``ws`` until its backward has run: stamp it, so that a later forward
+        # that had to take the workspace over is noticed instead of silently corrupting this node's gradients
+        model._stash_counter += 1  # one counter for all workspaces: the smallest live stamp is the oldest stash
+        ws.stash_gen = model._stash_counter
+        ws.stash_live = True
+        ctx.gen = ws.stash_gen
         return logits.clone()
 
     @staticmethod
     def backward(ctx, d_logits):
         model, ws = ctx.model, ctx.ws
+        if ws.stash_gen != ctx.gen or not ws.stash_live:
+            raise RuntimeError(
+                "silent_speech_amd: the activations stashed by this forward pass are gone -- more than "
+                f"{model.max_live_stashes} grad-enabled forward passes of one shape were alive at once (or backward ran "
+                "twice). Call backward() before further forwards, wrap evaluation in torch.no_grad(), or raise "
+                "model.max_live_stashes.")
+        ws.stash_live = False
         P = model._param_dict()
         names = list(P.keys())
         scratch = torch.zeros_like(model.flat_params)
         G = model._views_of(scratch)
         d_X = torch.empty_like(ctx.X) if ctx.need_dx else None
         E.backward(P, G, model.cfg, ws, ctx.X, ctx.R, d_logits.contiguous(), train=ctx.train, seed=ctx.seed, d_X=d_X)
-        return (None, d_X, None, None, *[G[k] for k in names])
+        return (None, d_X, None, None, None, *[G[k] for k in names])
 
 
 class BiGRUClassifier(nn.Module):
@@ -145,6 +157,10 @@ class BiGRUClassifier(nn.Module):
         self.flat_grads: Optional[torch.Tensor] = None
         self._ws_cache = {}
         self._step_seed = 0
+        # grad-enabled forward passes of one shape whose stashes may be alive together (each owns a workspace)
+        self.max_live_stashes = 2
+        self._stash_counter = 0
+        self._bucket_version = 0
         self._flatten()
 
     # ------------------------------------------------------------------ flat parameter bucket
@@ -158,7 +174,22 @@ class BiGRUClassifier(nn.Module):
     def _views_of(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         return {name: flat[off:off + n].view(shape) for name, off, n, shape in self._layout()[0]}
 
+    def _bucket_intact(self) -> bool:
+        """True when every parameter still is the right view of ``flat_params`` (e.g. after a ``.to()`` that moved nothing)."""
+        flat = self.flat_params
+        if flat is None or self.flat_grads is None:
+            return False
+        params = dict(self.named_parameters())
+        for name, off, n, shape in self._layout()[0]:
+            p = params[name]
+            if (p.dtype != torch.float32 or p.device != flat.device or tuple(p.shape) != shape or not p.is_contiguous()
+                    or p.data_ptr() != flat.data_ptr() + 4 * off):
+                return False
+        return True
+
     def _flatten(self):
+        if self._bucket_intact():
+            return
         params = dict(self.named_parameters())
         lay, total = self._layout()
         dev = next(iter(params.values())).device
@@ -171,6 +202,7 @@ class BiGRUClassifier(nn.Module):
             p.grad = None
         self.flat_params, self.flat_grads = flat, gflat
         self._ws_cache = {}
+        self._bucket_version += 1  # Trainer re-resolves its views of the bucket (and moves its Adam state) when this moves
 
     def attach_flat_grads(self):
         """Point every ``param.grad`` at its slice of ``flat_grads`` (used by the fused trainer)."""
@@ -187,7 +219,7 @@ class BiGRUClassifier(nn.Module):
         return {k: p.data for k, p in self.named_parameters()}
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, X, R, train: bool, slot: int = 0) -> E.Workspace:
+    def _workspace(self, X, R, train: bool, slot=0) -> E.Workspace:
         """Buffers for one (B, T, H, W) shape; ``slot`` separates micro-batches that are in flight together."""
         B, T, _ = X.shape
         hw = tuple(R.shape[2:]) if R is not None else None
@@ -196,6 +228,20 @@ class BiGRUClassifier(nn.Module):
         if ws is None:
             ws = E.Workspace(self.cfg, B, T, hw, X.device, train)
             self._ws_cache[key] = ws
+        return ws
+
+    def _stash_workspace(self, X, R) -> E.Workspace:
+        """Training workspace for an autograd forward: the first one of this shape whose stash is not waiting for a
+        backward pass.  ``la = m(Xa); lb = m(Xb); (la + lb).backward()`` therefore gets two workspaces; when
+        ``max_live_stashes`` are alive the oldest is taken over and ITS backward raises (see _Fn.backward)."""
+        cands = []
+        for i in range(max(1, self.max_live_stashes)):  # built on demand: a training workspace is hundreds of MB
+            ws = self._workspace(X, R, train=True, slot=("autograd", i))
+            if not ws.stash_live:
+                return ws
+            cands.append(ws)
+        ws = min(cands, key=lambda w: w.stash_gen)
+        ws.stash_live = False
         return ws
 
     def _check_inputs(self, X, lengths, R):
@@ -222,11 +268,11 @@ class BiGRUClassifier(nn.Module):
         else:
             R = None
         need_grad = torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in self.parameters()))
-        ws = self._workspace(X, R, train=need_grad)
+        ws = self._stash_workspace(X, R) if need_grad else self._workspace(X, R, train=False)
         # lengths may live anywhere (the reference calls lengths.cpu()); the kernels want int32 on device
         ws.lengths.copy_(lengths.to(torch.int32), non_blocking=True)
         if need_grad:
             self._step_seed += 1
-            return _Fn.apply(self, X, R, self._step_seed, *self.parameters())
+            return _Fn.apply(self, X, R, self._step_seed, ws, *self.parameters())
         logits = E.forward(self._param_dict(), self.cfg, ws, X, R, train=self.training, seed=self._step_seed)
         return logits.clone()

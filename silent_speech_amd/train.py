@@ -28,11 +28,12 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, min(n_items, lo + per)
 
 
-def allreduce_flat_grads(flat: torch.Tensor, group=None) -> None:
-    """Sum the flat gradient bucket over ranks (one collective per step)."""
+def allreduce_flat_grads(flat: torch.Tensor, group=None, always: bool = False) -> None:
+    """Sum the flat gradient bucket over ranks (one collective per step).  ``always`` issues the collective on a
+    one-rank group too (a sum over one rank: the identity) -- how the RCCL leg is exercised on a one-GPU box."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (always or dist.get_world_size(group) > 1):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
 
 
@@ -52,13 +53,14 @@ class Trainer:
 
     def __init__(self, model: BiGRUClassifier, lr: float = 3e-4, max_norm: float = 1.0,
                  label_smoothing: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, world_size: int = 1,
-                 process_group=None, dropout: bool = True, micro_batches: int = 1):
+                 process_group=None, dropout: bool = True, micro_batches: int = 1, always_allreduce: bool = False):
         if model.flat_params is None or not model.flat_params.is_cuda:
             raise RuntimeError("Trainer needs the model on a HIP device")
         L.load()
         self.model, self.lr, self.max_norm, self.ls = model, lr, max_norm, label_smoothing
         self.betas, self.eps = betas, eps
         self.world, self.group = world_size, process_group
+        self.always_allreduce = always_allreduce
         self.dropout = dropout
         dev = model.flat_params.device
         self.m = torch.zeros_like(model.flat_params)
@@ -67,21 +69,51 @@ class Trainer:
         self.scal = torch.zeros(2, device=dev, dtype=torch.float32)
         self.correct = torch.zeros(1, device=dev, dtype=torch.int32)
         self.step_count = 0
-        self.G = model._views_of(model.flat_grads)
-        model.attach_flat_grads()
+        self.rank = 0
+        if world_size > 1:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized():
+                self.rank = dist.get_rank(process_group)
+        self._bind_bucket()
         self.micro_batches = max(1, int(micro_batches))
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.micro_batches)] if self.micro_batches > 1 else []
         self.ev_start = torch.cuda.Event()
         self.ev_done = [torch.cuda.Event() for _ in self.streams]
 
-    def step(self, X: torch.Tensor, lengths: torch.Tensor, R: Optional[torch.Tensor], y: torch.Tensor):
+    def _bind_bucket(self):
+        """(Re)resolve everything that aliases the model's flat buckets.  ``model.to()/.cuda()/.float()`` keep the bucket
+        when nothing moves; when they do re-allocate it (``model._bucket_version`` moves) the gradient views are taken
+        again and the Adam moments follow the parameters to their device, so training carries on instead of
+        accumulating into an orphaned bucket."""
+        model = self.model
+        flat = model.flat_params
+        if self.m.device != flat.device or self.m.numel() != flat.numel():
+            if self.m.numel() != flat.numel():
+                raise RuntimeError("the model's parameter layout changed under the Trainer")
+            self.m, self.v = self.m.to(flat.device), self.v.to(flat.device)
+            self.scal, self.correct = self.scal.to(flat.device), self.correct.to(flat.device)
+        self.G = model._views_of(model.flat_grads)
+        model.attach_flat_grads()
+        self._bucket_version = model._bucket_version
+
+    def step(self, X: torch.Tensor, lengths: torch.Tensor, R: Optional[torch.Tensor], y: torch.Tensor,
+             global_batch: Optional[int] = None):
         """One optimiser step on this rank's shard.  Returns (loss, correct) device tensors:
-        loss = this shard's contribution to the global mean loss (sum over ranks = global loss)."""
+        loss = this shard's contribution to the global mean loss (sum over ranks = global loss).
+        ``global_batch`` = clips of ALL ranks in this step; needed only when the shards are unequal (``shard_range``
+        with a world size that does not divide the batch): the loss is divided by it, so the summed bucket is the
+        global-mean gradient whatever each rank holds.  Default: B * world_size (equal shards)."""
         model, cfg = self.model, self.model.cfg
+        if model._bucket_version != self._bucket_version:
+            self._bind_bucket()
         B = X.shape[0]
         self.step_count += 1
         train = self.dropout and model.training
-        denom = float(B * self.world)
+        # CE is divided by the GLOBAL clip count, so the summed bucket is the global-mean gradient
+        denom = float(global_batch if global_batch is not None else B * self.world)
+        # dropout streams must differ between ranks (clip b of every rank would otherwise draw the same Philox masks)
+        base_seed = self.step_count * self.world + self.rank
         M = self.micro_batches if (self.micro_batches > 1 and B % self.micro_batches == 0 and B // self.micro_batches >= 16) else 1
         fused_prologue = (M == 1 and lengths.dtype == torch.int64 and lengths.is_cuda and lengths.is_contiguous()
                           and X.is_contiguous())
@@ -97,7 +129,7 @@ class Trainer:
             self.scal.zero_()
             self.correct.zero_()
         if M == 1:
-            self._fwd_bwd(X, lengths, R, y, denom, train, seed=self.step_count, slot=0, phase="both",
+            self._fwd_bwd(X, lengths, R, y, denom, train, seed=base_seed, slot=0, phase="both",
                           prologue_done=fused_prologue)
         else:
             n = B // M
@@ -118,15 +150,15 @@ class Trainer:
                                 # chip-filling kernels of one slice run beside the 16-CU recurrence of the other
                                 prev = model._workspace(parts[m - 1][0], parts[m - 1][2], train=True, slot=m)
                                 self.streams[m].wait_event(prev.ev_cnn_fwd)
-                        self._fwd_bwd(Xm, Lm, Rm, ym, denom, train, seed=self.step_count * M + m, slot=m + 1, phase=phase)
+                        self._fwd_bwd(Xm, Lm, Rm, ym, denom, train, seed=base_seed * M + m, slot=m + 1, phase=phase)
                         if phase == "bwd":
                             self.ev_done[m].record(self.streams[m])
             for ev in self.ev_done:
                 cur.wait_event(ev)
             L.call("ss_roi_cnn_set_max_workgroups", 0)
         s = L.stream()
-        if self.world > 1:
-            allreduce_flat_grads(model.flat_grads, self.group)
+        if self.world > 1 or self.always_allreduce:
+            allreduce_flat_grads(model.flat_grads, self.group, always=self.always_allreduce)
         n_el = model.flat_grads.numel()
         L.call("ss_sumsq_f32", model.flat_grads.data_ptr(), n_el, self.scal.data_ptr() + 4, s)
         # d_logits already carries 1/(B*world), so the summed bucket IS the global-mean gradient

@@ -111,6 +111,124 @@ def test_fused_trainer_two_steps_match_reference(ss, golden_dir, name):
     assert err < LOGIT_TOL and err < 2e-4, err
 
 
+def test_minimal_change_loop_matches_reference_step(ss, golden_dir):
+    """the reference's own loop body (train_model_official.py:433-439) with only the class swapped:
+    forward -> CrossEntropyLoss(label_smoothing) -> zero_grad -> backward -> clip_grad_norm_ -> torch.optim.Adam.step,
+    against the parameters the reference had after its first step (``step1::*``) and its second loss."""
+    d, sd, X, Lh, R, y = load_case(golden_dir, "model_roi64")
+    m = build(ss, d, sd)  # eval(): both dropouts off, as when the golden step was made
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    loss_fn = torch.nn.CrossEntropyLoss(label_smoothing=0.05)
+    Xd, Rd, yd = X.cuda(), R.cuda(), y.cuda()
+    losses = []
+    for _ in range(2):
+        logits = m(Xd, Lh, Rd)
+        loss = loss_fn(logits, yd)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        total = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss))
+        if len(losses) == 1:
+            assert abs(float(total) - float(d["total_norm"])) < 1e-3 * float(d["total_norm"])
+            for k, v in m.state_dict().items():
+                atol = 6.1e-4 if k == "pool.score.bias" else 3e-6
+                np.testing.assert_allclose(W.reduce_tensor(v.detach().cpu()), d["step1::" + k], atol=atol, rtol=2e-5, err_msg=k)
+    assert abs(losses[0] - float(d["loss"])) < 2e-5 and abs(losses[1] - float(d["loss2"])) < 5e-5
+
+
+def test_two_forwards_one_backward_and_stale_stash_raises(ss, golden_dir):
+    """two grad-enabled forwards of ONE shape before a backward must each keep their own stash (the first
+    one's gradients used to be silently wrong); with more live stashes than workspaces the oldest must fail loudly."""
+    d, sd, X, Lh, R, y = load_case(golden_dir, "model_roi64")
+    m = build(ss, d, sd)
+    Xa, Ra = X.cuda(), R.cuda()
+    g = torch.Generator().manual_seed(5)
+    Xb = (X + 0.3 * torch.randn(X.shape, generator=g)).cuda()
+    Rb = torch.randint(0, 256, R.shape, generator=g, dtype=torch.uint8).cuda()
+    la = m(Xa, Lh, Ra)
+    lb = m(Xb, Lh, Rb)
+    loss = torch.nn.functional.cross_entropy(la, y.cuda(), label_smoothing=0.05) + \
+        torch.nn.functional.cross_entropy(lb, y.cuda(), label_smoothing=0.05)
+    loss.backward()
+    _, _, ga = MR.loss_and_grads(sd, X, Lh, R, y)
+    _, _, gb = MR.loss_and_grads(sd, Xb.cpu(), Lh, Rb.cpu(), y)
+    for k, p in m.named_parameters():
+        ref = ga[k] + gb[k]
+        scale = max(float(ref.abs().max()), 1e-4)
+        bad = (p.grad.cpu() - ref).abs() > 4e-4 * scale + 2e-3 * ref.abs()
+        assert not bad.any(), f"{k}: {float((p.grad.cpu() - ref).abs().max()):.3e} vs {scale:.3e}"
+    # three alive at once with two workspaces: the oldest stash is taken over and its backward must say so
+    l1, l2, l3 = m(Xa, Lh, Ra), m(Xb, Lh, Rb), m(Xa, Lh, Ra)
+    l3.sum().backward()
+    l2.sum().backward()
+    with pytest.raises(RuntimeError, match="stashed"):
+        l1.sum().backward()
+
+
+def test_trainer_survives_module_moves(ss, golden_dir):
+    """``model.to(dev)`` after the Trainer was built used to re-allocate the flat buckets, leaving the Trainer
+    to accumulate into an orphan: training silently stopped.  A no-op move must keep the bucket; a real move must be
+    followed (gradient views re-taken, Adam moments moved)."""
+    d, sd, X, Lh, R, y = load_case(golden_dir, "model_roi64")
+    m = build(ss, d, sd)
+    tr = ss.Trainer(m, dropout=False)
+    flat0, ver0 = m.flat_params.data_ptr(), m._bucket_version
+    m.to("cuda")
+    m.float()
+    m.cuda()
+    assert m.flat_params.data_ptr() == flat0 and m._bucket_version == ver0
+    Xd, Ld, Rd, yd = X.cuda(), Lh.cuda(), R.cuda(), y.cuda()
+    loss1, _ = tr.step(Xd, Ld, Rd, yd)
+    assert abs(float(loss1) - float(d["loss"])) < 2e-5
+    m.cpu()
+    m.cuda()  # a real round trip: new buckets
+    assert m._bucket_version != ver0
+    loss2, _ = tr.step(Xd, Ld, Rd, yd)
+    assert abs(float(loss2) - float(d["loss2"])) < 5e-5
+    with torch.no_grad():
+        after = m(Xd, Ld, Rd)
+    assert float((after.cpu() - torch.from_numpy(d["logits_after2"])).abs().max()) < 2e-4
+
+
+def test_one_rank_rccl_trainer_equals_single_process(ss, tmp_path):
+    """The data-parallel leg on the hardware at hand: a FRESH child process (torch.distributed.run, one rank) joins an
+    "nccl" (= RCCL) group and pushes the flat gradient bucket of two training steps through dist.all_reduce; the result
+    must equal the single-process trainer (a sum over one rank is the identity; dropout on, so the rank-folded seed is
+    covered too): first loss bit for bit, parameters to the run-to-run noise of the float atomics."""
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "child.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "_nccl_child.py"), out],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out, map_location="cpu", weights_only=False)
+    assert got["backend"] == "nccl" and got["world"] == 1
+    B, T = 16, 9
+    sd = W.make_state_dict(21, 84, 5, True)
+    X, Lh, R, y = W.make_inputs(21, B, T, 84, 5, (64, 64))
+    m = ss.BiGRUClassifier(84, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().train()
+    tr = ss.Trainer(m, dropout=True)
+    losses = [float(tr.step(X.cuda(), Lh.cuda(), R.cuda(), y.cuda())[0]) for _ in range(2)]
+    # same kernels, same seeds; what may differ between two runs is the order of the float atomics that sum the CNN and
+    # GRU-bias gradients over workgroups (rounding noise that Adam turns into at most a fraction of lr = 3e-4)
+    assert losses[0] == got["losses"][0] and abs(losses[1] - got["losses"][1]) < 1e-5, (losses, got["losses"])
+    for k, v in m.state_dict().items():
+        atol = 6.1e-4 if k == "pool.score.bias" else 2e-5
+        assert float((v.cpu() - got["sd"][k]).abs().max()) <= atol, k
+
+
 def test_padding_never_leaks_and_batch_permutes(ss, golden_dir):
     d, sd, X, Lh, R, y = load_case(golden_dir, "model_roi64")
     m = build(ss, d, sd)
