@@ -91,14 +91,19 @@ int ss_roi_cnn_stash_size(int H, int W, int* a1_floats, int* a2_floats, int* i1_
  * st_a1 (N, a1_floats) f32: the pooled conv1 map in the kernels' zero-haloed LDS layout (8 planes of
  *   (H/2+2) rows x (W/2+2) floats, plane stride padded; sizes from ss_roi_cnn_stash_size) so that the backward
  *   streams it back with linear 16-byte copies; st_i1 (N, i1_bytes) u8: its 2x2 argmax (0..3, row-major window),
- *   8 planes of H/2*W/2 + 4 bytes;
+ *   8 planes of Geom::I1S = H/2*W/2 bytes;
  * st_a2 (N, a2_floats) f32 and st_i2 (N,H/4,W/4,16) u8 (pixel-major): the same for conv2;
  * st_m3 (N,H/4*W/4,32) u8, pixel-major, channels 24..31 zero: conv3 output > 0; st_feat (N,52): globally averaged conv3 features, then the
- * per-channel counts of positive conv3 outputs, then the mean and the standard deviation of the frame (the backward kernel reuses them). */
+ * per-channel counts of positive conv3 outputs, then the mean and the standard deviation of the frame (the backward kernel reuses them).
+ * a1_floats / a2_floats / i1_bytes: the per-frame sizes the caller allocated st_a1 / st_a2 / st_i1 with (what
+ *   ss_roi_cnn_stash_size returned).  The forward and the backward kernel each compare them with the layout THEY were
+ *   compiled with and return SS_ERR_ARG on a mismatch instead of writing / reading out of bounds (round 1 lost a GPU
+ *   process to two objects built against different versions of that layout: DESIGN.md section 9). */
 int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
                          const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
                          const float* bfc, int E, float* out, int ld_out, float* st_a1, uint8_t* st_i1,
-                         float* st_a2, uint8_t* st_i2, uint8_t* st_m3, float* st_feat, ss_stream_t stream);
+                         float* st_a2, uint8_t* st_i2, uint8_t* st_m3, float* st_feat, int a1_floats, int a2_floats,
+                         int i1_bytes, ss_stream_t stream);
 
 /* autograd of the above w.r.t. the eight parameter tensors (the uint8 input has no gradient),
  * i.e. what loss.backward() (train_model_official.py:437) leaves in roi_cnn.*.grad.
@@ -107,8 +112,8 @@ int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int standardize,
 int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
                    const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
                    const float* bfc, int E, const float* st_a1, const uint8_t* st_i1, const float* st_a2,
-                   const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat, const float* d_out,
-                   int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
+                   const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat, int a1_floats, int a2_floats,
+                   int i1_bytes, const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
                    float* g_wfc, float* g_bfc, ss_stream_t stream);
 
 /* ---- dense contraction used by a7/a9 and their gradients -----------------------------------
@@ -289,6 +294,11 @@ int ss_tail_bwd(const float* h, const int32_t* lengths, const float* w_score, co
  * correct (1) int32 accumulated: argmax == y count (train_model_official.py:442). */
 int ss_ce_ls_fwd_bwd(const float* logits, const int64_t* y, int B, int C, float label_smoothing, float denom,
                      float* d_logits, float* loss_sum, int32_t* correct, ss_stream_t stream);
+
+/* a12: softmax over the classes + the k most probable of every clip, largest first
+ * (topk_from_logits, live_infer_official.py:223-226: softmax -> argsort descending -> first k).
+ * probs (B,k) f32, idx (B,k) int32 (class ids; -1 / 0 when k > C). */
+int ss_softmax_topk(const float* logits, int B, int C, int k, float* probs, int32_t* idx, ss_stream_t stream);
 
 /* sumsq (1) += sum x^2 over the flat gradient bucket (clip_grad_norm_'s global L2 norm). */
 int ss_sumsq_f32(const float* x, long n, float* sumsq, ss_stream_t stream);

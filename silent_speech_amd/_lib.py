@@ -27,10 +27,10 @@ SIGNATURES = {
     "ss_feature_fuse": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "ss_roi_crop_idx": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ss_roi_cnn_fwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i, _vp],
-    "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_vp],
+    "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_i, _i, _i, _vp],
     "ss_roi_cnn_set_max_workgroups": [_i],
     "ss_roi_cnn_stash_size": [_i, _i, _vp, _vp, _vp],
-    "ss_roi_cnn_bwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_vp, _i] + [_vp] * 8 + [_vp],
+    "ss_roi_cnn_bwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_i, _i, _i, _vp, _i] + [_vp] * 8 + [_vp],
     "ss_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
     "ss_gemm_f32_batched": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i,
                             _l, _l, _l, _l, _l, _vp],
@@ -58,6 +58,7 @@ SIGNATURES = {
     "ss_layernorm_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "ss_dropout": [_vp, _vp, _l, _f, _u64, _u64, _vp, _vp],
     "ss_ce_ls_fwd_bwd": [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
+    "ss_softmax_topk": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "ss_sumsq_f32": [_vp, _l, _vp, _vp],
     "ss_adam_clip": [_vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _f, _f, _i, _vp],
     "ss_copy_rows_f32": [_vp, _i, _vp, _i, _i, _i, _vp],

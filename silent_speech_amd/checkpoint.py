@@ -39,8 +39,22 @@ def load_classifier(path: str, device="cuda", roi_standardize: bool = True):
     return model, ckpt["id_to_label"], max_t, use_roi
 
 
+def softmax_topk(logits: torch.Tensor, k: int = 3) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``ss_softmax_topk`` over a (B, C) batch of logits on the device: -> (probs (B,k) f32, class ids (B,k) int32),
+    most probable first.  What the serving path returns for thousands of windows instead of raw logits."""
+    from . import _lib as L
+
+    if not logits.is_cuda:
+        raise RuntimeError("softmax_topk runs on the HIP device (there is no CPU path)")
+    lg = logits.detach().float().contiguous().reshape(-1, logits.shape[-1])
+    B, C = lg.shape
+    probs = torch.empty(B, k, device=lg.device, dtype=torch.float32)
+    idx = torch.empty(B, k, device=lg.device, dtype=torch.int32)
+    L.call("ss_softmax_topk", lg.data_ptr(), B, C, k, probs.data_ptr(), idx.data_ptr(), L.stream())
+    return probs, idx
+
+
 def topk_from_logits(logits: torch.Tensor, id_to_label: Dict[int, str], k: int = 3) -> List[Tuple[str, float]]:
-    probs = torch.softmax(logits.detach().float().reshape(-1), dim=-1)
-    order = torch.argsort(probs, descending=True)[:k].cpu().tolist()
-    probs = probs.cpu()
-    return [(id_to_label[int(i)], float(probs[i])) for i in order]
+    """live_infer_official.py:223-226 for one clip's logits (1, C): [(label, probability)] of the k most probable."""
+    probs, idx = softmax_topk(logits.reshape(1, -1), min(k, logits.numel()))
+    return [(id_to_label[int(i)], float(p)) for p, i in zip(probs[0].cpu().tolist(), idx[0].cpu().tolist())]

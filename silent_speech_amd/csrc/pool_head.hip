@@ -231,7 +231,54 @@ __global__ __launch_bounds__(256) void ce_ls_kernel(const float* __restrict__ lo
   if (correct && ok) atomicAdd(correct, 1);
 }
 
+// softmax + top-k of every logit row (live_infer_official.py:223-226): one wave per clip, probabilities as
+// exp(l - max) / sum like torch.softmax, k selection sweeps (largest first, lowest index among equals)
+__global__ __launch_bounds__(256) void softmax_topk_kernel(const float* __restrict__ logits, int B, int C, int k,
+                                                           float* __restrict__ probs, int32_t* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;  // whole waves leave together: no wave-wide operation below is left short of lanes
+  const float* lr = logits + (long)b * C;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, lr[c]);
+  m = wave_max(m);
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += expf(lr[c] - m);
+  se = wave_sum(se);
+  float last_v = INFINITY;
+  int last_i = -1;
+  for (int j = 0; j < k; ++j) {
+    // best entry that comes after (last_v, last_i) in the order "value descending, index ascending"
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+      const float v = lr[c];
+      const bool after = v < last_v || (v == last_v && c > last_i);
+      if (after && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+    }
+    const float wv = wave_max(bv);
+    int cand = (bv == wv) ? bi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    last_v = wv;
+    last_i = cand;
+    if (lane == 0) {
+      const bool have = cand != 0x7fffffff;
+      probs[(long)b * k + j] = have ? expf(wv - m) / se : 0.f;
+      idx[(long)b * k + j] = have ? cand : -1;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int ss_softmax_topk(const float* logits, int B, int C, int k, float* probs, int32_t* idx, ss_stream_t stream) {
+  SS_REQUIRE(logits && probs && idx && B > 0 && C > 0 && k > 0, SS_ERR_ARG);
+  SS_REQUIRE(k <= 64, SS_ERR_UNSUPPORTED);
+  hipLaunchKernelGGL(softmax_topk_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, B, C,
+                     k, probs, idx);
+  return ss_launch_status();
+}
 
 extern "C" int ss_attn_pool_fwd(const float* h, const int32_t* lengths, const float* w_score, const float* b_score,
                                 int B, int T, int D, float* attn, float* pooled, ss_stream_t stream) {

@@ -47,7 +47,7 @@ struct CnnFwdParams {
   int ld_out;
   // training stash (all null together)
   float* st_a1;     // [N][8][P1]  haloed LDS image of the pooled-1 map, as is
-  uint8_t* st_i1;   // [N][8][I1S] (plane stride I1S = H2*W2 + 4 bytes)
+  uint8_t* st_i1;   // [N][8][I1S] (plane stride Geom::I1S = H2*W2 bytes)
   float* st_a2;     // [N][16][P2] haloed LDS image of the pooled-2 map, as is
   uint8_t* st_i2;   // [N][H4][W4][16]  pixel-major: the backward pass consumes it next to its pixel-major da2
   uint8_t* st_m3;   // [N][P][32]  pixel-major, channels 24..31 unused: the backward turns 16 bytes into 16 floats of one pixel
@@ -451,7 +451,8 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
                                     const float* b1, const float* w2, const float* b2, const float* w3,
                                     const float* b3, const float* wfc, const float* bfc, int E, float* out,
                                     int ld_out, float* st_a1, uint8_t* st_i1, float* st_a2, uint8_t* st_i2,
-                                    uint8_t* st_m3, float* st_feat, ss_stream_t stream) {
+                                    uint8_t* st_m3, float* st_feat, int a1_floats, int a2_floats, int i1_bytes,
+                                    ss_stream_t stream) {
   SS_REQUIRE(R && w1 && b1 && w2 && b2 && w3 && b3 && wfc && bfc && out, SS_ERR_ARG);
   SS_REQUIRE(N > 0 && E > 0 && ld_out >= E, SS_ERR_ARG);
   SS_REQUIRE(E <= 64, SS_ERR_UNSUPPORTED);
@@ -464,8 +465,12 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
   p.E = E; p.out = out; p.ld_out = ld_out;
   p.st_a1 = st_a1; p.st_i1 = st_i1; p.st_a2 = st_a2; p.st_i2 = st_i2; p.st_m3 = st_m3; p.st_feat = st_feat;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define SS_DISPATCH(HH, WW) \
-  if (H == HH && W == WW) return launch_fwd<Geom<HH, WW>>(p, s);
+#define SS_DISPATCH(HH, WW)                                                                                      \
+  if (H == HH && W == WW) {                                                                                     \
+    using G_ = Geom<HH, WW>;                                                                                    \
+    SS_REQUIRE(!all || (a1_floats == 8 * G_::P1 && a2_floats == 16 * G_::P2 && i1_bytes == 8 * G_::I1S), SS_ERR_ARG); \
+    return launch_fwd<G_>(p, s);                                                                                \
+  }
   SS_CNN_SHAPES(SS_DISPATCH)
 #undef SS_DISPATCH
   return SS_ERR_UNSUPPORTED;
@@ -490,5 +495,5 @@ extern "C" int ss_roi_cnn_fwd(const uint8_t* R, int N, int H, int W, int standar
                               const float* wfc, const float* bfc, int E, float* out, int ld_out,
                               ss_stream_t stream) {
   return ss_roi_cnn_fwd_stash(R, N, H, W, standardize, w1, b1, w2, b2, w3, b3, wfc, bfc, E, out, ld_out, nullptr,
-                              nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                              nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, stream);
 }

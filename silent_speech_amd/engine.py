@@ -191,7 +191,7 @@ class Workspace:
             self.dZ = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
             if cfg.use_roi:
                 Hh, Ww = roi_hw
-                n_a1, n_a2, n_i1 = L.cnn_stash_sizes(Hh, Ww)  # the kernels' own LDS images, kept as they are
+                n_a1, n_a2, n_i1 = self.cnn_sizes = L.cnn_stash_sizes(Hh, Ww)  # the kernels' own LDS images, kept as they are
                 self.st_a1 = torch.empty(N, n_a1, **f32)
                 self.st_i1 = torch.empty(N, n_i1, **u8)
                 self.st_a2 = torch.empty(N, n_a2, **f32)
@@ -222,7 +222,7 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
         st = ([ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
                ws.st_m3.data_ptr(), ws.st_feat.data_ptr()] if stash else [None] * 6)
         L.call("ss_roi_cnn_fwd_stash", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
-               _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, s)
+               _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, *(ws.cnn_sizes if stash else (0, 0, 0)), s)
         if ws.train and ws.stagger:  # an event record is a barrier packet on this stream (~6 us): only when somebody waits for it
             ws.ev_cnn_fwd.record()
         layer_in, ld_in = ws_Z.data_ptr(), cfg.in_dim
@@ -373,7 +373,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                  "roi_cnn.net.6.weight", "roi_cnn.net.6.bias", "roi_cnn.fc.weight", "roi_cnn.fc.bias")
         L.call("ss_roi_cnn_bwd", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
                cfg.roi_emb, ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
-               ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
+               ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), *ws.cnn_sizes, _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
                *[G[k].data_ptr() for k in names], s)
     # join the side stream: the caller's next kernels (all-reduce, clip, Adam) read every gradient
     if USE_SIDE_STREAM and not side_joined:

@@ -91,22 +91,29 @@ def class_balanced_indices(labels: Sequence[str], num_samples: Optional[int] = N
 @torch.no_grad()
 def evaluate(model: BiGRUClassifier, store: DeviceClipStore, batch_size: int = BATCH_SIZE, label_smoothing: float = 0.05):
     """-> (mean loss, accuracy, y_true, y_pred) over every clip of ``store``, in order, eval mode, no augmentation."""
+    from . import _lib as L
+    from .checkpoint import softmax_topk
+
     was_training = model.training
     model.eval()
-    loss_sum, ok, y_true, y_pred = 0.0, 0, [], []
+    y_true, y_pred = [], []
+    dev = model.flat_params.device
+    loss_sum = torch.zeros(1, device=dev, dtype=torch.float32)   # sum of the per-clip losses (denom = 1)
+    correct = torch.zeros(1, device=dev, dtype=torch.int32)
     for lo in range(0, len(store), batch_size):
         idx = list(range(lo, min(len(store), lo + batch_size)))
         X, T, R, y = store.batch(idx, augment=False)
-        logits = model(X, T, R if model.use_roi else None)
-        loss = torch.nn.functional.cross_entropy(logits, y, label_smoothing=label_smoothing)
-        loss_sum += float(loss) * len(idx)
-        pred = logits.argmax(dim=1)
-        ok += int((pred == y).sum())
+        logits = model(X, T, R if model.use_roi else None).contiguous()
+        y = y.to(torch.int64).contiguous()
+        # loss and hit count by the path's own cross-entropy kernel, predictions by its top-k kernel (no aten op)
+        L.call("ss_ce_ls_fwd_bwd", logits.data_ptr(), y.data_ptr(), logits.shape[0], logits.shape[1], label_smoothing, 1.0,
+               None, loss_sum.data_ptr(), correct.data_ptr(), L.stream())
+        _, top = softmax_topk(logits, 1)
         y_true += y.cpu().tolist()
-        y_pred += pred.cpu().tolist()
+        y_pred += top[:, 0].cpu().tolist()
     model.train(was_training)
     n = max(1, len(store))
-    return loss_sum / n, ok / n, y_true, y_pred
+    return float(loss_sum) / n, int(correct) / n, y_true, y_pred
 
 
 def fit(clip_dir: str, out_path: str, epochs: int = EPOCHS, batch_size: int = BATCH_SIZE, patience: int = PATIENCE,

@@ -22,7 +22,7 @@ class GraphedInference:
     Inputs are copied into static device buffers (or written there directly through ``g.X / g.lengths / g.R``) and
     the captured forward is replayed; ``logits`` is the static output buffer (clone it to keep it across calls)."""
 
-    def __init__(self, model: BiGRUClassifier, B: int, T: int, roi_hw=None, warmup: int = 2):
+    def __init__(self, model: BiGRUClassifier, B: int, T: int, roi_hw=None, warmup: int = 2, topk: int = 0):
         if model.flat_params is None or not model.flat_params.is_cuda:
             raise RuntimeError("GraphedInference needs the model on a HIP device")
         if model.use_roi and roi_hw is None:
@@ -34,6 +34,11 @@ class GraphedInference:
         self.lengths = torch.full((B,), T, device=dev, dtype=torch.int32)
         self.R = torch.zeros(B, T, *roi_hw, device=dev, dtype=torch.uint8) if model.use_roi else None
         self.ws = E.Workspace(cfg, B, T, tuple(roi_hw) if roi_hw else None, dev, train=False)
+        # topk > 0: softmax + the k most probable classes of every window are part of the captured graph
+        # (live_infer_official.py:223-226 for every window), read from ``top_probs`` / ``top_idx`` after a call
+        self.topk = min(int(topk), cfg.num_classes)
+        self.top_probs = torch.zeros(B, self.topk, device=dev) if self.topk else None
+        self.top_idx = torch.zeros(B, self.topk, device=dev, dtype=torch.int32) if self.topk else None
         self._P = model._param_dict()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
@@ -48,7 +53,11 @@ class GraphedInference:
 
     def _run(self) -> torch.Tensor:
         self.ws.lengths.copy_(self.lengths)
-        return E.forward(self._P, self.model.cfg, self.ws, self.X, self.R, train=False, stash=False)
+        logits = E.forward(self._P, self.model.cfg, self.ws, self.X, self.R, train=False, stash=False)
+        if self.topk:
+            E.L.call("ss_softmax_topk", logits.data_ptr(), self.B, self.model.cfg.num_classes, self.topk,
+                     self.top_probs.data_ptr(), self.top_idx.data_ptr(), E.L.stream())
+        return logits
 
     def __call__(self, X: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
                  R: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -322,6 +322,47 @@ def gen_harness(tmo):
     print("wrote harness: val sizes", len(out["split42::val"]), len(out["split7::val"]), "top3", out["conf::top3"])
 
 
+# ------------------------------------------------------------------ checkpoint written by the build -> reference loader
+def gen_loader(live):
+    """A ``.pt`` written by the BUILD's ``save_checkpoint`` goes through the reference's own ``load_classifier``
+    (live_infer_official.py:198-221, torch.load with its defaults) and ``topk_from_logits`` (:223-226): stores the logits
+    the reference computes from that file on a fixed clip and its top-3, plus top-3 of a few free logit rows."""
+    repo = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, repo)
+    import silent_speech_amd as ss  # CPU instance: parameter container + checkpoint writer only
+
+    seed, x_dim, C, hw, B, T = 31, 84, 7, (48, 96), 2, 9
+    labels = ["aura", "go", "help", "no", "stop", "water", "yes"]
+    out = dict(seed=seed, x_dim=x_dim, num_classes=C, B=B, T=T, labels=np.asarray(labels))
+    for layers in (1, 2):
+        sd = W.make_state_dict(seed + layers, x_dim, C, True, gru_layers=layers)
+        m = ss.BiGRUClassifier(x_dim, C, use_roi=True, gru_layers=layers)
+        m.load_state_dict(sd)
+        X, L, R, _ = W.make_inputs(seed + layers, B, T, x_dim, C, hw, lengths=[T, 5])
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "word_model_points_roi.pt")
+            ss.save_checkpoint(path, m, labels, max_t=90, roi_w=hw[1], roi_h=hw[0], seed=42)
+            ref_model, id_to_label, max_t, use_roi = live.load_classifier(path)
+        assert max_t == 90 and use_roi and [id_to_label[i] for i in range(C)] == labels
+        with torch.no_grad():
+            logits = ref_model(X, L, R)
+        out[f"l{layers}::logits"] = logits.numpy()
+        for b in range(B):
+            top = live.topk_from_logits(logits[b:b + 1], id_to_label, k=3)
+            out[f"l{layers}::top_labels{b}"] = np.asarray([t[0] for t in top])
+            out[f"l{layers}::top_probs{b}"] = np.asarray([t[1] for t in top], np.float64)
+    g = torch.Generator().manual_seed(9)
+    free = torch.randn(16, C, generator=g) * 3.0
+    id_to_label = {i: lab for i, lab in enumerate(labels)}
+    out["free::logits"] = free.numpy()
+    out["free::top_idx"] = np.asarray([[labels.index(t[0]) for t in live.topk_from_logits(free[b:b + 1], id_to_label, k=3)]
+                                       for b in range(16)])
+    out["free::top_probs"] = np.asarray([[t[1] for t in live.topk_from_logits(free[b:b + 1], id_to_label, k=3)]
+                                         for b in range(16)], np.float64)
+    np.savez_compressed(os.path.join(HERE, "loader.npz"), **out)
+    print("wrote loader: top-3 of clip 0", out["l2::top_labels0"], out["l2::top_probs0"])
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -333,6 +374,7 @@ def main():
     gen_crop(rec, live)
     gen_dataset(tmo)
     gen_harness(tmo)
+    gen_loader(live)
 
 
 if __name__ == "__main__":

@@ -603,7 +603,11 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     st_feat = torch.empty(N, 52, device="cuda")  # 24 features, 24 positive-output counts, frame mean / std, pad
     st = [st_a1, st_i1, st_a2, st_i2, st_m3, st_feat]
     L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out.data_ptr(), 32,
-           *[s.data_ptr() for s in st], L.stream())
+           *[s.data_ptr() for s in st], n_a1, n_a2, n_i1, L.stream())
+    # a caller whose buffers were sized for another layout is turned away, not written over
+    with pytest.raises(RuntimeError, match="ss_roi_cnn_fwd_stash"):
+        L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out.data_ptr(), 32,
+               *[s.data_ptr() for s in st], n_a1 - 8, n_a2, n_i1, L.stream())
     sync()
     assert_close("roi_e", out, out_ref, atol=2e-5, rtol=1e-4)
 
@@ -640,8 +644,11 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     assert int(st_m3[:, :, 24:].sum()) == 0
 
     G = [torch.zeros_like(p) for p in P]
+    with pytest.raises(RuntimeError, match="ss_roi_cnn_bwd"):
+        L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
+               n_a1, n_a2, n_i1 + 32, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
     L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
-           dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
+           n_a1, n_a2, n_i1, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
     sync()
     for k, gg in zip(CNN_KEYS, G):
         ref = leaves[k].grad
@@ -649,7 +656,7 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
         assert_close("grad " + k, gg, ref, atol=3e-4 * max(scale, 1e-3), rtol=1e-3)
     # gradients accumulate: a second call doubles them
     L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
-           dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
+           n_a1, n_a2, n_i1, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
     sync()
     assert_close("accumulate", G[4], 2 * leaves[CNN_KEYS[4]].grad, atol=6e-4 * float(leaves[CNN_KEYS[4]].grad.abs().max()),
                  rtol=1e-3)

@@ -229,6 +229,43 @@ def test_one_rank_rccl_trainer_equals_single_process(ss, tmp_path):
         assert float((v.cpu() - got["sd"][k]).abs().max()) <= atol, k
 
 
+@pytest.mark.parametrize("layers", [1, 2])
+def test_checkpoint_and_topk_against_the_reference_loader(ss, golden_dir, layers, tmp_path):
+    """a11 + a12 pinned: tests/golden/loader.npz holds what the REFERENCE's load_classifier / forward / topk_from_logits
+    (live_infer_official.py:198-226) made of a ``.pt`` this build wrote.  Same file, this build's loader and kernels."""
+    d = np.load(os.path.join(golden_dir, "loader.npz"), allow_pickle=False)
+    seed, x_dim, C, B, T = int(d["seed"]), int(d["x_dim"]), int(d["num_classes"]), int(d["B"]), int(d["T"])
+    labels = [str(x) for x in d["labels"]]
+    sd = W.make_state_dict(seed + layers, x_dim, C, True, gru_layers=layers)
+    X, Lh, R, _ = W.make_inputs(seed + layers, B, T, x_dim, C, (48, 96), lengths=[T, 5])
+    m0 = ss.BiGRUClassifier(x_dim, C, use_roi=True, gru_layers=layers)
+    m0.load_state_dict(sd)
+    path = str(tmp_path / "word_model_points_roi.pt")
+    ss.save_checkpoint(path, m0, labels, max_t=90, roi_w=96, roi_h=48, seed=42)
+    model, id_to_label, max_t, use_roi = ss.load_classifier(path, roi_standardize=False)  # the live script's forward
+    assert max_t == 90 and use_roi and model.cfg.gru_layers == layers
+    with torch.no_grad():
+        logits = model(X.cuda(), Lh, R.cuda())
+    assert float((logits.cpu() - torch.from_numpy(d[f"l{layers}::logits"])).abs().max()) < TIGHT
+    for b in range(B):
+        top = ss.topk_from_logits(logits[b:b + 1], id_to_label, k=3)
+        assert [t[0] for t in top] == [str(x) for x in d[f"l{layers}::top_labels{b}"]]
+        np.testing.assert_allclose([t[1] for t in top], d[f"l{layers}::top_probs{b}"], rtol=2e-4)
+    # free logit rows: the kernel against the reference's softmax / argsort
+    from silent_speech_amd.checkpoint import softmax_topk
+
+    probs, idx = softmax_topk(torch.from_numpy(d["free::logits"]).cuda(), 3)
+    assert np.array_equal(idx.cpu().numpy(), d["free::top_idx"])
+    np.testing.assert_allclose(probs.cpu().numpy(), d["free::top_probs"], rtol=3e-6)
+    # k > C and wide rows (C > 64: more than one class per lane)
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn(5, 300, generator=g)
+    p2, i2 = softmax_topk(wide.cuda(), 5)
+    ref = torch.softmax(wide, -1)
+    order = torch.argsort(ref, dim=1, descending=True)[:, :5]
+    assert torch.equal(i2.cpu().long(), order) and float((p2.cpu() - ref.gather(1, order)).abs().max()) < 1e-7
+
+
 def test_padding_never_leaks_and_batch_permutes(ss, golden_dir):
     d, sd, X, Lh, R, y = load_case(golden_dir, "model_roi64")
     m = build(ss, d, sd)
@@ -372,9 +409,13 @@ def test_hipgraph_inference_equals_eager(ss):
     Xd, Rd = X.cuda(), R.cuda()
     with torch.no_grad():
         eager = m(Xd, Lh, Rd)
-    g = ss.GraphedInference(m, B, T, (64, 64))
+    g = ss.GraphedInference(m, B, T, (64, 64), topk=3)
     out1 = g(Xd, Lh, Rd).clone()
     assert torch.equal(out1, eager)
+    # softmax + top-3 of every window ride in the same graph (live_infer_official.py:223-226 per window)
+    pr = torch.softmax(eager, -1)
+    order = torch.argsort(pr, dim=1, descending=True)[:, :3]
+    assert torch.equal(g.top_idx.long(), order) and float((g.top_probs - pr.gather(1, order)).abs().max()) < 1e-6
     # replay on new window contents and ragged lengths without re-capturing
     X2, L2, R2, _ = W.make_inputs(14, B, T, 84, 5, (64, 64))
     with torch.no_grad():
