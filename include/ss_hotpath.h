@@ -199,14 +199,33 @@ int ss_batch_gather_u8(const uint8_t* src, int frame_bytes, const int32_t* frame
  * and a count: the deque(maxlen=max_t) of inactive/live_feed.py:155.  A push appends one frame for each of n DISTINCT
  * streams (feats (n,D), rois (n,frame_bytes)) and bumps frames_seen; the window map lists, oldest first, the rows of the
  * rings of n selected streams (-1 = zero padding; live_feed.py:203-207) for ss_batch_gather_f32/u8, lengths = frames held.
- * ss_mouth_gate: EMA (alpha) of the mouth openness and its open/close hysteresis (important_landmarks.py:136-144). */
+ * ss_mouth_openness: the openness signal itself, float64 like the reference's Python floats.  lm (n,K,2) f32 normalised
+ *   (x,y) landmarks; mode 0: |y[i_bot] - y[i_top]| / (dist2d(lm[i_eye_l], lm[i_eye_r]) + 1e-6)
+ *   (important_landmarks.py:64-67, 131-133; within one ulp of its ``** 0.5``); mode 1: max(y) - min(y) over the K
+ *   landmarks (inactive/live_test_5.py:92-94; the i_* arguments are ignored).
+ * ss_mouth_gate: EMA (alpha) of the openness and its open/close hysteresis, carried in float64
+ *   (important_landmarks.py:136-144: ``mouth_ema`` is a Python float).
+ * ss_clip_gate: openness-gated clip segmentation of n DISTINCT streams (inactive/live_test_5.py:146-152, 233-272):
+ *   state (S,4) int32 = {speaking, above_ct, below_ct, clip_len}, zero-initialised.  Per pushed frame:
+ *   openv > open_thresh bumps above_ct and clears below_ct, else the reverse; idle streams start a clip (clip_len = 0)
+ *   after start_n consecutive frames above -- the starting frame itself is not kept; speaking streams append the frame
+ *   (feats row -> clip_x (S,max_clip,D), rois -> clip_r (S,max_clip,frame_bytes)) and stop after end_n consecutive
+ *   frames below or at max_clip frames.  append_row (n): row written, -1 if none; emit_len (n): length of the clip that
+ *   just ended if >= min_clip (the reference classifies clips of >= 6 frames), else 0.  face_present (n) u8 may be
+ *   NULL; 0 resets the stream (the "NO FACE" branch, :293-301). */
 int ss_ring_push(float* ring_x, uint8_t* ring_r, int n_streams, int max_t, int D, int frame_bytes,
                  const int32_t* stream_ids, int n, const float* feats, const uint8_t* rois, int32_t* head, int32_t* count,
                  int32_t* frames_seen, ss_stream_t stream);
 int ss_ring_window_map(const int32_t* stream_ids, int n, int max_t, const int32_t* head, const int32_t* count,
                        int32_t* frame_map, int64_t* lengths, ss_stream_t stream);
-int ss_mouth_gate(const int32_t* stream_ids, int n, const float* openness, float alpha, float open_thr, float close_thr,
-                  float* ema, uint8_t* state_open, ss_stream_t stream);
+int ss_mouth_openness(const float* lm, int n, int K, int mode, int i_top, int i_bot, int i_eye_l, int i_eye_r,
+                      double* openness, ss_stream_t stream);
+int ss_mouth_gate(const int32_t* stream_ids, int n, const double* openness, double alpha, double open_thr,
+                  double close_thr, double* ema, uint8_t* state_open, ss_stream_t stream);
+int ss_clip_gate(const int32_t* stream_ids, int n, const double* openv, const uint8_t* face_present, double open_thresh,
+                 int start_n, int end_n, int max_clip, int min_clip, int32_t* state, int D, int frame_bytes,
+                 const float* feats, const uint8_t* rois, float* clip_x, uint8_t* clip_r, int32_t* append_row,
+                 int32_t* emit_len, ss_stream_t stream);
 
 /* ---- a7: one bidirectional GRU layer, recurrence only ---------------------------------------
  * replaces pack_padded_sequence -> nn.GRU -> pad_packed_sequence (train_model_official.py:301-305).

@@ -6,13 +6,13 @@ Drop-in surface of the reference's per-clip path:
 All arithmetic runs in ``libss_hotpath.so`` (hand-written HIP, C ABI in ``include/ss_hotpath.h``);
 there is no CPU or PyTorch-op fallback.
 """
-from . import checkpoint, data, features, harness
+from . import checkpoint, data, features, harness, serving
 from .checkpoint import load_classifier, save_checkpoint, topk_from_logits
 from .device_data import DeviceClipStore
 from .engine import Config
 from .features import crop_boxes, crop_rois, extract_features
 from .infer import GraphedInference
-from .serving import StreamServer
+from .serving import ClipGateServer, StreamServer, mouth_openness
 from .model import AttnPool, BiGRUClassifier, TinyROICNN
 from .train import Trainer, allreduce_flat_grads, shard_range
 

@@ -19,6 +19,7 @@ _i = C.c_int
 _f = C.c_float
 _l = C.c_long
 _u64 = C.c_uint64
+_d = C.c_double
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
 SIGNATURES = {
@@ -45,7 +46,9 @@ SIGNATURES = {
     "ss_crop_gray_resize": [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp],
     "ss_ring_push": [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_ring_window_map": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "ss_mouth_gate": [_vp, _i, _vp, _f, _f, _f, _vp, _vp, _vp],
+    "ss_mouth_openness": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "ss_mouth_gate": [_vp, _i, _vp, _d, _d, _d, _vp, _vp, _vp],
+    "ss_clip_gate": [_vp, _i, _vp, _vp, _d, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_gru_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "ss_gru_sync_bytes": [_i, _i, _i, _vp],
     "ss_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -18,6 +18,24 @@ from . import _lib as L
 from .model import BiGRUClassifier
 
 PRED_EVERY, EMA_ALPHA, OPEN_THR, CLOSE_THR = 2, 0.25, 0.02, 0.02
+# important_landmarks.py:49-54: landmark ids of the openness signal
+MOUTH_TOP, MOUTH_BOTTOM, LEFT_EYE_CORNER, RIGHT_EYE_CORNER = 13, 14, 33, 263
+# inactive/live_test_5.py:146-150 and :256 (clips shorter than 6 frames are not classified)
+OPEN_THRESH, START_N, END_N, MAX_CLIP, MIN_CLIP = 0.18, 3, 5, 60, 6
+
+
+def mouth_openness(landmarks: torch.Tensor, mode: str = "eye_span", idx=(MOUTH_TOP, MOUTH_BOTTOM, LEFT_EYE_CORNER, RIGHT_EYE_CORNER)):
+    """(n, K, 2) f32 normalised landmarks on the device -> (n,) float64 openness.  ``eye_span``:
+    important_landmarks.py:131-133 (lip gap over the eye-corner distance; ``idx`` = positions of landmarks 13, 14, 33, 263
+    in the K given); ``y_range``: inactive/live_test_5.py:92-94 (max y - min y over the K landmarks)."""
+    if not landmarks.is_cuda:
+        raise RuntimeError("mouth_openness runs on the HIP device (there is no CPU path)")
+    lm = landmarks.to(torch.float32).contiguous()
+    n, K, _ = lm.shape
+    out = torch.empty(n, device=lm.device, dtype=torch.float64)
+    L.call("ss_mouth_openness", lm.data_ptr(), n, K, 0 if mode == "eye_span" else 1, *[int(v) for v in idx], out.data_ptr(),
+           L.stream())
+    return out
 
 
 class StreamServer:
@@ -34,7 +52,7 @@ class StreamServer:
         self.head = torch.zeros(n_streams, device=dev, dtype=torch.int32)
         self.count = torch.zeros(n_streams, device=dev, dtype=torch.int32)
         self.frames_seen = torch.zeros(n_streams, device=dev, dtype=torch.int32)
-        self.ema = torch.zeros(n_streams, device=dev)
+        self.ema = torch.zeros(n_streams, device=dev, dtype=torch.float64)  # a Python float in the reference
         self.mouth_open = torch.zeros(n_streams, device=dev, dtype=torch.uint8)
         # host mirrors of the two counters decide who is due without reading the device back
         self._count = np.zeros(n_streams, np.int64)
@@ -57,7 +75,7 @@ class StreamServer:
                feats.data_ptr(), L.ptr(rois) if self.ring_r is not None else None, self.head.data_ptr(), self.count.data_ptr(),
                self.frames_seen.data_ptr(), L.stream())
         if openness is not None:
-            op = openness.to(dev, torch.float32).contiguous()
+            op = openness.to(dev, torch.float64).contiguous()
             L.call("ss_mouth_gate", ids_d.data_ptr(), n, op.data_ptr(), EMA_ALPHA, OPEN_THR, CLOSE_THR, self.ema.data_ptr(),
                    self.mouth_open.data_ptr(), L.stream())
         self._count[ids] = np.minimum(self._count[ids] + 1, self.max_t)
@@ -88,3 +106,55 @@ class StreamServer:
             L.call("ss_batch_gather_u8", self.ring_r.data_ptr(), H * W, fmap.data_ptr(), n * mt, R.data_ptr(), L.stream())
         X._ss_keep = (ids_d, fmap)
         return X, T, R
+
+
+class ClipGateServer:
+    """Openness-gated clip segmentation of S streams + batched classification of the clips that end
+    (inactive/live_test_5.py:233-272, one state machine per camera there).  ``push`` takes one frame for each of the
+    given streams -- feature rows, optional ROI frames, the openness value (``mouth_openness``) -- advances every
+    stream's machine in one launch (``ss_clip_gate``), and runs ONE forward over the clips that ended in this tick with
+    at least ``min_clip`` frames (lengths = clip lengths, so the padding never reaches the recurrence)."""
+
+    def __init__(self, model: BiGRUClassifier, n_streams: int, roi_hw=None, open_thresh: float = OPEN_THRESH,
+                 start_n: int = START_N, end_n: int = END_N, max_clip: int = MAX_CLIP, min_clip: int = MIN_CLIP, device="cuda"):
+        L.load()
+        self.model, self.S, self.roi_hw = model.eval(), n_streams, roi_hw
+        self.open_thresh, self.start_n, self.end_n, self.max_clip, self.min_clip = open_thresh, start_n, end_n, max_clip, min_clip
+        self.D = model.cfg.x_dim
+        dev = self.device = torch.device(device)
+        self.state = torch.zeros(n_streams, 4, device=dev, dtype=torch.int32)  # speaking, above_ct, below_ct, clip_len
+        self.clip_x = torch.zeros(n_streams, max_clip, self.D, device=dev)
+        self.clip_r = torch.zeros(n_streams, max_clip, roi_hw[0], roi_hw[1], device=dev, dtype=torch.uint8) if roi_hw else None
+
+    def push(self, stream_ids: Sequence[int], feats: torch.Tensor, openness: torch.Tensor, rois: Optional[torch.Tensor] = None,
+             face_present: Optional[torch.Tensor] = None):
+        """-> (append_row (n,) int32, emit_len (n,) int32, result) with result None or (ids, logits, lengths) of the clips
+        that ended in this tick."""
+        ids = np.asarray(stream_ids, np.int32)
+        n = len(ids)
+        if len(set(ids.tolist())) != n:
+            raise ValueError("one frame per stream and tick")
+        dev = self.device
+        ids_d = torch.from_numpy(ids).to(dev)
+        feats = feats.to(dev, torch.float32).contiguous()
+        op = openness.to(dev, torch.float64).contiguous()
+        rois = rois.to(dev).contiguous() if (rois is not None and self.clip_r is not None) else None
+        face = face_present.to(dev, torch.uint8).contiguous() if face_present is not None else None
+        fb = self.roi_hw[0] * self.roi_hw[1] if self.roi_hw else 0
+        row = torch.empty(n, device=dev, dtype=torch.int32)
+        emit = torch.empty(n, device=dev, dtype=torch.int32)
+        L.call("ss_clip_gate", ids_d.data_ptr(), n, op.data_ptr(), L.ptr(face), float(self.open_thresh), self.start_n, self.end_n,
+               self.max_clip, self.min_clip, self.state.data_ptr(), self.D, fb, feats.data_ptr(), L.ptr(rois),
+               self.clip_x.data_ptr(), L.ptr(self.clip_r) if rois is not None else None, row.data_ptr(), emit.data_ptr(), L.stream())
+        emit_h = emit.cpu().numpy()  # the one read-back of a tick: which clips ended
+        done = np.flatnonzero(emit_h > 0)
+        if len(done) == 0:
+            return row, emit, None
+        sel = torch.from_numpy(ids[done].astype(np.int64)).to(dev)
+        X = self.clip_x.index_select(0, sel)
+        T = torch.from_numpy(emit_h[done].astype(np.int64)).to(dev)
+        # rows past a clip's length still hold older clips' frames: lengths keep them out of the recurrence and the pool
+        R = self.clip_r.index_select(0, sel) if (self.clip_r is not None and self.model.use_roi) else None
+        with torch.no_grad():
+            logits = self.model(X, T, R)
+        return row, emit, (ids[done], logits, T)

@@ -509,7 +509,8 @@ def test_stream_server_matches_the_restated_loop(ss):
             continue
         feats = rng.normal(size=(len(ids), Dm)).astype(np.float32)
         rois = rng.integers(0, 256, (len(ids),) + hw, dtype=np.uint8)
-        op = (0.02 + 0.02 * rng.normal(size=len(ids))).astype(np.float32)
+        # float64 openness hovering around the open/close thresholds (0.02): a float32 EMA decides differently here
+        op = 0.02 + np.where(rng.random(len(ids)) < 0.5, 1e-9, 0.02) * rng.normal(size=len(ids))
         got = srv.push(ids, torch.from_numpy(feats), torch.from_numpy(rois), torch.from_numpy(op))
         want = {int(s): refs[s].push(feats[k], rois[k], float(op[k])) for k, s in enumerate(ids)}
         due = [s for s, w in want.items() if w is not None]
@@ -525,6 +526,119 @@ def test_stream_server_matches_the_restated_loop(ss):
         ref = MR.forward(sd, X.cpu(), T.cpu(), R.cpu(), impl="aten")
         assert float((logits.cpu() - ref).abs().max()) < TIGHT
         n_pred += len(due)
-        assert np.array_equal(srv.ema.cpu().numpy(), np.asarray([r.ema for r in refs], np.float32))
+        assert np.array_equal(srv.ema.cpu().numpy(), np.asarray([r.ema for r in refs], np.float64))  # bit for bit, float64
         assert srv.mouth_open.cpu().numpy().astype(bool).tolist() == [r.open for r in refs]
     assert n_pred > 40
+
+
+def test_mouth_gate_is_float64_near_the_thresholds(ss):
+    """the reference's ``mouth_ema`` is a Python float.  Traces built to land the EMA within a few
+    float64 ulps of the thresholds -- where a float32 EMA flips the other way -- must give the restated loop's states."""
+    from oracle import stream_ref as SR
+    from silent_speech_amd import _lib as L
+
+    rng = np.random.default_rng(0)
+    S, ticks = 64, 200
+    refs = [SR.StreamRef(4, 1) for _ in range(S)]
+    ids = torch.arange(S, dtype=torch.int32, device="cuda")
+    ema = torch.zeros(S, device="cuda", dtype=torch.float64)
+    st = torch.zeros(S, device="cuda", dtype=torch.uint8)
+    flips32 = 0
+    ema32 = np.zeros(S, np.float32)
+    for t in range(ticks):
+        # choose the openness that would put the EMA at threshold * (1 + k * 2^-52), k in [-3, 3], for half the streams
+        prev = np.asarray([r.ema for r in refs])
+        target = 0.02 * (1.0 + rng.integers(-3, 4, S) * 2.0 ** -52)
+        op = np.where(rng.random(S) < 0.5, (target - 0.75 * prev) / 0.25, rng.uniform(0.0, 0.05, S))
+        for s_, r in enumerate(refs):
+            r.push(np.zeros(1, np.float32), None, float(op[s_]))
+        opd = torch.from_numpy(op).cuda()
+        L.call("ss_mouth_gate", ids.data_ptr(), S, opd.data_ptr(), 0.25, 0.02, 0.02, ema.data_ptr(), st.data_ptr(), L.stream())
+        assert np.array_equal(ema.cpu().numpy(), np.asarray([r.ema for r in refs]))
+        assert st.cpu().numpy().astype(bool).tolist() == [r.open for r in refs], t
+        ema32 = (np.float32(0.75) * ema32 + np.float32(0.25) * op.astype(np.float32)).astype(np.float32)
+        flips32 += int(((ema32 > np.float32(0.02)) != (np.asarray([r.ema for r in refs]) > 0.02)).sum())
+    assert flips32 > 0, "the traces never separated a float32 EMA from the float64 one"
+
+
+def test_mouth_openness_kernel(ss):
+    """important_landmarks.py:131-133 / live_test_5.py:92-94 on synthetic faces against the literal Python-float restatement:
+    the y-range form bit for bit, the eye-span form to one ulp (its ``** 0.5`` is libm pow, the kernel takes sqrt)."""
+    from oracle import stream_ref as SR
+    from silent_speech_amd.serving import mouth_openness
+
+    rng = np.random.default_rng(2)
+    n, K = 300, 478
+    lm = rng.uniform(0.2, 0.8, (n, K, 2)).astype(np.float32)
+    lm[:5, 14, 1] = lm[:5, 13, 1]          # closed mouth: exactly 0
+    lm[5:8, 263] = lm[5:8, 33]             # degenerate eye span: the 1e-6 guard
+    got = mouth_openness(torch.from_numpy(lm).cuda(), "eye_span").cpu().numpy()
+    want = np.asarray([SR.openness_eye_span(lm[i]) for i in range(n)])
+    assert got.dtype == np.float64 and np.all(got[:5] == 0.0)
+    assert np.all(np.abs(got - want) <= 2.3e-16 * np.abs(want)), float(np.max(np.abs(got - want) / np.maximum(want, 1e-300)))
+    assert (got == want).mean() > 0.99
+    idx = rng.choice(K, 88, replace=False)
+    sub = np.ascontiguousarray(lm[:, idx])
+    got2 = mouth_openness(torch.from_numpy(sub).cuda(), "y_range").cpu().numpy()
+    assert np.array_equal(got2, np.asarray([SR.openness_y_range(sub[i]) for i in range(n)]))
+
+
+def test_clip_gate_server_matches_the_restated_state_machine(ss):
+    """inactive/live_test_5.py:233-272 batched over 9 streams: random open/close traces (runs of open frames of random
+    length, values within an ulp of OPEN_THRESH, missing faces, clips cut at MAX_CLIP) give the same appends, the same
+    finished clips (bit for bit) and logits of those clips within the forward's tolerance."""
+    from oracle import stream_ref as SR
+
+    rng = np.random.default_rng(8)
+    S, Dm, hw, max_clip = 9, 84, (32, 32), 20
+    sd = W.make_state_dict(3, Dm, 5, True)
+    m = ss.BiGRUClassifier(Dm, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    srv = ss.serving.ClipGateServer(m, S, roi_hw=hw, max_clip=max_clip)
+    refs = [SR.ClipGateRef(max_clip=max_clip) for _ in range(S)]
+    rrefs = [[] for _ in range(S)]  # ROI frames of the clip being collected, kept beside the restated machine
+    level = rng.random(S) < 0.5
+    n_clips = n_cut = 0
+    for tick in range(260):
+        ids = np.flatnonzero(rng.random(S) < 0.9)
+        if len(ids) == 0:
+            continue
+        level ^= rng.random(S) < 0.12  # open/closed runs
+        base = np.where(level[ids], 0.3, 0.05)
+        near = rng.random(len(ids)) < 0.2
+        op = np.where(near, 0.18 * (1.0 + rng.integers(-2, 3, len(ids)) * 2.0 ** -52), base + 0.02 * rng.normal(size=len(ids)))
+        face = (rng.random(len(ids)) > 0.02).astype(np.uint8)
+        feats = rng.normal(size=(len(ids), Dm)).astype(np.float32)
+        rois = rng.integers(0, 256, (len(ids),) + hw, dtype=np.uint8)
+        row, emit, res = srv.push(ids, torch.from_numpy(feats), torch.from_numpy(op), torch.from_numpy(rois), torch.from_numpy(face))
+        row, emit = row.cpu().numpy(), emit.cpu().numpy()
+        done = {}
+        for k, s_ in enumerate(ids):
+            was_speaking = refs[s_].speaking
+            n_before = len(refs[s_].clip_buf)
+            appended, clip = refs[s_].push(float(op[k]), feats[k], bool(face[k]))
+            if not face[k] or (not was_speaking and refs[s_].speaking):
+                rrefs[s_] = []
+            assert (row[k] >= 0) == appended and (not appended or row[k] == n_before)
+            if appended:
+                rrefs[s_].append(rois[k])
+            assert int(emit[k]) == (0 if clip is None else len(clip))
+            if clip is not None:
+                done[int(s_)] = (clip, np.stack(rrefs[s_]))
+                n_cut += len(clip) == max_clip
+        if not done:
+            assert res is None
+            continue
+        g_ids, logits, T = res
+        assert g_ids.tolist() == list(done.keys())
+        Xr = np.zeros((len(done), max_clip, Dm), np.float32)
+        Rr = np.zeros((len(done), max_clip) + hw, np.uint8)
+        for k, (clip, rr) in enumerate(done.values()):
+            assert np.array_equal(srv.clip_x[g_ids[k], :len(clip)].cpu().numpy(), clip)
+            assert np.array_equal(srv.clip_r[g_ids[k], :len(clip)].cpu().numpy(), rr)
+            Xr[k, :len(clip)], Rr[k, :len(clip)] = clip, rr
+        ref = MR.forward(sd, torch.from_numpy(Xr), T.cpu(), torch.from_numpy(Rr), impl="aten")
+        assert float((logits.cpu() - ref).abs().max()) < TIGHT
+        n_clips += len(done)
+    assert n_clips >= 10 and n_cut >= 1, (n_clips, n_cut)
