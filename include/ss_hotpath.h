@@ -227,6 +227,34 @@ int ss_clip_gate(const int32_t* stream_ids, int n, const double* openv, const ui
                  const float* feats, const uint8_t* rois, float* clip_x, uint8_t* clip_r, int32_t* append_row,
                  int32_t* emit_len, ss_stream_t stream);
 
+/* ---- BASELINE config 5 (100 words, 96x96 ROI, CNN 16/32/64/96, BiGRU H = 512, bf16 MFMA) ----------------------
+ * The reference defines no such model ("build-defined"); it is the same module
+ * (train_model_official.py:209-229, 253-310) with wider layers, run on v_mfma_f32_16x16x32_bf16: operands rounded to
+ * bf16 on their way into LDS / registers, f32 accumulation, f32 master weights, activations between the GRU kernels f32.
+ *
+ * ss_gemm_bf16_batched: C[M,N] (+)= opA * opB (+ bias), the conventions of ss_gemm_f32_batched (f32 operands in HBM,
+ *   a_kcontig / b_kcontig, storage-row remap, batch strides in elements); flags bit0 accumulate, bit2 float atomics;
+ *   splits > 1 slices K and needs bit0 (atomics into a C the caller initialised).  Contiguous dimensions % 4 == 0. */
+int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
+                         int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
+                         float* C, int ldc, const float* bias, int flags, int splits, int batch, long stride_a,
+                         long stride_b, long stride_c, long stride_bias, ss_stream_t stream);
+
+/* GRU recurrence for wide hidden states (H % 128 == 0), one launch per time step, both directions per launch, same
+ * masking semantics and buffer layouts as ss_gru_fwd / ss_gru_bwd (gi (2,N,3H), out (N,2H), save / d_g (2,N,4,H)).
+ * ss_gru_bf16_prep: W_hh of both directions -> whh_bf16 (2,3H,H) and its transpose whh_t_bf16 (2,H,3H), once per
+ *   optimiser step.  ws: ss_gru_bf16_ws_bytes(B, H) bytes (state / gate-gradient hand-over between the step launches).
+ * ss_gru_bf16_bwd leaves d_g; bias and weight gradients are column sums / GEMMs over d_g (ss_colsum_f32,
+ *   ss_gemm_bf16_batched).  drop_p / seed / offset: the inter-layer dropout mask re-drawn on d_out (see ss_gru_bwd). */
+int ss_gru_bf16_prep(const float* w_hh_f, const float* w_hh_r, int H, uint16_t* whh_bf16, uint16_t* whh_t_bf16,
+                     ss_stream_t stream);
+int ss_gru_bf16_ws_bytes(int B, int H, long* bytes);
+int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const float* b_hh_f, const float* b_hh_r,
+                    const int32_t* lengths, int B, int T, int H, float* out, float* save, void* ws, ss_stream_t stream);
+int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, const uint16_t* whh_t_bf16,
+                    const int32_t* lengths, int B, int T, int H, float* d_g, float drop_p, uint64_t seed,
+                    uint64_t offset, void* ws, ss_stream_t stream);
+
 /* ---- a7: one bidirectional GRU layer, recurrence only ---------------------------------------
  * replaces pack_padded_sequence -> nn.GRU -> pad_packed_sequence (train_model_official.py:301-305).
  * gi      (2, B*T, 3H): W_ih x + b_ih per direction (forward, reverse), from ss_gemm_f32

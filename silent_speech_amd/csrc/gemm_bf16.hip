@@ -1,0 +1,176 @@
+// bf16-MFMA GEMM of the BASELINE config-5 GRU layers (H = 512): C[M,N] (+)= opA[M,K] * opB[K,N] (+ bias[N]).
+//
+// Same operand conventions as ss_gemm_f32_batched (include/ss_hotpath.h): f32 operands in HBM, either k-contiguous
+// ([row][k]) or k-major ([k][row]) with the storage-row remap that pairs dG[b][t] with h[b][t -+ 1].  The operands are
+// rounded to bf16 (nearest even) while they are staged into LDS and multiplied on v_mfma_f32_16x16x32_bf16 with f32
+// accumulation; C, the bias and every accumulation (split-K float atomics) stay f32.
+//
+// 128 x 128 x 32 tiles, 4 waves (2 x 2, 64 x 64 each = 16 accumulators), double-buffered LDS, one barrier per k tile,
+// global loads of tile t+1 issued before the MFMAs of tile t.  k-contiguous operands sit in LDS as [row][32 + 8] and
+// are read with ds_read_b128 (row stride 80 B = 20 banks: the 16 rows of a fragment cover all 64 banks); k-major
+// operands sit as [k][128 + 8] (written with 8-byte stores as they arrive) and are read with the transposing
+// ds_read_b64_tr_b16 -- no transpose pass, no strided global loads.
+#include "bf16_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDK = BK + 8;    // [row][k] image, elements per row
+constexpr int LDR = 128 + 8;   // [k][row] image, elements per k line
+constexpr int TILE_ELEMS = (BM * LDK > BK * LDR) ? BM * LDK : BK * LDR;
+
+struct GemmBfParams {
+  int M, N, K;
+  const float* A; int lda, a_group, a_gstride, a_off;
+  const float* B; int ldb, b_group, b_gstride, b_off;
+  float* C; int ldc;
+  const float* bias;
+  int flags, splits;
+  long sa, sb, sc, sbias;
+};
+
+__device__ __forceinline__ long remap_row(int r, int group, int gstride, int off) {
+  return (long)(r / group) * gstride + (r % group) + off;
+}
+
+// One operand tile (128 rows x 32 k) from HBM into 4 float4 registers per thread.
+// KC = 1: storage [row][k]: thread -> (row = idx / 8, k = 4 (idx % 8)), idx = tid + 256 i.
+// KC = 0: storage [k][row]: thread -> (k = idx / 32, row = 4 (idx % 32)).
+template <int KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int group, int gstride, int off, int row0, int rows,
+                                          int k0, int k_end, int tid, f32x4 v[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (KC) {
+      const int r = row0 + (idx >> 3), k = k0 + 4 * (idx & 7);
+      if (r < rows && k < k_end) x = *reinterpret_cast<const f32x4*>(src + remap_row(r, group, gstride, off) * ld + k);
+    } else {
+      const int k = k0 + (idx >> 5), r = row0 + 4 * (idx & 31);
+      if (k < k_end && r < rows) x = *reinterpret_cast<const f32x4*>(src + remap_row(k, group, gstride, off) * ld + r);
+    }
+    v[i] = x;
+  }
+}
+
+template <int KC>
+__device__ __forceinline__ void store_tile(bf16_t* tile, int tid, const f32x4 v[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    bf16_t* dst = KC ? tile + (idx >> 3) * LDK + 4 * (idx & 7) : tile + (idx >> 5) * LDR + 4 * (idx & 31);
+    *reinterpret_cast<uint2*>(dst) = pack_bf16x4(v[i][0], v[i][1], v[i][2], v[i][3]);
+  }
+}
+
+template <int AKC, int BKC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // A0 B0 A1 B1
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int batch = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+  const float* A = p.A + batch * p.sa;
+  const float* B = p.B + batch * p.sb;
+  float* C = p.C + batch * p.sc;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // K range of this split, in whole k tiles
+  const int nkt = (p.K + BK - 1) / BK;
+  const int per = (nkt + p.splits - 1) / p.splits;
+  const int kt0 = split * per, kt1 = min(nkt, kt0 + per);
+  const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kt0 < kt1) {
+    f32x4 va[4], vb[4];
+    load_tile<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, kt0 * BK, p.K, tid, va);
+    load_tile<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, kt0 * BK, p.K, tid, vb);
+    store_tile<AKC>(lds, tid, va);
+    store_tile<BKC>(lds + TILE_ELEMS, tid, vb);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      const bf16_t* As = lds + (2 * cur) * TILE_ELEMS;
+      const bf16_t* Bs = lds + (2 * cur + 1) * TILE_ELEMS;
+      const bool more = kt + 1 < kt1;
+      if (more) {
+        load_tile<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, (kt + 1) * BK, p.K, tid, va);
+        load_tile<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, (kt + 1) * BK, p.K, tid, vb);
+      }
+      s16x8 fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = AKC ? lds_frag(As + (wm + 16 * t + li) * LDK + 8 * g) : lds_frag_tr(As + wm + 16 * t, LDR, lane);
+        fb[t] = BKC ? lds_frag(Bs + (wn + 16 * t + li) * LDK + 8 * g) : lds_frag_tr(Bs + wn + 16 * t, LDR, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
+      if (more) {
+        store_tile<AKC>(lds + (2 * (cur ^ 1)) * TILE_ELEMS, tid, va);
+        store_tile<BKC>(lds + (2 * (cur ^ 1) + 1) * TILE_ELEMS, tid, vb);
+      }
+      __syncthreads();
+    }
+  }
+
+  // epilogue: D row = 4 g + r, column = li
+  const bool accumulate = p.flags & 1, atomic = (p.flags & 4) || p.splits > 1;
+  const float* bias = p.bias ? p.bias + batch * p.sbias : nullptr;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int n = n0 + wn + 16 * b + li;
+    if (n >= p.N) continue;
+    const float bv = (bias && split == 0) ? bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + 16 * a + 4 * g + r;
+        if (m >= p.M) continue;
+        float* dst = C + (long)m * p.ldc + n;
+        const float v = acc[a][b][r] + bv;
+        if (atomic) atomicAdd(dst, v);
+        else if (accumulate) *dst += v;
+        else *dst = v;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
+                                    int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
+                                    float* C, int ldc, const float* bias, int flags, int splits, int batch, long stride_a,
+                                    long stride_b, long stride_c, long stride_bias, ss_stream_t stream) {
+  SS_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && splits > 0, SS_ERR_ARG);
+  SS_REQUIRE(a_group > 0 && b_group > 0, SS_ERR_ARG);
+  SS_REQUIRE(!(flags & ~5), SS_ERR_UNSUPPORTED);                 // bit0 accumulate, bit2 atomics
+  SS_REQUIRE(splits == 1 || (flags & 1), SS_ERR_ARG);            // K slices add into a C the caller initialised
+  SS_REQUIRE(!(flags & 4) || (flags & 1), SS_ERR_ARG);
+  // 16-byte loads along the contiguous dimension of either layout
+  SS_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && stride_a % 4 == 0 && stride_b % 4 == 0, SS_ERR_UNSUPPORTED);
+  SS_REQUIRE((a_kcontig ? K : M) % 4 == 0 && (b_kcontig ? K : N) % 4 == 0, SS_ERR_UNSUPPORTED);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0, SS_ERR_UNSUPPORTED);
+  GemmBfParams p;
+  p.M = M; p.N = N; p.K = K;
+  p.A = A; p.lda = lda; p.a_group = a_group; p.a_gstride = a_gstride; p.a_off = a_off;
+  p.B = B; p.ldb = ldb; p.b_group = b_group; p.b_gstride = b_gstride; p.b_off = b_off;
+  p.C = C; p.ldc = ldc; p.bias = bias; p.flags = flags;
+  const int nkt = (K + BK - 1) / BK;
+  p.splits = splits < nkt ? splits : nkt;
+  p.sa = stride_a; p.sb = stride_b; p.sc = stride_c; p.sbias = stride_bias;
+  dim3 grid(ceil_div(N, BN), ceil_div(M, BM), batch * p.splits);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, dim3(256), 0, s, p);
+  else if (a_kcontig) hipLaunchKernelGGL((gemm_bf16_kernel<1, 0>), grid, dim3(256), 0, s, p);
+  else if (b_kcontig) hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, dim3(256), 0, s, p);
+  return ss_launch_status();
+}

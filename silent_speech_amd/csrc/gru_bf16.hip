@@ -1,0 +1,287 @@
+// Masked bidirectional GRU recurrence with bf16 MFMA for wide hidden states (BASELINE config 5: H = 512), forward and BPTT.
+//
+// Replaces pack_padded_sequence -> nn.GRU -> pad_packed_sequence (/root/reference/train_model_official.py:261-267,
+// 301-305) for hidden sizes whose W_hh (3H x H = 1.5 MB in bf16 at H = 512) no longer fits the registers of a handful
+// of CUs -- the f32 kernels of gru.hip / gru_split.h keep W_hh resident for H <= 192.  Here ONE launch is ONE time step of
+// BOTH directions: 2 * (H/16) * ceil(B/64) workgroups (256 at B = 256, H = 512: every CU), each producing 16 hidden units
+// of 64 clips.  W_hh streams from L2 as bf16 (3 MB for both directions, resident in every XCD's 4 MB L2 across the
+// steps), the previous state comes as the bf16 copy the previous launch left, the four waves of a workgroup split the
+// contraction (K = H forward, K = 3H backward) and reduce through LDS, and the gate arithmetic stays f32 on the
+// accumulators.  A step is a kernel boundary (~1.5 us) + one L2 round trip + 48 (forward) / 48 (backward) MFMAs per wave:
+// the same price as a step of the multi-CU persistent form, with no inter-workgroup protocol to keep alive.
+//
+// Packed-sequence semantics by masking, exactly as gru.hip: forward direction t = s, reverse direction t = T-1-s at step
+// s; a step with t >= len[b] leaves the state (and emits zeros); the reverse direction therefore starts at len-1.
+#include "bf16_common.h"
+
+namespace {
+
+constexpr int CG = 64;  // clips per workgroup (4 MFMA column tiles)
+
+// ---- W_hh (f32, [3H][H]) of both directions -> bf16 copy and bf16 transpose [H][3H]
+__global__ __launch_bounds__(256) void whh_prep_kernel(const float* __restrict__ w_f, const float* __restrict__ w_r, int H,
+                                                       bf16_t* __restrict__ wb, bf16_t* __restrict__ wtb) {
+  __shared__ float tile[32][33];
+  const int dir = blockIdx.z;
+  const float* w = dir ? w_r : w_f;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;  // rows of W (3H), columns (H)
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const float v = w[(long)(r0 + i) * H + c0 + tx];
+    tile[i][tx] = v;
+    wb[(long)dir * 3 * H * H + (long)(r0 + i) * H + c0 + tx] = to_bf16(v);
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    wtb[(long)dir * 3 * H * H + (long)(c0 + i) * 3 * H + r0 + tx] = to_bf16(tile[tx][i]);
+}
+
+struct StepFwdParams {
+  const float* gi;        // (2, N, 3H) f32: W_ih x + b_ih
+  const bf16_t* whh;      // (2, 3H, H) bf16
+  const float *bhh_f, *bhh_r;
+  const int* lengths;
+  int B, T, H, s;
+  float* out;             // (N, 2H) f32
+  float* save;            // (2, N, 4, H) f32 or null
+  const bf16_t* hb_in;    // (2, B, H) bf16 state after step s-1 (unused at s = 0)
+  bf16_t* hb_out;         // (2, B, H)
+};
+
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 4 * 3 * 64 * 4];  // [wave][clip tile][gate][lane][4]
+  const int H = p.H, B = p.B, T = p.T;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int dir = blockIdx.y;
+  const int nut = H / 16;
+  const int ut = blockIdx.x % nut, cg = blockIdx.x / nut;
+  const int t = dir ? (T - 1 - p.s) : p.s;
+  const long N = (long)B * T;
+
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.s > 0) {
+    const bf16_t* W = p.whh + (long)dir * 3 * H * H;
+    const bf16_t* hb = p.hb_in + (long)dir * B * H;
+    const int kq = H / 4;  // this wave's quarter of the contraction
+    for (int k0 = wv * kq; k0 < (wv + 1) * kq; k0 += 32) {
+      s16x8 fa[3], fb[4];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const s16x8*>(W + (long)(q * H + 16 * ut + li) * H + k0 + 8 * g);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int b = CG * cg + 16 * c + li;
+        fb[c] = b < B ? *reinterpret_cast<const s16x8*>(hb + (long)b * H + k0 + 8 * g) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc[c][q] = mfma_bf16(fa[q], fb[c], acc[c][q]);
+    }
+  }
+  // K slices -> LDS; wave w then owns clip tile w
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<f32x4*>(red + (((wv * 4 + c) * 3 + q) * 64 + lane) * 4) = acc[c][q];
+  __syncthreads();
+  f32x4 gh[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(red + (((w * 4 + wv) * 3 + q) * 64 + lane) * 4);
+    gh[q] = s;
+  }
+  const int b = CG * cg + 16 * wv + li;
+  if (b >= B) return;
+  const int u = 16 * ut + 4 * g;  // this lane's 4 hidden units
+  const bool valid = t < p.lengths[b];
+  const long row = (long)b * T + t;
+  f32x4 hn = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const float* gi = p.gi + ((long)dir * N + row) * 3 * H;
+    const float* bhh = dir ? p.bhh_r : p.bhh_f;
+    const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + u), giz = *reinterpret_cast<const f32x4*>(gi + H + u),
+                gin = *reinterpret_cast<const f32x4*>(gi + 2 * H + u);
+    const f32x4 br = *reinterpret_cast<const f32x4*>(bhh + u), bz = *reinterpret_cast<const f32x4*>(bhh + H + u),
+                bn = *reinterpret_cast<const f32x4*>(bhh + 2 * H + u);
+    f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+    const int tp = dir ? t + 1 : t - 1;
+    if (p.s > 0 && tp >= 0 && tp < T) hp = *reinterpret_cast<const f32x4*>(p.out + ((long)b * T + tp) * 2 * H + dir * H + u);
+    f32x4 rr, zz, nn, hh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float r = sigmoid_f(gir[e] + gh[0][e] + br[e]);
+      const float z = sigmoid_f(giz[e] + gh[1][e] + bz[e]);
+      const float hpre = gh[2][e] + bn[e];
+      const float n = tanh_f(gin[e] + r * hpre);
+      rr[e] = r; zz[e] = z; nn[e] = n; hh[e] = hpre;
+      hn[e] = (1.0f - z) * n + z * hp[e];
+    }
+    if (p.save) {
+      float* sv = p.save + ((long)dir * N + row) * 4 * H;
+      *reinterpret_cast<f32x4*>(sv + u) = rr;
+      *reinterpret_cast<f32x4*>(sv + H + u) = zz;
+      *reinterpret_cast<f32x4*>(sv + 2 * H + u) = nn;
+      *reinterpret_cast<f32x4*>(sv + 3 * H + u) = hh;
+    }
+  }
+  *reinterpret_cast<f32x4*>(p.out + row * 2 * H + dir * H + u) = hn;
+  *reinterpret_cast<uint2*>(p.hb_out + ((long)dir * B + b) * H + u) = pack_bf16x4(hn[0], hn[1], hn[2], hn[3]);
+}
+
+struct StepBwdParams {
+  const float* d_out;     // (N, 2H) f32 gradient w.r.t. this layer's (dropped-out) output
+  const float* out;       // (N, 2H) f32 this layer's output (h_prev)
+  const float* save;      // (2, N, 4, H)
+  const bf16_t* whht;     // (2, H, 3H) bf16 transposed W_hh
+  const int* lengths;
+  int B, T, H, s;
+  float* dG;              // (2, N, 4, H) f32: d gi_r, d gi_z, d gi_n, d(W_hn h + b_hn)
+  const bf16_t* dgh_in;   // (2, B, 3H) bf16: d gh_r | d gh_z | d gh_n of step s-1
+  bf16_t* dgh_out;
+  float* dhz;             // (2, B, H) f32: the part of d h carried on without passing W_hh (dh * z, or all of it past a clip's end)
+  float drop_p;
+  uint64_t seed, offset;
+};
+
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];  // [wave][clip tile][lane][4]
+  const int H = p.H, B = p.B, T = p.T;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int dir = blockIdx.y;
+  const int nut = H / 16;
+  const int ut = blockIdx.x % nut, cg = blockIdx.x / nut;
+  // BPTT walks the forward order backwards: forward direction t = T-1-s, reverse direction t = s
+  const int t = dir ? p.s : (T - 1 - p.s);
+  const long N = (long)B * T;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.s > 0) {
+    const bf16_t* Wt = p.whht + (long)dir * 3 * H * H;
+    const bf16_t* dg = p.dgh_in + (long)dir * B * 3 * H;
+    const int kq = 3 * H / 4;
+    for (int k0 = wv * kq; k0 < (wv + 1) * kq; k0 += 32) {
+      const s16x8 fa = *reinterpret_cast<const s16x8*>(Wt + (long)(16 * ut + li) * 3 * H + k0 + 8 * g);
+      s16x8 fb[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int b = CG * cg + 16 * c + li;
+        fb[c] = b < B ? *reinterpret_cast<const s16x8*>(dg + (long)b * 3 * H + k0 + 8 * g) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = mfma_bf16(fa, fb[c], acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(red + ((wv * 4 + c) * 64 + lane) * 4) = acc[c];
+  __syncthreads();
+  f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) carry += *reinterpret_cast<const f32x4*>(red + ((w * 4 + wv) * 64 + lane) * 4);
+  const int b = CG * cg + 16 * wv + li;
+  if (b >= B) return;
+  const int u = 16 * ut + 4 * g;
+  float* dhz = p.dhz + ((long)dir * B + b) * H + u;
+  if (p.s > 0) carry += *reinterpret_cast<const f32x4*>(dhz);
+  const bool valid = t < p.lengths[b];
+  const long row = (long)b * T + t;
+  f32x4 drp = {0.f, 0.f, 0.f, 0.f}, dzp = drp, dnp = drp, dhn = drp, keep = carry;
+  if (valid) {
+    f32x4 dh = *reinterpret_cast<const f32x4*>(p.d_out + row * 2 * H + dir * H + u);
+    if (p.drop_p > 0.f) dh *= drop_scale4((row * 2 * H + dir * H + u) >> 2, p.drop_p, p.seed, p.offset);
+    dh += carry;
+    const float* sv = p.save + ((long)dir * N + row) * 4 * H;
+    const f32x4 r = *reinterpret_cast<const f32x4*>(sv + u), z = *reinterpret_cast<const f32x4*>(sv + H + u),
+                n = *reinterpret_cast<const f32x4*>(sv + 2 * H + u), hpre = *reinterpret_cast<const f32x4*>(sv + 3 * H + u);
+    f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+    const int tp = dir ? t + 1 : t - 1;  // the step before this one in forward order
+    if (tp >= 0 && tp < T) hp = *reinterpret_cast<const f32x4*>(p.out + ((long)b * T + tp) * 2 * H + dir * H + u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dn = dh[e] * (1.0f - z[e]);
+      const float dz = dh[e] * (hp[e] - n[e]);
+      keep[e] = dh[e] * z[e];
+      dnp[e] = dn * (1.0f - n[e] * n[e]);
+      dhn[e] = dnp[e] * r[e];
+      drp[e] = dnp[e] * hpre[e] * r[e] * (1.0f - r[e]);
+      dzp[e] = dz * z[e] * (1.0f - z[e]);
+    }
+  }
+  float* dG = p.dG + ((long)dir * N + row) * 4 * H;
+  *reinterpret_cast<f32x4*>(dG + u) = drp;
+  *reinterpret_cast<f32x4*>(dG + H + u) = dzp;
+  *reinterpret_cast<f32x4*>(dG + 2 * H + u) = dnp;
+  *reinterpret_cast<f32x4*>(dG + 3 * H + u) = dhn;
+  bf16_t* dgo = p.dgh_out + ((long)dir * B + b) * 3 * H;
+  *reinterpret_cast<uint2*>(dgo + u) = pack_bf16x4(drp[0], drp[1], drp[2], drp[3]);
+  *reinterpret_cast<uint2*>(dgo + H + u) = pack_bf16x4(dzp[0], dzp[1], dzp[2], dzp[3]);
+  *reinterpret_cast<uint2*>(dgo + 2 * H + u) = pack_bf16x4(dhn[0], dhn[1], dhn[2], dhn[3]);
+  *reinterpret_cast<f32x4*>(dhz) = keep;
+}
+
+}  // namespace
+
+extern "C" int ss_gru_bf16_prep(const float* w_hh_f, const float* w_hh_r, int H, uint16_t* whh_bf16, uint16_t* whh_t_bf16,
+                                ss_stream_t stream) {
+  SS_REQUIRE(w_hh_f && w_hh_r && whh_bf16 && whh_t_bf16 && H > 0 && H % 32 == 0, SS_ERR_ARG);
+  hipLaunchKernelGGL(whh_prep_kernel, dim3(H / 32, 3 * H / 32, 2), dim3(256), 0, static_cast<hipStream_t>(stream), w_hh_f, w_hh_r,
+                     H, whh_bf16, whh_t_bf16);
+  return ss_launch_status();
+}
+
+extern "C" int ss_gru_bf16_ws_bytes(int B, int H, long* bytes) {
+  SS_REQUIRE(bytes && B > 0 && H > 0, SS_ERR_ARG);
+  // two state slots (2,B,H) bf16, two gate-gradient slots (2,B,3H) bf16, one (2,B,H) f32 carry
+  *bytes = 2L * 2 * B * H * 2 + 2L * 2 * B * 3 * H * 2 + 2L * B * H * 4;
+  return SS_OK;
+}
+
+// All T steps of one layer, both directions (T launches on ``stream``).
+extern "C" int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const float* b_hh_f, const float* b_hh_r,
+                               const int32_t* lengths, int B, int T, int H, float* out, float* save, void* ws,
+                               ss_stream_t stream) {
+  SS_REQUIRE(gi && whh_bf16 && b_hh_f && b_hh_r && lengths && out && ws, SS_ERR_ARG);
+  SS_REQUIRE(B > 0 && T > 0 && H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);  // four waves x whole 32-deep k steps
+  StepFwdParams p;
+  p.gi = gi; p.whh = whh_bf16; p.bhh_f = b_hh_f; p.bhh_r = b_hh_r; p.lengths = lengths;
+  p.B = B; p.T = T; p.H = H; p.out = out; p.save = save;
+  bf16_t* hb = static_cast<bf16_t*>(ws);
+  const long slot = 2L * B * H;
+  dim3 grid((H / 16) * ceil_div(B, CG), 2);
+  for (int s = 0; s < T; ++s) {
+    p.s = s;
+    p.hb_in = hb + ((s + 1) & 1) * slot;
+    p.hb_out = hb + (s & 1) * slot;
+    hipLaunchKernelGGL(gru_step_fwd_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  }
+  return ss_launch_status();
+}
+
+extern "C" int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, const uint16_t* whh_t_bf16,
+                               const int32_t* lengths, int B, int T, int H, float* d_g, float drop_p, uint64_t seed,
+                               uint64_t offset, void* ws, ss_stream_t stream) {
+  SS_REQUIRE(d_out && out && save && whh_t_bf16 && lengths && d_g && ws, SS_ERR_ARG);
+  SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
+  SS_REQUIRE(H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);
+  StepBwdParams p;
+  p.d_out = d_out; p.out = out; p.save = save; p.whht = whh_t_bf16; p.lengths = lengths;
+  p.B = B; p.T = T; p.H = H; p.dG = d_g; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
+  bf16_t* base = static_cast<bf16_t*>(ws) + 2L * 2 * B * H;  // behind the two forward state slots
+  const long slot = 2L * B * 3 * H;
+  p.dhz = reinterpret_cast<float*>(base + 2 * slot);
+  dim3 grid((H / 16) * ceil_div(B, CG), 2);
+  for (int s = 0; s < T; ++s) {
+    p.s = s;
+    p.dgh_in = base + ((s + 1) & 1) * slot;
+    p.dgh_out = base + (s & 1) * slot;
+    hipLaunchKernelGGL(gru_step_bwd_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  }
+  return ss_launch_status();
+}

@@ -195,7 +195,7 @@ def test_one_rank_rccl_trainer_equals_single_process(ss, tmp_path):
     """The data-parallel leg on the hardware at hand: a FRESH child process (torch.distributed.run, one rank) joins an
     "nccl" (= RCCL) group and pushes the flat gradient bucket of two training steps through dist.all_reduce; the result
     must equal the single-process trainer (a sum over one rank is the identity; dropout on, so the rank-folded seed is
-    covered too): first loss bit for bit, parameters to the run-to-run noise of the float atomics."""
+    covered too), to the run-to-run noise of the float atomics (the loss itself is summed with one atomic per workgroup)."""
     import socket
     import subprocess
     import sys
@@ -223,7 +223,7 @@ def test_one_rank_rccl_trainer_equals_single_process(ss, tmp_path):
     losses = [float(tr.step(X.cuda(), Lh.cuda(), R.cuda(), y.cuda())[0]) for _ in range(2)]
     # same kernels, same seeds; what may differ between two runs is the order of the float atomics that sum the CNN and
     # GRU-bias gradients over workgroups (rounding noise that Adam turns into at most a fraction of lr = 3e-4)
-    assert losses[0] == got["losses"][0] and abs(losses[1] - got["losses"][1]) < 1e-5, (losses, got["losses"])
+    assert abs(losses[0] - got["losses"][0]) < 1e-6 and abs(losses[1] - got["losses"][1]) < 1e-5, (losses, got["losses"])
     for k, v in m.state_dict().items():
         atol = 6.1e-4 if k == "pool.score.bias" else 2e-5
         assert float((v.cpu() - got["sd"][k]).abs().max()) <= atol, k
