@@ -255,6 +255,34 @@ int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, con
                     const int32_t* lengths, int B, int T, int H, float* d_g, float drop_p, uint64_t seed,
                     uint64_t offset, void* ws, ss_stream_t stream);
 
+/* bf16 ROI-CNN of config 5: 96x96 uint8 frame -> normalise -> [conv3x3 + ReLU + maxpool2] x 3 (1->16->32->64) ->
+ * conv3x3 64->96 + ReLU -> global average -> Linear(96 -> E): TinyROICNN (train_model_official.py:209-229) with a fourth
+ * block.  One persistent kernel per layer; between the layers the pooled maps are NHWC bf16 (N,H,W,C) in HBM with one
+ * argmax byte per pooled element (0..3 = position in the 2x2 window, 4 = maximum not positive: no gradient).
+ *   ss_c5_conv1_fwd      R (N,96,96) u8 -> a1 (N,48,48,16) bf16, i1 (N,48,48,16) u8, st (N,2) f32 mean/std (may be NULL)
+ *   ss_c5_conv_fwd       layer 2: a1 -> a2 (N,24,24,32), i2;  layer 3: a2 -> a3 (N,12,12,64), i3
+ *   ss_c5_conv_last_fwd  a3 -> z rows (E floats at z + n*ld_z); training also mask (N,144,96) u8 and feat (N,96) f32
+ * Backward (gradients ACCUMULATE into g_*; d a maps are UNMASKED, the argmax byte of the layer below applies its ReLU):
+ *   ss_c5_conv_last_wgrad  d z (N,E at ld_dz) -> g_w4, g_b4, g_wfc, g_bfc;   ss_c5_conv_last_dgrad -> da3 (N,12,12,64)
+ *   ss_c5_conv_wgrad / ss_c5_conv_dgrad  layer 3: (a2, da3, i3) -> g_w3, g_b3 / da2;  layer 2: (a1, da2, i2) -> g_w2, g_b2 / da1
+ *   ss_c5_conv1_wgrad      (R, st, da1, i1) -> g_w1, g_b1 */
+int ss_c5_conv1_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, uint16_t* a1, uint8_t* i1,
+                    float* st, ss_stream_t stream);
+int ss_c5_conv_fwd(int layer, const uint16_t* in, int N, const float* w, const float* b, uint16_t* out, uint8_t* idx,
+                   ss_stream_t stream);
+int ss_c5_conv_last_fwd(const uint16_t* in, int N, const float* w, const float* b, const float* wfc, const float* bfc, int E,
+                        float* z, int ld_z, uint8_t* mask, float* feat, ss_stream_t stream);
+int ss_c5_conv_wgrad(int layer, const uint16_t* a_in, const uint16_t* da_out, const uint8_t* idx, int N, float* g_w, float* g_b,
+                     ss_stream_t stream);
+int ss_c5_conv_dgrad(int layer, const uint16_t* da_out, const uint8_t* idx, int N, const float* w, uint16_t* da_in,
+                     ss_stream_t stream);
+int ss_c5_conv_last_wgrad(const uint16_t* a_in, const float* dz, int ld_dz, int E, const float* wfc, const uint8_t* mask,
+                          const float* feat, int N, float* g_w, float* g_b, float* g_wfc, float* g_bfc, ss_stream_t stream);
+int ss_c5_conv_last_dgrad(const float* dz, int ld_dz, int E, const float* wfc, const uint8_t* mask, int N, const float* w,
+                          uint16_t* da_in, ss_stream_t stream);
+int ss_c5_conv1_wgrad(const uint8_t* R, int N, int standardize, const float* st, const uint16_t* da1, const uint8_t* i1,
+                      float* g_w1, float* g_b1, ss_stream_t stream);
+
 /* ---- a7: one bidirectional GRU layer, recurrence only ---------------------------------------
  * replaces pack_padded_sequence -> nn.GRU -> pad_packed_sequence (train_model_official.py:301-305).
  * gi      (2, B*T, 3H): W_ih x + b_ih per direction (forward, reverse), from ss_gemm_f32

@@ -37,6 +37,14 @@ SIGNATURES = {
                             _l, _l, _l, _l, _l, _vp],
     "ss_gemm_bf16_batched": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _l, _l, _l, _l,
                              _vp],
+    "ss_c5_conv1_fwd": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ss_c5_conv_fwd": [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "ss_c5_conv_last_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp],
+    "ss_c5_conv_wgrad": [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "ss_c5_conv_dgrad": [_i, _vp, _vp, _i, _vp, _vp, _vp],
+    "ss_c5_conv_last_wgrad": [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "ss_c5_conv_last_dgrad": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "ss_c5_conv1_wgrad": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_gru_bf16_prep": [_vp, _vp, _i, _vp, _vp, _vp],
     "ss_gru_bf16_ws_bytes": [_i, _i, _vp],
     "ss_gru_bf16_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],

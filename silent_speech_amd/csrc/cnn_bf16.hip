@@ -1,0 +1,385 @@
+// bf16 ROI-CNN forward of BASELINE config 5: geometry and data flow in cnn_bf16.h.
+//
+//   ss_c5_conv1_fwd      uint8 frame -> exact integer statistics -> (u/255 - mu)/std table -> bf16 haloed image ->
+//                        conv 1->16 as a PATCH GEMM: K = 32 = a 4-row x 8-column input patch, M = the 16 patches of one
+//                        row pair (96 = 16 x 6 columns), one MFMA per output position of the patch (2 rows x 6 columns)
+//                        against a constant sparse weight fragment kept in registers -- 1 operand read per 12 MFMAs,
+//                        2x2 max-pool across the accumulators of a lane -> pooled map + argmax bytes
+//   ss_c5_conv_fwd       layers 2 and 3: implicit GEMM out of the haloed LDS image (cnn_bf16.h), bias + ReLU + 2x2
+//                        max-pool inside a lane (an M tile is 2 rows x 8 columns = 4 pool windows, the 4 rows a lane
+//                        holds of a 16x16 result are one window)
+//   ss_c5_conv_last_fwd  layer 4 (no pool): bias + ReLU + sign mask + global average + Linear(96 -> E), written
+//                        straight into the (B,T,x_dim+E) GRU input (the torch.cat of train_model_official.py:297)
+//
+// Replaces /root/reference/train_model_official.py:286-291 (normalise) and :212-229 (CNN) for the wider model.
+#include "cnn_bf16.h"
+
+namespace {
+using namespace c5;
+
+__device__ __forceinline__ void zero_lds(void* base, int bytes, int tid) {
+  uint4* p = reinterpret_cast<uint4*>(base);
+  for (int q = tid; q < bytes / 16; q += NT) p[q] = uint4{0u, 0u, 0u, 0u};
+}
+
+// ------------------------------------------------------------------------------------------------ conv1
+struct Conv1Params {
+  const uint8_t* R;   // (N, 96, 96)
+  int N, standardize;
+  const float *w1, *b1;  // (16,1,3,3), (16)
+  bf16_t* a1;         // (N, 48, 48, 16)
+  uint8_t* i1;        // (N, 48, 48, 16)
+  float* st;          // (N, 2): mean, std of the frame (backward reuses them) or null
+};
+
+constexpr int RS0 = 104;  // row stride of the 98 x 98 haloed one-channel image (elements)
+
+__global__ __launch_bounds__(NT, 2) void conv1_fwd_kernel(Conv1Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HP = HW0 / 2;
+  bf16_t* img = reinterpret_cast<bf16_t*>(smem);                         // [98][RS0]
+  constexpr int o_tab = round_up(98 * RS0 * 2, 16);
+  float* s_xn = reinterpret_cast<float*>(smem + o_tab);                  // [256]
+  float* s_misc = s_xn + 256;                                            // [64]
+  constexpr int o_a1 = o_tab + (256 + 64) * 4;
+  bf16_t* oa = reinterpret_cast<bf16_t*>(smem + o_a1);                   // [48][48][16]
+  uint8_t* oi = smem + o_a1 + HP * HP * C1 * 2;                          // [48][48][16]
+  unsigned* s_red = reinterpret_cast<unsigned*>(s_misc);                 // [NW][2]
+  float* s_stat = s_misc + 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  zero_lds(img, o_tab, tid);
+  // constant B fragments: output position q = (oy, ox) of a patch reads patch cell (oy + ky, ox + kx)
+  s16x8 bq[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    const int oy = q / 6, ox = q % 6;
+    s16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ky = g - oy, kx = j - ox;
+      const float w = (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) ? p.w1[li * 9 + ky * 3 + kx] : 0.f;
+      f[j] = (short)to_bf16(w);
+    }
+    bq[q] = f;
+  }
+  const float bias = p.b1[li];
+  __syncthreads();
+
+  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    // ---- frame bytes, exact statistics (train_model_official.py:286-290)
+    const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
+    uint4 px[2];
+    px[0] = src[tid];
+    px[1] = (tid + NT < HW0 * HW0 / 16) ? src[tid + NT] : uint4{0u, 0u, 0u, 0u};
+    unsigned su = 0, sq = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const unsigned u = (wds[e] >> (8 * b)) & 255u;
+          su += u;
+          sq += u * u;
+        }
+    }
+    su = wave_sum_u32(su);
+    sq = wave_sum_u32(sq);
+    if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long tsu = 0, tsq = 0;
+      for (int k = 0; k < NW; ++k) { tsu += s_red[2 * k]; tsq += s_red[2 * k + 1]; }
+      float mu = 0.f, sd = 1.f;
+      if (p.standardize) {
+        const double nn = (double)(HW0 * HW0);
+        mu = (float)((double)tsu / nn) / 255.0f;
+        const double var = ((double)tsq - (double)tsu * (double)tsu / nn) / (nn - 1.0);
+        sd = fmaxf((float)(sqrt(var > 0.0 ? var : 0.0) / 255.0), 1e-6f);
+      }
+      s_stat[0] = mu;
+      s_stat[1] = sd;
+      if (p.st) { p.st[2 * (long)n] = mu; p.st[2 * (long)n + 1] = sd; }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const float rr = (float)tid / 255.0f;
+      s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + k * NT;
+      if (q < HW0 * HW0 / 16) {
+        const int lin = q * 16;
+        bf16_t* dst = img + (lin / HW0 + 1) * RS0 + (lin % HW0) + 1;
+        const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) dst[4 * e + b] = to_bf16(s_xn[(wds[e] >> (8 * b)) & 255u]);
+      }
+    }
+    __syncthreads();
+    // ---- patch GEMM: row pair yp, patch i = li covers haloed rows 2yp..2yp+3, haloed columns 6i..6i+7
+    for (int yp = wv; yp < HP; yp += NW) {
+      const unsigned* ap = reinterpret_cast<const unsigned*>(img + (2 * yp + g) * RS0 + 6 * li);
+      const unsigned a0 = ap[0], a1v = ap[1], a2 = ap[2], a3 = ap[3];
+      const s16x8 fa = __builtin_bit_cast(s16x8, uint4{a0, a1v, a2, a3});
+      f32x4 acc[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) acc[q] = mfma_bf16(fa, bq[q], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          float best = acc[2 * w][r];
+          int bi = 0;
+          if (acc[2 * w + 1][r] > best) { best = acc[2 * w + 1][r]; bi = 1; }
+          if (acc[6 + 2 * w][r] > best) { best = acc[6 + 2 * w][r]; bi = 2; }
+          if (acc[6 + 2 * w + 1][r] > best) { best = acc[6 + 2 * w + 1][r]; bi = 3; }
+          const float v = fmaxf(best + bias, 0.f);
+          const int o = (yp * HP + 3 * (4 * g + r) + w) * C1 + li;
+          oa[o] = to_bf16(v);
+          oi[o] = (uint8_t)(v > 0.f ? bi : IDX_DEAD);
+        }
+    }
+    __syncthreads();
+    uint4* da = reinterpret_cast<uint4*>(p.a1 + (long)n * HP * HP * C1);
+    for (int q = tid; q < HP * HP * C1 * 2 / 16; q += NT) da[q] = reinterpret_cast<const uint4*>(oa)[q];
+    uint4* di = reinterpret_cast<uint4*>(p.i1 + (long)n * HP * HP * C1);
+    for (int q = tid; q < HP * HP * C1 / 16; q += NT) di[q] = reinterpret_cast<const uint4*>(oi)[q];
+    // the next frame's epilogue writes oa / oi only behind the barriers of its own statistics phase
+  }
+}
+
+constexpr int CONV1_LDS = round_up(98 * RS0 * 2, 16) + (256 + 64) * 4 + 48 * 48 * C1 * 3;
+
+// ------------------------------------------------------------------------------------------------ layers 2..4
+struct ConvFwdParams {
+  const bf16_t* in;   // (N, H, W, CIN)
+  int N;
+  const float *w, *b; // (COUT, CIN, 3, 3), (COUT)
+  bf16_t* out;        // (N, H/2, W/2, COUT)            pooled layers
+  uint8_t* idx;       // (N, H/2, W/2, COUT)
+  // last layer
+  const float *wfc, *bfc;  // (E, COUT), (E)
+  int E;
+  float* z;           // row n at z + n * ld_z
+  int ld_z;
+  uint8_t* mask;      // (N, H*W, COUT) conv output > 0, or null (inference)
+  float* feat;        // (N, COUT) averaged features, or null
+};
+
+// bf16 weight matrix [COUT][kk = tap*CIN + ci] into LDS
+template <int CIN, int COUT>
+__device__ __forceinline__ void stage_weights(const float* __restrict__ w, bf16_t* wl, int tid) {
+  using WM = Wmat<CIN, COUT>;
+  for (int q = tid; q < COUT * WM::KP; q += NT) {
+    const int co = q / WM::KP, kk = q % WM::KP, tap = kk / CIN, ci = kk % CIN;
+    wl[co * WM::LD + kk] = to_bf16(tap < 9 ? w[(co * CIN + ci) * 9 + tap] : 0.f);
+  }
+}
+
+// un-haloed NHWC frame (HBM) -> haloed LDS image, 16-byte pieces
+template <class IM>
+__device__ __forceinline__ void load_image(const bf16_t* __restrict__ src, bf16_t* img, int tid) {
+  constexpr int CH = IM::C / 8;  // 16-byte pieces per pixel
+  for (int q = tid; q < IM::H * IM::W * CH; q += NT) {
+    const int pix = q / CH, c8 = q % CH;
+    *reinterpret_cast<uint4*>(img + IM::at(pix / IM::W, pix % IM::W) + 8 * c8) = reinterpret_cast<const uint4*>(src)[q];
+  }
+}
+
+// element offset of the A fragment of k step s relative to the lane's base (pixel (y-1, x-1), chunk folded into the base)
+template <class IM>
+__device__ __forceinline__ int koff(int s, int hi) {
+  constexpr int CIN = IM::C;
+  if (CIN >= 32) {
+    const int tap = (32 * s) / CIN, ci0 = (32 * s) % CIN;
+    return (tap / 3) * IM::RS + (tap % 3) * IM::PS + ci0;
+  }
+  int tap = 2 * s + hi;  // 16 channels: a k step is two taps
+  if (tap > 8) tap = 8;  // padding half of the last step: any valid address, its weights are zero
+  return (tap / 3) * IM::RS + (tap % 3) * IM::PS;
+}
+
+template <int CIN, int COUT, int H, int W, bool LAST, int MT, int NTL>
+__global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using IM = Img<CIN, H, W>;
+  using WM = Wmat<CIN, COUT>;
+  constexpr int HO = H / 2, WO = W / 2;
+  bf16_t* img = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* wl = reinterpret_cast<bf16_t*>(smem + IM::BYTES);
+  constexpr int o_out = IM::BYTES + round_up(WM::BYTES, 16);
+  bf16_t* oa = reinterpret_cast<bf16_t*>(smem + o_out);                       // pooled: [HO][WO][COUT]
+  uint8_t* oi = smem + o_out + (LAST ? 0 : HO * WO * COUT * 2);               // pooled: argmax; last: mask [H*W][COUT]
+  constexpr int o_misc = o_out + (LAST ? H * W * COUT : HO * WO * COUT * 3);
+  float* s_bias = reinterpret_cast<float*>(smem + round_up(o_misc, 16));      // [COUT]
+  float* s_feat = s_bias + COUT;                                              // [COUT]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  zero_lds(img, IM::BYTES, tid);
+  stage_weights<CIN, COUT>(p.w, wl, tid);
+  for (int q = tid; q < COUT; q += NT) s_bias[q] = p.b[q];
+  __syncthreads();
+
+  constexpr int MTILES = LAST ? H * W / 16 : HO * (W / 8);
+  constexpr int NTILES = COUT / 16;
+  static_assert(MTILES % MT == 0 && NTILES % NTL == 0, "unit split");
+  constexpr int UNITS = (MTILES / MT) * (NTILES / NTL);
+  const int chunk = (CIN >= 32) ? g : (g & 1), hi = (CIN >= 32) ? 0 : (g >> 1);
+
+  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    load_image<IM>(p.in + (long)n * H * W * CIN, img, tid);
+    if (LAST)
+      for (int q = tid; q < COUT; q += NT) s_feat[q] = 0.f;
+    __syncthreads();
+    for (int u = wv; u < UNITS; u += NW) {
+      const int mg = u % (MTILES / MT), ng = u / (MTILES / MT);
+      int base[MT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        const int mt = mg * MT + a;
+        int y, x;
+        if (LAST) {
+          const int P = 16 * mt + li;
+          y = P / W; x = P % W;
+        } else {
+          const int yp = mt / (W / 8), xt = mt % (W / 8);
+          y = 2 * yp + ((li >> 1) & 1); x = 8 * xt + 2 * (li >> 2) + (li & 1);
+        }
+        base[a] = IM::at(y - 1, x - 1) + 8 * chunk;
+      }
+      f32x4 acc[MT][NTL];
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTL; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < WM::KSTEPS; ++s) {
+        const int off = (CIN >= 32) ? koff<IM>(s, 0) : (hi ? koff<IM>(s, 1) : koff<IM>(s, 0));
+        s16x8 fa[MT], fb[NTL];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) fa[a] = lds_frag(img + base[a] + off);
+#pragma unroll
+        for (int b = 0; b < NTL; ++b) fb[b] = lds_frag(wl + (16 * (ng * NTL + b) + li) * WM::LD + 32 * s + 8 * g);
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < NTL; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
+      }
+      // ---- epilogue
+#pragma unroll
+      for (int b = 0; b < NTL; ++b) {
+        const int co = 16 * (ng * NTL + b) + li;
+        const float bias = s_bias[co];
+        float fsum = 0.f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          const int mt = mg * MT + a;
+          const f32x4 v = acc[a][b];
+          if (LAST) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float x = v[r] + bias;
+              if (p.mask) oi[(16 * mt + 4 * g + r) * COUT + co] = x > 0.f;
+              fsum += fmaxf(x, 0.f);
+            }
+          } else {
+            float best = v[0];
+            int bi = 0;
+            if (v[1] > best) { best = v[1]; bi = 1; }
+            if (v[2] > best) { best = v[2]; bi = 2; }
+            if (v[3] > best) { best = v[3]; bi = 3; }
+            const float x = fmaxf(best + bias, 0.f);
+            const int yp = mt / (W / 8), xt = mt % (W / 8);
+            const int o = (yp * WO + 4 * xt + g) * COUT + co;
+            oa[o] = to_bf16(x);
+            oi[o] = (uint8_t)(x > 0.f ? bi : IDX_DEAD);
+          }
+        }
+        if (LAST) {
+          fsum += __shfl_xor(fsum, 16, 64);
+          fsum += __shfl_xor(fsum, 32, 64);
+          if (g == 0) atomicAdd(&s_feat[co], fsum);
+        }
+      }
+    }
+    __syncthreads();
+    if (LAST) {
+      if (p.mask) {
+        uint4* dm = reinterpret_cast<uint4*>(p.mask + (long)n * H * W * COUT);
+        for (int q = tid; q < H * W * COUT / 16; q += NT) dm[q] = reinterpret_cast<const uint4*>(oi)[q];
+      }
+      for (int q = tid; q < COUT; q += NT) {
+        const float f = s_feat[q] / (float)(H * W);
+        s_feat[q] = f;
+        if (p.feat) p.feat[(long)n * COUT + q] = f;
+      }
+      __syncthreads();
+      for (int e = tid; e < p.E; e += NT) {
+        float o = p.bfc[e];
+        for (int c = 0; c < COUT; ++c) o += s_feat[c] * p.wfc[e * COUT + c];
+        p.z[(long)n * p.ld_z + e] = o;
+      }
+      __syncthreads();
+    } else {
+      uint4* da = reinterpret_cast<uint4*>(p.out + (long)n * HO * WO * COUT);
+      for (int q = tid; q < HO * WO * COUT * 2 / 16; q += NT) da[q] = reinterpret_cast<const uint4*>(oa)[q];
+      uint4* di = reinterpret_cast<uint4*>(p.idx + (long)n * HO * WO * COUT);
+      for (int q = tid; q < HO * WO * COUT / 16; q += NT) di[q] = reinterpret_cast<const uint4*>(oi)[q];
+      // no barrier: the next frame's load writes img only, and its epilogue writes oa / oi behind the barrier after that load
+    }
+  }
+}
+
+template <int CIN, int COUT, int H, int W, bool LAST>
+constexpr int conv_fwd_lds() {
+  return Img<CIN, H, W>::BYTES + round_up(Wmat<CIN, COUT>::BYTES, 16) +
+         round_up(LAST ? H * W * COUT : (H / 2) * (W / 2) * COUT * 3, 16) + 16 + 2 * COUT * 4;
+}
+
+template <class P, class K>
+int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s) {
+  if (lds_bytes > 160 * 1024) return SS_ERR_UNSUPPORTED;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    return SS_ERR_LAUNCH;
+  const int grid = N < 256 ? N : 256;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds_bytes, s, p);
+  return ss_launch_status();
+}
+
+}  // namespace
+
+extern "C" int ss_c5_conv1_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, uint16_t* a1,
+                               uint8_t* i1, float* st, ss_stream_t stream) {
+  SS_REQUIRE(R && w1 && b1 && a1 && i1 && N > 0, SS_ERR_ARG);
+  Conv1Params p{R, N, standardize, w1, b1, a1, i1, st};
+  return launch_persistent(conv1_fwd_kernel, p, CONV1_LDS, N, static_cast<hipStream_t>(stream));
+}
+
+// layer = 2: (N,48,48,16) -> (N,24,24,32);  layer = 3: (N,24,24,32) -> (N,12,12,64)
+extern "C" int ss_c5_conv_fwd(int layer, const uint16_t* in, int N, const float* w, const float* b, uint16_t* out, uint8_t* idx,
+                              ss_stream_t stream) {
+  SS_REQUIRE(in && w && b && out && idx && N > 0, SS_ERR_ARG);
+  ConvFwdParams p{};
+  p.in = in; p.N = N; p.w = w; p.b = b; p.out = out; p.idx = idx;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (layer == 2) return launch_persistent(conv_fwd_kernel<C1, C2, 48, 48, false, 6, 2>, p, conv_fwd_lds<C1, C2, 48, 48, false>(), N, s);
+  if (layer == 3) return launch_persistent(conv_fwd_kernel<C2, C3, 24, 24, false, 9, 2>, p, conv_fwd_lds<C2, C3, 24, 24, false>(), N, s);
+  return SS_ERR_UNSUPPORTED;
+}
+
+extern "C" int ss_c5_conv_last_fwd(const uint16_t* in, int N, const float* w, const float* b, const float* wfc, const float* bfc,
+                                   int E, float* z, int ld_z, uint8_t* mask, float* feat, ss_stream_t stream) {
+  SS_REQUIRE(in && w && b && wfc && bfc && z && N > 0 && E > 0 && ld_z >= E, SS_ERR_ARG);
+  SS_REQUIRE((mask == nullptr) == (feat == nullptr), SS_ERR_ARG);
+  ConvFwdParams p{};
+  p.in = in; p.N = N; p.w = w; p.b = b; p.wfc = wfc; p.bfc = bfc; p.E = E; p.z = z; p.ld_z = ld_z; p.mask = mask; p.feat = feat;
+  return launch_persistent(conv_fwd_kernel<C3, C4, 12, 12, true, 3, 3>, p, conv_fwd_lds<C3, C4, 12, 12, true>(), N,
+                           static_cast<hipStream_t>(stream));
+}

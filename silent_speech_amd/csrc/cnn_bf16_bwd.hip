@@ -1,0 +1,464 @@
+// bf16 ROI-CNN backward of BASELINE config 5 (geometry: cnn_bf16.h; forward: cnn_bf16.hip).
+//
+// Per layer L (input a_in with CIN channels at H x W, output COUT channels) two persistent kernels:
+//   wgrad  d W[co][ci][tap] = sum_pixels dy[p][co] * a_in[p + tap][ci]   M = co, N = ci, K = 32 pixels per MFMA.
+//          Both operands are pixel-major in LDS (the contraction index is the SLOW one), so both fragments come from
+//          ds_read_b64_tr_b16: every lane hands in the address of one pixel's 4-channel piece, the hardware
+//          transposes.  A pixel's address is computed per lane, so the 32 pixels of a k step need no common stride
+//          (rows of 12, 24 or 48 pixels, haloed on the a_in side).  The 9 taps share the dy fragment; the weight
+//          gradient lives in registers for the whole walk over the frames and leaves as float atomics once.
+//          d b[co] = sum_pixels dy[p][co] rides on the same data path (one more MFMA per k step against a fragment
+//          of ones).
+//   dgrad  d a_in = conv_transpose(dy, W): the forward routine on the haloed dy image with the flipped, transposed
+//          weights [ci][tap'][co].  Stored UNMASKED: the ReLU of the layer below is applied when ITS backward
+//          expands the gradient through its pool (argmax byte 4 = dead window).
+// dy is rebuilt in LDS from the pooled-grid gradient + the argmax bytes (pooled layers) or from d feat + the sign mask
+// (last layer).  Large maps are processed in row bands so that dy (dense, bf16) fits beside the other operand.
+//   conv1 wgrad: 1 input channel -- 9 FMAs per routed gradient on the VALU (4 % of the backward MACs).
+#include "cnn_bf16.h"
+
+namespace {
+using namespace c5;
+
+__device__ __forceinline__ void zero_lds(void* base, int bytes, int tid) {
+  uint4* p = reinterpret_cast<uint4*>(base);
+  for (int q = tid; q < bytes / 16; q += NT) p[q] = uint4{0u, 0u, 0u, 0u};
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ s16x8 tr_pair(const bf16_t* lo, const bf16_t* hi) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lo);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)hi);
+  return s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+struct ConvBwdParams {
+  int N;
+  const bf16_t* a_in;     // (N, H, W, CIN) input of the layer (forward stash)
+  const bf16_t* da_out;   // (N, H/2, W/2, COUT) gradient w.r.t. the pooled output (unmasked)      pooled layers
+  const uint8_t* idx;     // (N, H/2, W/2, COUT) argmax bytes
+  // last layer: d z (N, E) at ld_dz, fc weights, sign mask, averaged features
+  const float* dz; int ld_dz, E;
+  const float* wfc;
+  const uint8_t* mask;    // (N, H*W, COUT)
+  const float* feat;      // (N, COUT)
+  const float* w;         // (COUT, CIN, 3, 3) f32 (dgrad)
+  float *g_w, *g_b;       // gradient accumulators (wgrad), +=
+  float *g_wfc, *g_bfc;   // (E, COUT), (E)  (last layer's wgrad)
+  bf16_t* da_in;          // (N, H, W, CIN) (dgrad)
+};
+
+// dense dy rows [y0, y0 + rows) of a pooled layer into an LDS image whose local row 0 is y0 (rows outside the frame: zeros)
+//   dst(yl, x) = img + off0 + yl * RS + x * PS
+template <int COUT, int H, int W>
+__device__ __forceinline__ void expand_dy(const bf16_t* __restrict__ da, const uint8_t* __restrict__ idx, bf16_t* img, int off0, int RS,
+                                          int PS, int y0, int rows, int tid) {
+  constexpr int WO = W / 2, CH = COUT / 8;
+  for (int q = tid; q < rows * WO * CH; q += NT) {
+    const int c8 = q % CH, xp = (q / CH) % WO, yl = q / (CH * WO);
+    const int y = y0 + yl;
+    uint4 v0 = {0u, 0u, 0u, 0u}, v1 = v0;
+    if (y >= 0 && y < H) {
+      const long src = ((long)(y >> 1) * WO + xp) * COUT + 8 * c8;
+      const uint4 dv = *reinterpret_cast<const uint4*>(da + src);
+      const uint2 iv = *reinterpret_cast<const uint2*>(idx + src);
+      const unsigned d[4] = {dv.x, dv.y, dv.z, dv.w};
+      const unsigned e0 = (unsigned)(y & 1) * 2u;
+      unsigned o0[4], o1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // channels 2k, 2k+1
+        const unsigned ib = (k < 2 ? iv.x : iv.y) >> (16 * (k & 1));
+        const unsigned ia = ib & 255u, ic = (ib >> 8) & 255u;
+        const unsigned lo = d[k] & 0xffffu, hi = d[k] & 0xffff0000u;
+        o0[k] = (ia == e0 ? lo : 0u) | (ic == e0 ? hi : 0u);
+        o1[k] = (ia == e0 + 1u ? lo : 0u) | (ic == e0 + 1u ? hi : 0u);
+      }
+      v0 = uint4{o0[0], o0[1], o0[2], o0[3]};
+      v1 = uint4{o1[0], o1[1], o1[2], o1[3]};
+    }
+    bf16_t* dst = img + off0 + yl * RS + (2 * xp) * PS + 8 * c8;
+    *reinterpret_cast<uint4*>(dst) = v0;
+    *reinterpret_cast<uint4*>(dst + PS) = v1;
+  }
+}
+
+// last layer: dy[P][co] = mask[P][co] ? dfeat[co] / (H*W) : 0, all pixels
+template <int COUT, int NPIX>
+__device__ __forceinline__ void expand_dy_last(const uint8_t* __restrict__ mask, const float* s_dfeat, bf16_t* img, int off0, int RS,
+                                               int PS, int W, int tid) {
+  constexpr int CH = COUT / 8;
+  for (int q = tid; q < NPIX * CH; q += NT) {
+    const int c8 = q % CH, P = q / CH;
+    const uint2 mv = *reinterpret_cast<const uint2*>(mask + (long)P * COUT + 8 * c8);
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned mb = (k < 2 ? mv.x : mv.y) >> (16 * (k & 1));
+      const float a = (mb & 255u) ? s_dfeat[8 * c8 + 2 * k] : 0.f, b = ((mb >> 8) & 255u) ? s_dfeat[8 * c8 + 2 * k + 1] : 0.f;
+      o[k] = pack_bf16(a, b);
+    }
+    *reinterpret_cast<uint4*>(img + off0 + (P / W) * RS + (P % W) * PS + 8 * c8) = uint4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+// rows [y0, y0 + rows) of an NHWC frame into a haloed LDS image whose local row -1 is y0 (frame rows outside [0,H): zeros)
+template <class IM, int HF>
+__device__ __forceinline__ void load_band(const bf16_t* __restrict__ src, bf16_t* img, int y0, int rows, int tid) {
+  constexpr int CH = IM::C / 8;
+  for (int q = tid; q < rows * IM::W * CH; q += NT) {
+    const int c8 = q % CH, x = (q / CH) % IM::W, yl = q / (CH * IM::W);
+    const int y = y0 + yl;
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (y >= 0 && y < HF) v = *reinterpret_cast<const uint4*>(src + ((long)y * IM::W + x) * IM::C + 8 * c8);
+    *reinterpret_cast<uint4*>(img + IM::at(yl - 1, x) + 8 * c8) = v;
+  }
+}
+
+// d feat[co] = sum_e dz[e] wfc[e][co] / (H*W)  (gradient of Linear o global average)
+template <int COUT>
+__device__ __forceinline__ void last_dfeat(const ConvBwdParams& p, int n, float* s_dz, float* s_dfeat, float inv_hw, int tid) {
+  for (int e = tid; e < p.E; e += NT) s_dz[e] = p.dz[(long)n * p.ld_dz + e];
+  __syncthreads();
+  for (int c = tid; c < COUT; c += NT) {
+    float s = 0.f;
+    for (int e = 0; e < p.E; ++e) s += s_dz[e] * p.wfc[e * COUT + c];
+    s_dfeat[c] = s * inv_hw;
+  }
+}
+
+// ================================================================================================ wgrad
+// BH = rows of a band; WCO x WCI x WK = 8 waves: a wave owns COUT/16/WCO co tiles x CIN/16/WCI ci tiles (all 9 taps) and
+// every WK-th 32-pixel k step
+template <int CIN, int COUT, int H, int W, bool LAST, int BH, int WCO, int WCI, int WK>
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
+  static_assert(WCO * WCI * WK == NW && H % BH == 0, "wave split");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using IA = Img<CIN, BH, W>;
+  constexpr int PSD = COUT + 8, RSD = W * PSD;           // dense dy band, no halo
+  constexpr int DY_BYTES = BH * RSD * 2;
+  constexpr int NCO = COUT / 16 / WCO, NCI = CIN / 16 / WCI;
+  constexpr int NPIX = BH * W, NCH = (NPIX + 31) / 32;
+  bf16_t* dyi = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* ai = reinterpret_cast<bf16_t*>(smem + DY_BYTES);
+  bf16_t* zeros = reinterpret_cast<bf16_t*>(smem + DY_BYTES + IA::BYTES);    // 64 bytes of zeros: pixels past the band
+  float* s_dz = reinterpret_cast<float*>(smem + DY_BYTES + IA::BYTES + 64);  // [64]
+  float* s_dfeat = s_dz + 64;                                                // [COUT]
+  float* s_feat = s_dfeat + 96;                                              // [COUT]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int q4 = li >> 2, p4 = li & 3;
+  const int wco = wv % WCO, wci = (wv / WCO) % WCI, wk = wv / (WCO * WCI);
+  zero_lds(smem, DY_BYTES + IA::BYTES + 64, tid);
+
+  f32x4 acc[NCO][NCI][9];
+  f32x4 accb[NCO];
+#pragma unroll
+  for (int a = 0; a < NCO; ++a) {
+    accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NCI; ++b)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  // fc gradients of the last layer: thread-private partial sums over the frames
+  constexpr int FCN = LAST ? (64 * COUT + NT - 1) / NT : 1;
+  float fcw[FCN];
+  float fcb = 0.f;
+#pragma unroll
+  for (int k = 0; k < FCN; ++k) fcw[k] = 0.f;
+  __syncthreads();
+
+  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    if (LAST) {
+      last_dfeat<COUT>(p, n, s_dz, s_dfeat, 1.0f / (float)(H * W), tid);
+      for (int c = tid; c < COUT; c += NT) s_feat[c] = p.feat[(long)n * COUT + c];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < FCN; ++k) {
+        const int q = tid + k * NT;
+        if (q < p.E * COUT) fcw[k] += s_dz[q / COUT] * s_feat[q % COUT];
+      }
+      if (tid < p.E) fcb += s_dz[tid];
+    }
+    for (int y0 = 0; y0 < H; y0 += BH) {
+      if (LAST) expand_dy_last<COUT, H * W>(p.mask + (long)n * H * W * COUT, s_dfeat, dyi, 0, RSD, PSD, W, tid);
+      else expand_dy<COUT, H, W>(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, dyi, 0, RSD,
+                                 PSD, y0, BH, tid);
+      load_band<IA, H>(p.a_in + (long)n * H * W * CIN, ai, y0 - 1, BH + 2, tid);
+      __syncthreads();
+      for (int ch = wk; ch < NCH; ch += WK) {
+        // this lane's two pixels of the k step: rows q4 and q4 + 4 of its 8-pixel group
+        const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;
+        const bool in0 = P0 < NPIX, in1 = P1 < NPIX;
+        const int y0l = P0 / W, x0l = P0 % W, y1l = P1 / W, x1l = P1 % W;
+        const bf16_t* dy0 = in0 ? dyi + y0l * RSD + x0l * PSD + 4 * p4 : zeros + 4 * p4;
+        const bf16_t* dy1 = in1 ? dyi + y1l * RSD + x1l * PSD + 4 * p4 : zeros + 4 * p4;
+        const bf16_t* a0 = ai + (in0 ? IA::at(y0l - 1, x0l - 1) : IA::at(0, 0)) + 4 * p4;
+        const bf16_t* a1 = ai + (in1 ? IA::at(y1l - 1, x1l - 1) : IA::at(0, 0)) + 4 * p4;
+        s16x8 fa[NCO];
+#pragma unroll
+        for (int a = 0; a < NCO; ++a) {
+          const int co0 = 16 * (wco * NCO + a);
+          fa[a] = tr_pair(dy0 + co0, dy1 + co0);
+          if (wci == 0) accb[a] = mfma_bf16(fa[a], ones, accb[a]);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int toff = (t / 3) * IA::RS + (t % 3) * IA::PS;
+#pragma unroll
+          for (int b = 0; b < NCI; ++b) {
+            const int ci0 = 16 * (wci * NCI + b);
+            const s16x8 fb = tr_pair(a0 + toff + ci0, a1 + toff + ci0);
+#pragma unroll
+            for (int a = 0; a < NCO; ++a) acc[a][b][t] = mfma_bf16(fa[a], fb, acc[a][b][t]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- hand the register-resident gradients over: D row 4 g + r = co, column li = ci
+#pragma unroll
+  for (int a = 0; a < NCO; ++a) {
+    const int co0 = 16 * (wco * NCO + a) + 4 * g;
+#pragma unroll
+    for (int b = 0; b < NCI; ++b) {
+      const int ci = 16 * (wci * NCI + b) + li;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(p.g_w + ((long)(co0 + r) * CIN + ci) * 9 + t, acc[a][b][t][r]);
+    }
+    if (wci == 0 && li == 0)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(p.g_b + co0 + r, accb[a][r]);
+  }
+  if (LAST) {
+#pragma unroll
+    for (int k = 0; k < FCN; ++k) {
+      const int q = tid + k * NT;
+      if (q < p.E * COUT) atomicAdd(p.g_wfc + q, fcw[k]);
+    }
+    if (tid < p.E) atomicAdd(p.g_bfc + tid, fcb);
+  }
+}
+
+template <int CIN, int COUT, int W, int BH>
+constexpr int wgrad_lds() {
+  return BH * W * (COUT + 8) * 2 + Img<CIN, BH, W>::BYTES + 64 + (64 + 96 + 96) * 4;
+}
+
+// ================================================================================================ dgrad
+// STAGE: the band's result goes through LDS and leaves in 16-byte pieces; without it (last layer: dy + 110 KB of weights
+// leave no room) every lane stores its 2-byte results itself -- 18 KB per frame, the smallest map of the net
+template <int CIN, int COUT, int H, int W, bool LAST, int BH, int MT, bool STAGE>
+__global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
+  static_assert(H % BH == 0 && (BH * W) % 16 == 0, "band split");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using ID = Img<COUT, BH, W>;         // haloed dy band
+  using WM = Wmat<COUT, CIN>;          // [ci][tap' * COUT + co]
+  bf16_t* dyi = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* wl = reinterpret_cast<bf16_t*>(smem + ID::BYTES);
+  constexpr int o_out = ID::BYTES + round_up(WM::BYTES, 16);
+  bf16_t* oa = reinterpret_cast<bf16_t*>(smem + o_out);                         // [BH*W][CIN]
+  float* s_dz = reinterpret_cast<float*>(smem + o_out + (STAGE ? BH * W * CIN * 2 : 0));  // [64]
+  float* s_dfeat = s_dz + 64;                                                   // [96]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+
+  zero_lds(dyi, ID::BYTES, tid);
+  for (int q = tid; q < CIN * WM::KP; q += NT) {
+    const int ci = q / WM::KP, kk = q % WM::KP, tap = kk / COUT, co = kk % COUT;
+    wl[ci * WM::LD + kk] = to_bf16(tap < 9 ? p.w[((long)co * CIN + ci) * 9 + (8 - tap)] : 0.f);
+  }
+  __syncthreads();
+  constexpr int MTILES = BH * W / 16, NTILES = CIN / 16;
+  static_assert(MTILES % MT == 0, "unit split");
+  constexpr int UNITS = (MTILES / MT) * NTILES;
+
+  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    if (LAST) {
+      last_dfeat<COUT>(p, n, s_dz, s_dfeat, 1.0f / (float)(H * W), tid);
+      __syncthreads();
+    }
+    for (int y0 = 0; y0 < H; y0 += BH) {
+      if (LAST) expand_dy_last<COUT, H * W>(p.mask + (long)n * H * W * COUT, s_dfeat, dyi, ID::at(0, 0), ID::RS, ID::PS, W, tid);
+      else expand_dy<COUT, H, W>(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, dyi,
+                                 ID::at(-1, 0), ID::RS, ID::PS, y0 - 1, BH + 2, tid);
+      __syncthreads();
+      for (int u = wv; u < UNITS; u += NW) {
+        const int mg = u % (MTILES / MT), nt = u / (MTILES / MT);
+        int base[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          const int P = 16 * (mg * MT + a) + li;
+          base[a] = ID::at(P / W - 1, P % W - 1) + 8 * g;
+        }
+        f32x4 acc[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < WM::KSTEPS; ++s) {
+          const int tap = (32 * s) / COUT, c0 = (32 * s) % COUT;
+          const int off = (tap / 3) * ID::RS + (tap % 3) * ID::PS + c0;
+          const s16x8 fb = lds_frag(wl + (16 * nt + li) * WM::LD + 32 * s + 8 * g);
+#pragma unroll
+          for (int a = 0; a < MT; ++a) acc[a] = mfma_bf16(lds_frag(dyi + base[a] + off), fb, acc[a]);
+        }
+        bf16_t* od = STAGE ? oa : p.da_in + ((long)n * H + y0) * W * CIN;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) od[(16 * (mg * MT + a) + 4 * g + r) * CIN + 16 * nt + li] = to_bf16(acc[a][r]);
+      }
+      __syncthreads();
+      if (STAGE) {
+        uint4* dst = reinterpret_cast<uint4*>(p.da_in + ((long)n * H + y0) * W * CIN);
+        for (int q = tid; q < BH * W * CIN * 2 / 16; q += NT) dst[q] = reinterpret_cast<const uint4*>(oa)[q];
+        __syncthreads();  // the next band's expansion overwrites dy, its epilogue the staging area
+      }
+    }
+  }
+}
+
+template <int CIN, int COUT, int W, int BH, bool STAGE>
+constexpr int dgrad_lds() {
+  return Img<COUT, BH, W>::BYTES + round_up(Wmat<COUT, CIN>::BYTES, 16) + (STAGE ? BH * W * CIN * 2 : 0) + (64 + 96) * 4;
+}
+
+// ================================================================================================ conv1 wgrad
+struct Conv1BwdParams {
+  const uint8_t* R;
+  int N, standardize;
+  const float* st;       // (N, 2) mean, std from the forward
+  const bf16_t* da1;     // (N, 48, 48, 16) unmasked
+  const uint8_t* i1;     // (N, 48, 48, 16)
+  float *g_w1, *g_b1;    // (16, 1, 3, 3), (16)
+};
+
+__global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
+  __shared__ float xh[98 * 100];   // haloed normalised frame, f32 (the weights' gradient keeps the un-rounded input)
+  __shared__ float s_xn[256];
+  __shared__ float s_red[NT / 16][16];
+  constexpr int HP = HW0 / 2, XS = 100;
+  const int tid = threadIdx.x, c = tid & 15, sub = tid >> 4;  // channel, pixel subset (32 of them)
+  for (int q = tid; q < 98 * XS; q += NT) xh[q] = 0.f;
+  float gw[9], gb = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) gw[k] = 0.f;
+  __syncthreads();
+  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    if (tid < 256) {
+      const float rr = (float)tid / 255.0f;
+      // rounded to bf16 as the forward kernel's image is: the gradient of the function that was actually computed
+      s_xn[tid] = from_bf16(to_bf16(p.standardize ? (rr - p.st[2 * (long)n]) / p.st[2 * (long)n + 1] : rr));
+    }
+    __syncthreads();
+    const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
+    for (int q = tid; q < HW0 * HW0 / 16; q += NT) {
+      const uint4 v = src[q];
+      const int lin = q * 16;
+      float* dst = xh + (lin / HW0 + 1) * XS + (lin % HW0) + 1;
+      const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dst[4 * e + b] = s_xn[(wds[e] >> (8 * b)) & 255u];
+    }
+    __syncthreads();
+    const bf16_t* da = p.da1 + (long)n * HP * HP * C1;
+    const uint8_t* ix = p.i1 + (long)n * HP * HP * C1;
+    for (int pp = sub; pp < HP * HP; pp += NT / 16) {
+      const unsigned e = ix[pp * C1 + c];
+      if (e < 4u) {
+        const float gval = from_bf16(da[pp * C1 + c]);
+        const int y = 2 * (pp / HP) + (int)(e >> 1), x = 2 * (pp % HP) + (int)(e & 1);
+        const float* xp = xh + y * XS + x;  // haloed (y-1+1, x-1+1)
+        gb += gval;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) gw[3 * ky + kx] += gval * xp[ky * XS + kx];
+      }
+    }
+    __syncthreads();
+  }
+  // reduce the 32 pixel subsets of every channel
+  for (int k = 0; k < 10; ++k) {
+    s_red[sub][c] = k < 9 ? gw[k] : gb;
+    __syncthreads();
+    if (tid < 16) {
+      float s = 0.f;
+      for (int j = 0; j < NT / 16; ++j) s += s_red[j][tid];
+      if (k < 9) atomicAdd(p.g_w1 + tid * 9 + k, s);
+      else atomicAdd(p.g_b1 + tid, s);
+    }
+    __syncthreads();
+  }
+}
+
+template <class P, class K>
+int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s) {
+  if (lds_bytes > 160 * 1024) return SS_ERR_UNSUPPORTED;
+  if (lds_bytes > 0 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    return SS_ERR_LAUNCH;
+  const int grid = N < 256 ? N : 256;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds_bytes, s, p);
+  return ss_launch_status();
+}
+
+}  // namespace
+
+// layer 2: a_in (N,48,48,16), da_out / idx (N,24,24,32);  layer 3: a_in (N,24,24,32), da_out / idx (N,12,12,64)
+extern "C" int ss_c5_conv_wgrad(int layer, const uint16_t* a_in, const uint16_t* da_out, const uint8_t* idx, int N, float* g_w,
+                                float* g_b, ss_stream_t stream) {
+  SS_REQUIRE(a_in && da_out && idx && g_w && g_b && N > 0, SS_ERR_ARG);
+  ConvBwdParams p{};
+  p.N = N; p.a_in = a_in; p.da_out = da_out; p.idx = idx; p.g_w = g_w; p.g_b = g_b;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (layer == 2) return launch_persistent(conv_wgrad_kernel<C1, C2, 48, 48, false, 16, 1, 1, 8>, p, wgrad_lds<C1, C2, 48, 16>(), N, s);
+  if (layer == 3) return launch_persistent(conv_wgrad_kernel<C2, C3, 24, 24, false, 24, 2, 2, 2>, p, wgrad_lds<C2, C3, 24, 24>(), N, s);
+  return SS_ERR_UNSUPPORTED;
+}
+
+extern "C" int ss_c5_conv_dgrad(int layer, const uint16_t* da_out, const uint8_t* idx, int N, const float* w, uint16_t* da_in,
+                                ss_stream_t stream) {
+  SS_REQUIRE(da_out && idx && w && da_in && N > 0, SS_ERR_ARG);
+  ConvBwdParams p{};
+  p.N = N; p.da_out = da_out; p.idx = idx; p.w = w; p.da_in = da_in;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (layer == 2) return launch_persistent(conv_dgrad_kernel<C1, C2, 48, 48, false, 16, 12, true>, p, dgrad_lds<C1, C2, 48, 16, true>(), N, s);
+  if (layer == 3) return launch_persistent(conv_dgrad_kernel<C2, C3, 24, 24, false, 12, 9, true>, p, dgrad_lds<C2, C3, 24, 12, true>(), N, s);
+  return SS_ERR_UNSUPPORTED;
+}
+
+// last layer (conv 64 -> 96 on 12 x 12, global average, Linear(96 -> E)): d z (N,E) -> d W4, d b4, d Wfc, d bfc / d a3
+extern "C" int ss_c5_conv_last_wgrad(const uint16_t* a_in, const float* dz, int ld_dz, int E, const float* wfc, const uint8_t* mask,
+                                     const float* feat, int N, float* g_w, float* g_b, float* g_wfc, float* g_bfc,
+                                     ss_stream_t stream) {
+  SS_REQUIRE(a_in && dz && wfc && mask && feat && g_w && g_b && g_wfc && g_bfc && N > 0, SS_ERR_ARG);
+  SS_REQUIRE(E > 0 && E <= 64 && ld_dz >= E, SS_ERR_UNSUPPORTED);
+  ConvBwdParams p{};
+  p.N = N; p.a_in = a_in; p.dz = dz; p.ld_dz = ld_dz; p.E = E; p.wfc = wfc; p.mask = mask; p.feat = feat;
+  p.g_w = g_w; p.g_b = g_b; p.g_wfc = g_wfc; p.g_bfc = g_bfc;
+  return launch_persistent(conv_wgrad_kernel<C3, C4, 12, 12, true, 12, 2, 4, 1>, p, wgrad_lds<C3, C4, 12, 12>(), N,
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ss_c5_conv_last_dgrad(const float* dz, int ld_dz, int E, const float* wfc, const uint8_t* mask, int N, const float* w,
+                                     uint16_t* da_in, ss_stream_t stream) {
+  SS_REQUIRE(dz && wfc && mask && w && da_in && N > 0, SS_ERR_ARG);
+  SS_REQUIRE(E > 0 && E <= 64 && ld_dz >= E, SS_ERR_UNSUPPORTED);
+  ConvBwdParams p{};
+  p.N = N; p.dz = dz; p.ld_dz = ld_dz; p.E = E; p.wfc = wfc; p.mask = mask; p.w = w; p.da_in = da_in;
+  return launch_persistent(conv_dgrad_kernel<C3, C4, 12, 12, true, 12, 9, false>, p, dgrad_lds<C3, C4, 12, 12, false>(), N,
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ss_c5_conv1_wgrad(const uint8_t* R, int N, int standardize, const float* st, const uint16_t* da1, const uint8_t* i1,
+                                 float* g_w1, float* g_b1, ss_stream_t stream) {
+  SS_REQUIRE(R && st && da1 && i1 && g_w1 && g_b1 && N > 0, SS_ERR_ARG);
+  Conv1BwdParams p{R, N, standardize, st, da1, i1, g_w1, g_b1};
+  return launch_persistent(conv1_wgrad_kernel, p, 0, N, static_cast<hipStream_t>(stream));
+}

@@ -157,3 +157,237 @@ def test_gru_bf16_fwd_bwd(L, B, T, H):
         dW = torch.einsum("btg,bth->gh", dgh, hprev)
         refW = whh_l[d].grad
         assert float((dW - refW).abs().max()) < 3e-2 * float(refW.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ ROI CNN (cnn_bf16*.hip)
+import torch.nn.functional as F  # noqa: E402
+
+C5 = [1, 16, 32, 64, 96]
+
+
+def nhwc_bf16(x):
+    """(N,C,H,W) f32 holding bf16 values -> device int16 tensor (N,H,W,C) of the bf16 bit patterns."""
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).view(torch.int16).cuda()
+
+
+def from_nhwc(t, dtype=torch.bfloat16):
+    """device (N,H,W,C) bit patterns -> CPU (N,C,H,W) f32."""
+    return t.cpu().view(dtype).float().permute(0, 3, 1, 2).contiguous()
+
+
+def pool_ref(c, bias):
+    """raw conv output (N,C,H,W) -> (pooled ReLU(max + b) f32, argmax byte with the kernels' encoding, top-2 gap)."""
+    n, ch, h, w = c.shape
+    win = c.reshape(n, ch, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, ch, h // 2, w // 2, 4)
+    best, bi = win.max(dim=-1)
+    val = torch.relu(best + bias.view(1, -1, 1, 1))
+    idx = torch.where(val > 0, bi, torch.full_like(bi, 4)).to(torch.uint8)
+    top = win.topk(2, dim=-1).values
+    return val, idx, top[..., 0] - top[..., 1]
+
+
+def assert_bf16_close(name, got, ref, frac_exact=0.995):
+    """``got`` holds bf16 values a kernel rounded from f32 sums; ``ref`` the same sums from another summation order."""
+    refb = bf(ref)
+    exact = (got == refb).float().mean().item()
+    err = (got - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 1e-6 * max(1.0, float(ref.abs().max()))
+    assert bool((err <= tol).all()), f"{name}: max err {float(err.max()):.3e} (ref max {float(ref.abs().max()):.3e})"
+    assert exact >= frac_exact, f"{name}: only {exact:.4f} of the elements round identically"
+
+
+def expand_ref(da, idx):
+    """pooled-grid gradient (N,C,h,w) + argmax bytes -> dense (N,C,2h,2w)."""
+    n, c, h, w = da.shape
+    out = torch.zeros(n, c, h, 2, w, 2)
+    for e in range(4):
+        out[:, :, :, e >> 1, :, e & 1] = torch.where(idx == e, da, torch.zeros_like(da))
+    return out.reshape(n, c, 2 * h, 2 * w)
+
+
+def normalise_like_kernel(R, standardize=True):
+    """The forward kernel's per-frame normalisation, operation by operation (exact integer sums, f64 mean / variance,
+    f32 table of the 256 grey levels, train_model_official.py:286-291): -> (xn f32 (N,96,96), mu (N,), sd (N,))."""
+    Rn = R.numpy().astype(np.int64)
+    N = Rn.shape[0]
+    xn = np.empty(Rn.shape, np.float32)
+    mus, sds = np.zeros(N, np.float32), np.ones(N, np.float32)
+    lev = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    for n in range(N):
+        tab = lev
+        if standardize:
+            tsu, tsq, nn = float(Rn[n].sum()), float((Rn[n] ** 2).sum()), float(Rn[n].size)
+            mu = np.float32(np.float32(tsu / nn) / np.float32(255.0))
+            var = (tsq - tsu * tsu / nn) / (nn - 1.0)
+            sd = max(np.float32(np.sqrt(max(var, 0.0)) / 255.0), np.float32(1e-6))
+            tab = ((lev - mu) / sd).astype(np.float32)
+            mus[n], sds[n] = mu, sd
+        xn[n] = tab[Rn[n]]
+    return torch.from_numpy(xn), torch.from_numpy(mus), torch.from_numpy(sds)
+
+
+@pytest.mark.parametrize("N,standardize", [(3, 1), (300, 1), (4, 0)])
+def test_c5_conv1_fwd(L, N, standardize):
+    g = torch.Generator().manual_seed(N)
+    R = torch.randint(0, 256, (N, 96, 96), generator=g, dtype=torch.uint8)
+    R[0] = 7                     # constant frame: std clamp, every normalised pixel is exactly 0
+    R[1] = 200
+    R[1, 5, 9] = 201             # near-constant frame
+    w1 = torch.randn(16, 1, 3, 3, generator=g) * 0.4
+    b1 = torch.randn(16, generator=g) * 0.2
+    xn, mu, sd = normalise_like_kernel(R, bool(standardize))
+    c1 = F.conv2d(bf(xn).unsqueeze(1).double(), bf(w1).double(), padding=1).float()
+    val, idx, gap = pool_ref(c1, b1)
+    a1 = torch.empty(N, 48, 48, 16, device="cuda", dtype=torch.int16)
+    i1 = torch.empty(N, 48, 48, 16, device="cuda", dtype=torch.uint8)
+    st = torch.empty(N, 2, device="cuda")
+    L.call("ss_c5_conv1_fwd", R.cuda().data_ptr(), N, standardize, w1.cuda().data_ptr(), b1.cuda().data_ptr(), a1.data_ptr(),
+           i1.data_ptr(), st.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    if standardize:
+        assert torch.equal(st[:, 0].cpu(), mu) and torch.equal(st[:, 1].cpu(), sd)
+        # the statistics are torch's (train_model_official.py:288-290) to f32 rounding
+        r = R.float() / 255.0
+        assert float((mu - r.mean(dim=(1, 2))).abs().max()) < 1e-6
+        assert float(((sd - r.std(dim=(1, 2)).clamp_min(1e-6)) / sd).abs().max()) < 1e-5
+    got = from_nhwc(a1)
+    if standardize:  # constant frame: conv output 0 everywhere -> ReLU(bias)
+        assert torch.equal(got[0], bf(torch.relu(b1)).view(16, 1, 1).expand(16, 48, 48))
+    assert_bf16_close("a1", got, val)
+    sure = (gap > 1e-3) & ((val > 1e-3) | (val == 0))
+    assert torch.equal(i1.cpu().permute(0, 3, 1, 2)[sure], idx[sure])
+
+
+@pytest.mark.parametrize("layer,N", [(2, 2), (2, 270), (3, 3), (3, 300)])
+def test_c5_conv_fwd(L, layer, N):
+    cin, cout = C5[layer - 1], C5[layer]
+    hw = 96 >> (layer - 1)
+    g = torch.Generator().manual_seed(layer * 100 + N)
+    a_in = bf(torch.relu(torch.randn(N, cin, hw, hw, generator=g)))
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    c = F.conv2d(a_in.double(), bf(w).double(), padding=1).float()
+    val, idx, gap = pool_ref(c, b)
+    out = torch.empty(N, hw // 2, hw // 2, cout, device="cuda", dtype=torch.int16)
+    io = torch.empty(N, hw // 2, hw // 2, cout, device="cuda", dtype=torch.uint8)
+    L.call("ss_c5_conv_fwd", layer, nhwc_bf16(a_in).data_ptr(), N, w.cuda().data_ptr(), b.cuda().data_ptr(), out.data_ptr(),
+           io.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert_bf16_close(f"a{layer}", from_nhwc(out), val)
+    sure = (gap > 1e-3) & ((val > 1e-3) | (val == 0))
+    assert torch.equal(io.cpu().permute(0, 3, 1, 2)[sure], idx[sure])
+
+
+@pytest.mark.parametrize("N", [3, 300])
+def test_c5_conv_last_fwd(L, N):
+    g = torch.Generator().manual_seed(N)
+    E, ld = 64, 148
+    a3 = bf(torch.relu(torch.randn(N, 64, 12, 12, generator=g)))
+    w = torch.randn(96, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(96, generator=g) * 0.1
+    wfc = torch.randn(E, 96, generator=g) / 10.0
+    bfc = torch.randn(E, generator=g) * 0.1
+    x = F.conv2d(a3.double(), bf(w).double(), padding=1).float() + b.view(1, -1, 1, 1)
+    feat = torch.relu(x).mean(dim=(2, 3))
+    z_ref = feat @ wfc.t() + bfc
+    z = torch.full((N, ld), 5.0, device="cuda")
+    mask = torch.empty(N, 144, 96, device="cuda", dtype=torch.uint8)
+    fo = torch.empty(N, 96, device="cuda")
+    L.call("ss_c5_conv_last_fwd", nhwc_bf16(a3).data_ptr(), N, w.cuda().data_ptr(), b.cuda().data_ptr(), wfc.cuda().data_ptr(),
+           bfc.cuda().data_ptr(), E, z.data_ptr() + 84 * 4, ld, mask.data_ptr(), fo.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert float((fo.cpu() - feat).abs().max()) < 2e-5
+    assert float((z[:, 84:].cpu() - z_ref).abs().max()) < 5e-5 and float((z[:, :84] - 5.0).abs().max()) == 0.0
+    m_ref = (x > 0).reshape(N, 96, 144).permute(0, 2, 1)
+    sure = (x.abs() > 1e-3).reshape(N, 96, 144).permute(0, 2, 1)
+    assert torch.equal(mask.cpu().bool()[sure], m_ref[sure])
+    # inference form: no stash
+    z2 = torch.zeros(N, E, device="cuda")
+    L.call("ss_c5_conv_last_fwd", nhwc_bf16(a3).data_ptr(), N, w.cuda().data_ptr(), b.cuda().data_ptr(), wfc.cuda().data_ptr(),
+           bfc.cuda().data_ptr(), E, z2.data_ptr(), E, None, None, L.stream())
+    torch.cuda.synchronize()
+    assert float((z2.cpu() - z_ref).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("layer,N", [(2, 2), (2, 270), (3, 3), (3, 300)])
+def test_c5_conv_bwd(L, layer, N):
+    cin, cout = C5[layer - 1], C5[layer]
+    hw = 96 >> (layer - 1)
+    g = torch.Generator().manual_seed(layer * 10 + N)
+    a_in = bf(torch.relu(torch.randn(N, cin, hw, hw, generator=g)))
+    da = bf(torch.randn(N, cout, hw // 2, hw // 2, generator=g))
+    idx = torch.randint(0, 5, (N, cout, hw // 2, hw // 2), generator=g).to(torch.uint8)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)
+    dy = expand_ref(da, idx)
+    gw_ref = torch.nn.grad.conv2d_weight(a_in.double(), w.shape, dy.double(), padding=1).float()
+    gb_ref = dy.double().sum(dim=(0, 2, 3)).float()
+    din_ref = F.conv_transpose2d(dy.double(), bf(w).double(), padding=1).float()
+    a_d, da_d = nhwc_bf16(a_in), nhwc_bf16(da)
+    idx_d = idx.permute(0, 2, 3, 1).contiguous().cuda()
+    gw = torch.ones(cout, cin, 3, 3, device="cuda")   # gradients accumulate: start from 1
+    gb = torch.ones(cout, device="cuda")
+    L.call("ss_c5_conv_wgrad", layer, a_d.data_ptr(), da_d.data_ptr(), idx_d.data_ptr(), N, gw.data_ptr(), gb.data_ptr(), L.stream())
+    din = torch.empty(N, hw, hw, cin, device="cuda", dtype=torch.int16)
+    L.call("ss_c5_conv_dgrad", layer, da_d.data_ptr(), idx_d.data_ptr(), N, w.cuda().data_ptr(), din.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert float((gw.cpu() - 1.0 - gw_ref).abs().max()) < 2e-4 * float(gw_ref.abs().max())
+    assert float((gb.cpu() - 1.0 - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
+    assert_bf16_close(f"da{layer - 1}", from_nhwc(din), din_ref)
+
+
+@pytest.mark.parametrize("N", [3, 300])
+def test_c5_conv_last_bwd(L, N):
+    g = torch.Generator().manual_seed(N + 5)
+    E, ld = 64, 148
+    a3 = bf(torch.relu(torch.randn(N, 64, 12, 12, generator=g)))
+    w = torch.randn(96, 64, 3, 3, generator=g) / 24.0
+    wfc = torch.randn(E, 96, generator=g) / 10.0
+    dz = torch.zeros(N, ld)
+    dz[:, 84:] = torch.randn(N, E, generator=g)
+    mask = torch.rand(N, 96, 12, 12, generator=g) < 0.5
+    feat = torch.rand(N, 96, generator=g)
+    dfeat = (dz[:, 84:] @ wfc) * (1.0 / 144.0)
+    dy = bf(dfeat).view(N, 96, 1, 1) * mask.float()
+    gw_ref = torch.nn.grad.conv2d_weight(a3.double(), w.shape, dy.double(), padding=1).float()
+    gb_ref = dy.double().sum(dim=(0, 2, 3)).float()
+    gwfc_ref = dz[:, 84:].t() @ feat
+    gbfc_ref = dz[:, 84:].sum(0)
+    din_ref = F.conv_transpose2d(dy.double(), bf(w).double(), padding=1).float()
+    m_d = mask.reshape(N, 96, 144).permute(0, 2, 1).contiguous().to(torch.uint8).cuda()
+    dz_d, wfc_d, feat_d, a_d = dz.cuda(), wfc.cuda(), feat.cuda(), nhwc_bf16(a3)
+    gw = torch.zeros(96, 64, 3, 3, device="cuda")
+    gb = torch.zeros(96, device="cuda")
+    gwfc = torch.zeros(E, 96, device="cuda")
+    gbfc = torch.zeros(E, device="cuda")
+    L.call("ss_c5_conv_last_wgrad", a_d.data_ptr(), dz_d.data_ptr() + 84 * 4, ld, E, wfc_d.data_ptr(), m_d.data_ptr(), feat_d.data_ptr(),
+           N, gw.data_ptr(), gb.data_ptr(), gwfc.data_ptr(), gbfc.data_ptr(), L.stream())
+    din = torch.empty(N, 12, 12, 64, device="cuda", dtype=torch.int16)
+    L.call("ss_c5_conv_last_dgrad", dz_d.data_ptr() + 84 * 4, ld, E, wfc_d.data_ptr(), m_d.data_ptr(), N, w.cuda().data_ptr(),
+           din.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert float((gw.cpu() - gw_ref).abs().max()) < 3e-4 * float(gw_ref.abs().max())
+    assert float((gb.cpu() - gb_ref).abs().max()) < 3e-4 * float(gb_ref.abs().max())
+    assert float((gwfc.cpu() - gwfc_ref).abs().max()) < 1e-4 * float(gwfc_ref.abs().max())
+    assert float((gbfc.cpu() - gbfc_ref).abs().max()) < 1e-4 * float(gbfc_ref.abs().max())
+    assert_bf16_close("da3", from_nhwc(din), din_ref, frac_exact=0.98)
+
+
+@pytest.mark.parametrize("N", [2, 300])
+def test_c5_conv1_wgrad(L, N):
+    g = torch.Generator().manual_seed(N + 11)
+    R = torch.randint(0, 256, (N, 96, 96), generator=g, dtype=torch.uint8)
+    xn, mu, sd = normalise_like_kernel(R)
+    xn = bf(xn)
+    da = bf(torch.randn(N, 16, 48, 48, generator=g))
+    idx = torch.randint(0, 5, (N, 16, 48, 48), generator=g).to(torch.uint8)
+    dy = expand_ref(da, idx)
+    gw_ref = torch.nn.grad.conv2d_weight(xn.unsqueeze(1).double(), (16, 1, 3, 3), dy.double(), padding=1).float()
+    gb_ref = dy.double().sum(dim=(0, 2, 3)).float()
+    st = torch.stack([mu, sd], 1).contiguous().cuda()
+    gw = torch.zeros(16, 1, 3, 3, device="cuda")
+    gb = torch.zeros(16, device="cuda")
+    L.call("ss_c5_conv1_wgrad", R.cuda().data_ptr(), N, 1, st.data_ptr(), nhwc_bf16(da).data_ptr(),
+           idx.permute(0, 2, 3, 1).contiguous().cuda().data_ptr(), gw.data_ptr(), gb.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert float((gw.cpu() - gw_ref).abs().max()) < 2e-4 * float(gw_ref.abs().max())
+    assert float((gb.cpu() - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
