@@ -140,15 +140,17 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
   constexpr int NPIX = BH * W, NCH = (NPIX + 31) / 32;
   bf16_t* dyi = reinterpret_cast<bf16_t*>(smem);
   bf16_t* ai = reinterpret_cast<bf16_t*>(smem + DY_BYTES);
-  bf16_t* zeros = reinterpret_cast<bf16_t*>(smem + DY_BYTES + IA::BYTES);    // 64 bytes of zeros: pixels past the band
-  float* s_dz = reinterpret_cast<float*>(smem + DY_BYTES + IA::BYTES + 64);  // [64]
+  constexpr int ZB = 256;  // a pixel's worth of zeros (COUT <= 96 channels + the lane's piece): what pixels past the band read
+  bf16_t* zeros = reinterpret_cast<bf16_t*>(smem + DY_BYTES + IA::BYTES);
+  float* s_dz = reinterpret_cast<float*>(smem + DY_BYTES + IA::BYTES + ZB);  // [64]
   float* s_dfeat = s_dz + 64;                                                // [COUT]
   float* s_feat = s_dfeat + 96;                                              // [COUT]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
   const int q4 = li >> 2, p4 = li & 3;
   const int wco = wv % WCO, wci = (wv / WCO) % WCI, wk = wv / (WCO * WCI);
-  zero_lds(smem, DY_BYTES + IA::BYTES + 64, tid);
+  static_assert((COUT + 8) * 2 <= ZB, "zero pixel");
+  zero_lds(smem, DY_BYTES + IA::BYTES + ZB, tid);
 
   f32x4 acc[NCO][NCI][9];
   f32x4 accb[NCO];
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
 
 template <int CIN, int COUT, int W, int BH>
 constexpr int wgrad_lds() {
-  return BH * W * (COUT + 8) * 2 + Img<CIN, BH, W>::BYTES + 64 + (64 + 96 + 96) * 4;
+  return BH * W * (COUT + 8) * 2 + Img<CIN, BH, W>::BYTES + 256 + (64 + 96 + 96) * 4;
 }
 
 // ================================================================================================ dgrad

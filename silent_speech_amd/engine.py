@@ -51,6 +51,8 @@ class Config:
     head_dropout: float = 0.2
     head_mid: int = 128
     ln_eps: float = 1e-5
+    cnn_channels: tuple = (8, 16, 24)
+    precision: str = "f32"  # "bf16": the wide-model path of engine_bf16.py (BASELINE config 5)
 
     @property
     def in_dim(self) -> int:
@@ -135,8 +137,18 @@ def _addr(t: torch.Tensor, offset_elems: int = 0) -> int:
     return t.data_ptr() + offset_elems * t.element_size()
 
 
+def make_workspace(cfg: Config, B: int, T: int, roi_hw, device, train: bool):
+    if cfg.precision == "bf16":
+        from .engine_bf16 import WorkspaceBf16
+
+        return WorkspaceBf16(cfg, B, T, roi_hw, device, train)
+    return Workspace(cfg, B, T, roi_hw, device, train)
+
+
 class Workspace:
     """Activation / gradient buffers for one (B, T, H, W) shape; reused across steps (hipGraph friendly)."""
+
+    bf16 = False
 
     def __init__(self, cfg: Config, B: int, T: int, roi_hw, device, train: bool):
         self.cfg, self.B, self.T, self.roi_hw, self.train = cfg, B, T, roi_hw, train
@@ -206,6 +218,10 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
     ``train`` turns the two dropouts on (p from cfg); ``stash`` keeps what ``backward`` needs (needs a
     Workspace built with train=True).  ``ce = (y_ptr, label_smoothing, denom, loss_ptr, correct_ptr)`` makes the
     fused tail kernel also evaluate the loss and leave d(loss)/d(logits) in ``ws.d_logits``."""
+    if ws.bf16:
+        from . import engine_bf16
+
+        return engine_bf16.forward(P, cfg, ws, X, R, train=train, stash=stash, seed=seed, ce=ce, x_in_place=x_in_place)
     B, T, H, N = ws.B, ws.T, cfg.hidden, ws.B * ws.T
     s = L.stream()
     if stash and not ws.train:
@@ -264,6 +280,10 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
              d_X: Optional[torch.Tensor] = None) -> None:
     """Accumulates d(loss)/d(param) into ``G`` (same keys as ``P``) given d(loss)/d(logits).
     Must follow a ``forward(..., train=<same>, seed=<same>)`` on the same workspace."""
+    if ws.bf16:
+        from . import engine_bf16
+
+        return engine_bf16.backward(P, G, cfg, ws, X, R, d_logits, train=train, seed=seed, d_X=d_X)
     B, T, H, N = ws.B, ws.T, cfg.hidden, ws.B * ws.T
     s = L.stream()
     C, MID = cfg.num_classes, cfg.head_mid

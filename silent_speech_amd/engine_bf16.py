@@ -1,0 +1,263 @@
+"""Kernel orchestration of the bf16-MFMA path (BASELINE config 5: 100 words, 96x96 ROI, CNN 16/32/64/96, BiGRU H = 512).
+
+Same contract as ``engine.py`` (explicit forward / backward over raw device buffers, no aten compute op, no CPU
+fallback); what differs is the kernel set:
+
+    ROI CNN      ss_c5_conv1_fwd -> ss_c5_conv_fwd(2) -> ss_c5_conv_fwd(3) -> ss_c5_conv_last_fwd   (cnn_bf16.hip)
+                 pooled maps between the layers: NHWC bf16 in HBM + one argmax byte per element (the training stash)
+    GRU layers   ss_gemm_bf16_batched (input projections, d layer_in, weight gradients) + ss_gru_bf16_fwd / _bwd
+                 (one launch per time step, both directions; W_hh as bf16 copies made once per step by ss_gru_bf16_prep)
+    tail         the f32 fused AttnPool / head / CE kernels of the f32 path (0.1 % of the FLOPs)
+
+f32 master weights, f32 gradients, f32 Adam: only MFMA operands are bf16.  The reference defines no such model
+(SURVEY.md 8d row 5); the module is train_model_official.py:209-310 with wider layers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+
+INT_MAX = 2**31 - 1
+CNN_CHANNELS = (16, 32, 64, 96)
+ROI_HW = (96, 96)
+_IDENT = (INT_MAX, 0, 0)
+
+
+def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, atomic=False, splits=1, a_map=_IDENT,
+         b_map=_IDENT, batch=1, strides=(0, 0, 0, 0), tag="gemm_bf16"):
+    flags = (1 if accumulate else 0) | (4 if atomic else 0)
+    L.call("ss_gemm_bf16_batched", int(a_kc), int(b_kc), M, N, K, A, lda, *a_map, B, ldb, *b_map, Cm, ldc, bias, flags, splits,
+           batch, *strides, L.stream(), tag=tag)
+
+
+def split_k(M, N, K, batch, target_wgs=768):
+    tiles = -(-M // 128) * -(-N // 128) * batch
+    return max(1, min(-(-K // 32), target_wgs // tiles))
+
+
+def _pstride(P, a: str, b: str) -> int:
+    return (P[b].data_ptr() - P[a].data_ptr()) // 4
+
+
+def _addr(t: torch.Tensor, offset_elems: int = 0) -> int:
+    return t.data_ptr() + offset_elems * t.element_size()
+
+
+def check_config(cfg, roi_hw) -> None:
+    if cfg.hidden % 128 != 0:
+        raise RuntimeError("precision='bf16' needs hidden % 128 == 0 (ss_gru_bf16_*); use the f32 path for small hidden sizes")
+    if cfg.use_roi and (tuple(cfg.cnn_channels) != CNN_CHANNELS or tuple(roi_hw) != ROI_HW):
+        raise RuntimeError(f"the bf16 ROI CNN is built for channels {CNN_CHANNELS} on {ROI_HW[0]}x{ROI_HW[1]} frames "
+                           f"(got {tuple(cfg.cnn_channels)} on {tuple(roi_hw)})")
+    if cfg.in_dim % 4 != 0:
+        raise RuntimeError("precision='bf16' needs (x_dim + roi_emb) % 4 == 0 (16-byte operand loads of the GEMM)")
+
+
+class WorkspaceBf16:
+    """Activation / gradient buffers of the bf16 path for one (B, T) shape."""
+
+    bf16 = True
+
+    def __init__(self, cfg, B: int, T: int, roi_hw, device, train: bool):
+        check_config(cfg, roi_hw if cfg.use_roi else ROI_HW)
+        self.cfg, self.B, self.T, self.roi_hw, self.train = cfg, B, T, roi_hw, train
+        self.stash_gen, self.stash_live = 0, False
+        self.stagger = False
+        N, H = B * T, cfg.hidden
+        f32 = dict(device=device, dtype=torch.float32)
+        u8 = dict(device=device, dtype=torch.uint8)
+        i16 = dict(device=device, dtype=torch.int16)  # bf16 bit patterns
+        self.lengths = torch.empty(B, device=device, dtype=torch.int32)
+        self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
+        self.gi = [torch.empty(2, N, 3 * H, **f32) for _ in range(cfg.gru_layers)]
+        self.out = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers)]
+        self.out_drop = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers - 1)]
+        self.whh = [torch.empty(2, 3 * H, H, **i16) for _ in range(cfg.gru_layers)]
+        self.whht = [torch.empty(2, H, 3 * H, **i16) for _ in range(cfg.gru_layers)]
+        nb = C.c_long(0)
+        if L.load().ss_gru_bf16_ws_bytes(B, H, C.byref(nb)) != 0:
+            raise RuntimeError("ss_gru_bf16_ws_bytes failed")
+        self.gru_ws = torch.empty(nb.value, **u8)
+        self.logits = torch.empty(B, cfg.num_classes, **f32)
+        self.attn = torch.empty(B, T, **f32)
+        self.mid_drop = torch.empty(B, cfg.head_mid, **f32)
+        self.ln = torch.empty(B, 2 * H, **f32)
+        self.mid = torch.empty(B, cfg.head_mid, **f32)
+        if cfg.use_roi:
+            c1, c2, c3, c4 = CNN_CHANNELS
+            self.a1 = torch.empty(N, 48, 48, c1, **i16)
+            self.i1 = torch.empty(N, 48, 48, c1, **u8)
+            self.a2 = torch.empty(N, 24, 24, c2, **i16)
+            self.i2 = torch.empty(N, 24, 24, c2, **u8)
+            self.a3 = torch.empty(N, 12, 12, c3, **i16)
+            self.i3 = torch.empty(N, 12, 12, c3, **u8)
+        if train:
+            self.save = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
+            self.dG = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
+            self.d_out = torch.empty(N, 2 * H, **f32)
+            self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
+            self.xhat = torch.empty(B, 2 * H, **f32)
+            self.rstd = torch.empty(B, **f32)
+            self.d_logits = torch.empty(B, cfg.num_classes, **f32)
+            self.d_mid = torch.empty(B, cfg.head_mid, **f32)
+            self.tail_part = torch.empty(B, 3, 2 * H, **f32)
+            self.dZ = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
+            if cfg.use_roi:
+                c1, c2, c3, c4 = CNN_CHANNELS
+                self.st = torch.empty(N, 2, **f32)
+                self.m4 = torch.empty(N, 144, c4, **u8)
+                self.feat = torch.empty(N, c4, **f32)
+                self.da1 = torch.empty(N, 48, 48, c1, **i16)
+                self.da2 = torch.empty(N, 24, 24, c2, **i16)
+                self.da3 = torch.empty(N, 12, 12, c3, **i16)
+
+
+_CONV = ("roi_cnn.net.0", "roi_cnn.net.3", "roi_cnn.net.6", "roi_cnn.net.9")
+
+
+def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor, R: Optional[torch.Tensor], *, train: bool,
+            stash: bool = False, seed: int = 0, ce=None, x_in_place: bool = False) -> torch.Tensor:
+    B, T, H, N = ws.B, ws.T, cfg.hidden, ws.B * ws.T
+    s = L.stream()
+    if stash and not ws.train:
+        raise RuntimeError("stash=True needs a training workspace")
+    if cfg.use_roi:
+        if not x_in_place:
+            L.call("ss_copy_rows_f32", X.data_ptr(), cfg.x_dim, ws.Z.data_ptr(), cfg.in_dim, N, cfg.x_dim, s)
+        w = [P[k + ".weight"].data_ptr() for k in _CONV]
+        b = [P[k + ".bias"].data_ptr() for k in _CONV]
+        L.call("ss_c5_conv1_fwd", R.data_ptr(), N, int(cfg.roi_standardize), w[0], b[0], ws.a1.data_ptr(), ws.i1.data_ptr(),
+               ws.st.data_ptr() if stash else None, s)
+        L.call("ss_c5_conv_fwd", 2, ws.a1.data_ptr(), N, w[1], b[1], ws.a2.data_ptr(), ws.i2.data_ptr(), s, tag="ss_c5_conv2_fwd")
+        L.call("ss_c5_conv_fwd", 3, ws.a2.data_ptr(), N, w[2], b[2], ws.a3.data_ptr(), ws.i3.data_ptr(), s, tag="ss_c5_conv3_fwd")
+        L.call("ss_c5_conv_last_fwd", ws.a3.data_ptr(), N, w[3], b[3], P["roi_cnn.fc.weight"].data_ptr(), P["roi_cnn.fc.bias"].data_ptr(),
+               cfg.roi_emb, _addr(ws.Z, cfg.x_dim), cfg.in_dim, ws.m4.data_ptr() if stash else None,
+               ws.feat.data_ptr() if stash else None, s)
+        layer_in, ld_in = ws.Z.data_ptr(), cfg.in_dim
+    else:
+        layer_in, ld_in = X.data_ptr(), cfg.x_dim
+    for l in range(cfg.gru_layers):
+        K = cfg.in_dim if l == 0 else 2 * H
+        wf, wr = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
+        L.call("ss_gru_bf16_prep", P[f"gru.weight_hh_l{l}"].data_ptr(), P[f"gru.weight_hh_l{l}_reverse"].data_ptr(), H,
+               ws.whh[l].data_ptr(), ws.whht[l].data_ptr(), s)
+        gemm(1, 1, N, 3 * H, K, layer_in, ld_in, P[wf].data_ptr(), K, ws.gi[l].data_ptr(), 3 * H, bias=P[f"gru.bias_ih_l{l}"].data_ptr(),
+             batch=2, strides=(0, _pstride(P, wf, wr), N * 3 * H, _pstride(P, f"gru.bias_ih_l{l}", f"gru.bias_ih_l{l}_reverse")),
+             tag="gemm_bf16_ih")
+        L.call("ss_gru_bf16_fwd", ws.gi[l].data_ptr(), ws.whh[l].data_ptr(), P[f"gru.bias_hh_l{l}"].data_ptr(),
+               P[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.lengths.data_ptr(), B, T, H, ws.out[l].data_ptr(),
+               ws.save[l].data_ptr() if stash else None, ws.gru_ws.data_ptr(), s)
+        layer_in, ld_in = ws.out[l].data_ptr(), 2 * H
+        if train and l < cfg.gru_layers - 1 and cfg.gru_dropout > 0.0:
+            L.call("ss_dropout", ws.out[l].data_ptr(), ws.out_drop[l].data_ptr(), N * 2 * H, cfg.gru_dropout, seed, (l + 1) << 40,
+                   None, s)
+            layer_in = ws.out_drop[l].data_ptr()
+    top = ws.out[cfg.gru_layers - 1]
+    p_drop = cfg.head_dropout if train else 0.0
+    y_ptr, ls, denom, loss_ptr, correct_ptr = ce if ce is not None else (None, 0.0, 1.0, None, None)
+    L.call("ss_tail_fwd", top.data_ptr(), ws.lengths.data_ptr(), P["pool.score.weight"].data_ptr(), P["pool.score.bias"].data_ptr(),
+           P["head.0.weight"].data_ptr(), P["head.0.bias"].data_ptr(), P["head.1.weight"].data_ptr(), P["head.1.bias"].data_ptr(),
+           P["head.4.weight"].data_ptr(), P["head.4.bias"].data_ptr(), y_ptr, B, T, 2 * H, cfg.head_mid, cfg.num_classes, cfg.ln_eps,
+           p_drop, seed, 7 << 40, ls, denom, ws.attn.data_ptr() if stash else None, ws.xhat.data_ptr() if stash else None,
+           ws.rstd.data_ptr() if stash else None, ws.ln.data_ptr() if stash else None, ws.mid.data_ptr() if stash else None,
+           ws.mid_drop.data_ptr() if stash else None, ws.logits.data_ptr(), ws.d_logits.data_ptr() if ce is not None else None,
+           loss_ptr, correct_ptr, s)
+    return ws.logits
+
+
+def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
+             R: Optional[torch.Tensor], d_logits: torch.Tensor, *, train: bool, seed: int = 0,
+             d_X: Optional[torch.Tensor] = None) -> None:
+    from .engine import gemm as gemm_f32  # the head's two tiny weight-gradient GEMMs stay f32
+
+    B, T, H, N = ws.B, ws.T, cfg.hidden, ws.B * ws.T
+    s = L.stream()
+    Cn, MID = cfg.num_classes, cfg.head_mid
+    p_drop = cfg.head_dropout if train else 0.0
+    top = ws.out[cfg.gru_layers - 1]
+    L.call("ss_tail_bwd", top.data_ptr(), ws.lengths.data_ptr(), P["pool.score.weight"].data_ptr(), P["head.0.weight"].data_ptr(),
+           P["head.1.weight"].data_ptr(), P["head.4.weight"].data_ptr(), ws.attn.data_ptr(), ws.xhat.data_ptr(), ws.rstd.data_ptr(),
+           ws.mid.data_ptr(), d_logits.data_ptr(), B, T, 2 * H, MID, Cn, p_drop, seed, 7 << 40, ws.d_mid.data_ptr(),
+           ws.d_out.data_ptr(), G["head.0.weight"].data_ptr(), G["head.0.bias"].data_ptr(), G["pool.score.weight"].data_ptr(),
+           G["pool.score.bias"].data_ptr(), ws.tail_part.data_ptr(), s)
+    for k_, name_ in enumerate(("head.0.weight", "head.0.bias", "pool.score.weight")):
+        L.call("ss_colsum_f32", _addr(ws.tail_part, k_ * 2 * H), B, 2 * H, 3 * 2 * H, G[name_].data_ptr(), s)
+    gemm_f32(0, 0, Cn, MID, B, d_logits.data_ptr(), Cn, ws.mid_drop.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
+             accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
+    gemm_f32(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(), 2 * H,
+             accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
+    for t_ in ws.d_lower[1:]:
+        t_.zero_()
+    if cfg.use_roi:
+        ws.dZ.zero_()
+    use_drop = train and cfg.gru_dropout > 0.0
+    for l in range(cfg.gru_layers - 1, -1, -1):
+        K = cfg.in_dim if l == 0 else 2 * H
+        top_layer = l == cfg.gru_layers - 1
+        g_in = ws.d_out if top_layer else ws.d_lower[l + 1]
+        L.call("ss_gru_bf16_bwd", g_in.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(), ws.whht[l].data_ptr(),
+               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), 0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed,
+               (l + 1) << 40, ws.gru_ws.data_ptr(), s)
+        if l == 0:
+            lin, ld_in = (ws.Z.data_ptr(), cfg.in_dim) if cfg.use_roi else (X.data_ptr(), cfg.x_dim)
+        else:
+            lin, ld_in = (ws.out_drop[l - 1] if use_drop else ws.out[l - 1]).data_ptr(), 2 * H
+        dg = ws.dG[l].data_ptr()
+        # ---- bias gradients: column sums of d_g (r | z | n | hn)
+        for d, suf in enumerate(("", "_reverse")):
+            base = dg + d * N * 4 * H * 4
+            L.call("ss_colsum_f32", base, N, 3 * H, 4 * H, G[f"gru.bias_ih_l{l}{suf}"].data_ptr(), s)
+            L.call("ss_colsum_f32", base, N, 2 * H, 4 * H, G[f"gru.bias_hh_l{l}{suf}"].data_ptr(), s)
+            L.call("ss_colsum_f32", base + 3 * H * 4, N, H, 4 * H, _addr(G[f"gru.bias_hh_l{l}{suf}"], 2 * H), s)
+        # ---- d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r (both directions in one launch, float atomics into a cleared buffer)
+        need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
+        wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
+        if need_dx:
+            if l > 0:
+                dst, ld_dst, c0 = ws.d_lower[l].data_ptr(), 2 * H, 0
+            elif cfg.use_roi:
+                c0 = cfg.x_dim if d_X is None else 0
+                if c0 % 4:
+                    c0 = 0  # 16-byte operand loads: take all columns
+                dst, ld_dst = ws.dZ.data_ptr() + 4 * c0, cfg.in_dim
+            else:
+                d_X.zero_()
+                dst, ld_dst, c0 = d_X.data_ptr(), cfg.x_dim, 0
+            gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(P[wi], c0), K, dst, ld_dst, accumulate=True, atomic=True, batch=2,
+                 strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0), tag="gemm_bf16_dX")
+        # ---- weight gradients: d W_ih = dGi^T . layer_in;  d W_hh = dGh^T . h_prev (rows r|z from columns [0,2H), rows n from [3H,4H))
+        gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
+             splits=split_k(3 * H, K, N, 2), batch=2, strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0), tag="gemm_bf16_dW")
+        if T > 1:
+            wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
+            Kh = B * (T - 1)
+            am, bm = (T - 1, T, 1), (T - 1, T, 0)
+            # forward direction pairs dG[b][t] with out[b][t-1]; the reverse direction dG[b][t] with out[b][t+1]: the same
+            # pairing seen from one row earlier in dG and one row later in out (two pointer shifts = the batch strides)
+            sa, sb, sc = N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr)
+            hp = ws.out[l].data_ptr()
+            gemm(0, 0, 2 * H, H, Kh, dg, 4 * H, hp, 2 * H, G[wh].data_ptr(), H, accumulate=True, atomic=True,
+                 splits=split_k(2 * H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
+            gemm(0, 0, H, H, Kh, dg + 3 * H * 4, 4 * H, hp, 2 * H, _addr(G[wh], 2 * H * H), H, accumulate=True, atomic=True,
+                 splits=split_k(H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
+    if cfg.use_roi:
+        if d_X is not None:
+            L.call("ss_copy_rows_f32", ws.dZ.data_ptr(), cfg.in_dim, d_X.data_ptr(), cfg.x_dim, N, cfg.x_dim, s)
+        w = [P[k + ".weight"].data_ptr() for k in _CONV]
+        gw = [G[k + ".weight"].data_ptr() for k in _CONV]
+        gb = [G[k + ".bias"].data_ptr() for k in _CONV]
+        dz = _addr(ws.dZ, cfg.x_dim)
+        wfc = P["roi_cnn.fc.weight"].data_ptr()
+        L.call("ss_c5_conv_last_wgrad", ws.a3.data_ptr(), dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), ws.feat.data_ptr(), N,
+               gw[3], gb[3], G["roi_cnn.fc.weight"].data_ptr(), G["roi_cnn.fc.bias"].data_ptr(), s)
+        L.call("ss_c5_conv_last_dgrad", dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), N, w[3], ws.da3.data_ptr(), s)
+        L.call("ss_c5_conv_wgrad", 3, ws.a2.data_ptr(), ws.da3.data_ptr(), ws.i3.data_ptr(), N, gw[2], gb[2], s, tag="ss_c5_conv3_wgrad")
+        L.call("ss_c5_conv_dgrad", 3, ws.da3.data_ptr(), ws.i3.data_ptr(), N, w[2], ws.da2.data_ptr(), s, tag="ss_c5_conv3_dgrad")
+        L.call("ss_c5_conv_wgrad", 2, ws.a1.data_ptr(), ws.da2.data_ptr(), ws.i2.data_ptr(), N, gw[1], gb[1], s, tag="ss_c5_conv2_wgrad")
+        L.call("ss_c5_conv_dgrad", 2, ws.da2.data_ptr(), ws.i2.data_ptr(), N, w[1], ws.da1.data_ptr(), s, tag="ss_c5_conv2_dgrad")
+        L.call("ss_c5_conv1_wgrad", R.data_ptr(), N, int(cfg.roi_standardize), ws.st.data_ptr(), ws.da1.data_ptr(), ws.i1.data_ptr(),
+               gw[0], gb[0], s)

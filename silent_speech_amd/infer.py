@@ -33,7 +33,7 @@ class GraphedInference:
         self.X = torch.zeros(B, T, cfg.x_dim, device=dev)
         self.lengths = torch.full((B,), T, device=dev, dtype=torch.int32)
         self.R = torch.zeros(B, T, *roi_hw, device=dev, dtype=torch.uint8) if model.use_roi else None
-        self.ws = E.Workspace(cfg, B, T, tuple(roi_hw) if roi_hw else None, dev, train=False)
+        self.ws = E.make_workspace(cfg, B, T, tuple(roi_hw) if roi_hw else None, dev, train=False)
         # topk > 0: softmax + the k most probable classes of every window are part of the captured graph
         # (live_infer_official.py:223-226 for every window), read from ``top_probs`` / ``top_idx`` after a call
         self.topk = min(int(topk), cfg.num_classes)

@@ -68,12 +68,15 @@ def _indexed(mods: Dict[int, nn.Module], n: int) -> nn.Module:
 
 
 class TinyROICNN(_Holder):
-    """train_model_official.py:209-229: net.{0,3,6} convs, fc."""
+    """train_model_official.py:209-229: net.{0,3,6} convs, fc.  ``channels`` widens / deepens it the way the reference's
+    Sequential would grow: [conv, ReLU, MaxPool] per block (conv at index 3 i), the last block without the pool, then the
+    global average and ``fc`` -- BASELINE config 5 uses (16, 32, 64, 96)."""
 
-    def __init__(self, out_dim: int = 32):
+    def __init__(self, out_dim: int = 32, channels=(8, 16, 24)):
         super().__init__()
-        self.net = _indexed({0: ConvParams(1, 8), 3: ConvParams(8, 16), 6: ConvParams(16, 24)}, 8)
-        self.fc = LinearParams(24, out_dim)
+        chans = (1,) + tuple(channels)
+        self.net = _indexed({3 * i: ConvParams(chans[i], chans[i + 1]) for i in range(len(channels))}, 3 * len(channels) - 1)
+        self.fc = LinearParams(chans[-1], out_dim)
 
 
 class AttnPool(_Holder):
@@ -141,10 +144,16 @@ class BiGRUClassifier(nn.Module):
     False = the live script's /255-only variant, live_infer_official.py:126)."""
 
     def __init__(self, x_dim, num_classes, use_roi=False, roi_emb=32, hidden=192, gru_layers=2,
-                 roi_standardize=True):
+                 roi_standardize=True, cnn_channels=(8, 16, 24), precision="f32"):
         super().__init__()
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' (exact-f32 MFMA, the reference's numerics) or 'bf16' (bf16 MFMA operands, "
+                             "f32 accumulation and master weights: BASELINE config 5)")
+        if precision == "f32" and use_roi and tuple(cnn_channels) != (8, 16, 24):
+            raise ValueError("the f32 ROI-CNN kernels are built for the reference's channels (8, 16, 24); wider CNNs run with "
+                             "precision='bf16'")
         self.use_roi = use_roi
-        self.roi_cnn = TinyROICNN(out_dim=roi_emb) if use_roi else None
+        self.roi_cnn = TinyROICNN(out_dim=roi_emb, channels=cnn_channels) if use_roi else None
         in_dim = x_dim + (roi_emb if use_roi else 0)
         self.gru = GRUParams(in_dim, hidden, gru_layers)
         self.pool = AttnPool(hidden * 2)
@@ -152,7 +161,7 @@ class BiGRUClassifier(nn.Module):
                               4: LinearParams(128, num_classes)}, 5)
         self.cfg = E.Config(x_dim=x_dim, num_classes=num_classes, use_roi=bool(use_roi), roi_emb=roi_emb,
                             hidden=hidden, gru_layers=gru_layers, roi_standardize=roi_standardize,
-                            gru_dropout=0.0 if gru_layers < 2 else 0.1)
+                            gru_dropout=0.0 if gru_layers < 2 else 0.1, cnn_channels=tuple(cnn_channels), precision=precision)
         self.flat_params: Optional[torch.Tensor] = None
         self.flat_grads: Optional[torch.Tensor] = None
         self._ws_cache = {}
@@ -226,7 +235,7 @@ class BiGRUClassifier(nn.Module):
         key = (B, T, hw, train, X.device, slot)
         ws = self._ws_cache.get(key)
         if ws is None:
-            ws = E.Workspace(self.cfg, B, T, hw, X.device, train)
+            ws = E.make_workspace(self.cfg, B, T, hw, X.device, train)
             self._ws_cache[key] = ws
         return ws
 

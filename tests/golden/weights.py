@@ -14,17 +14,16 @@ import torch
 
 
 def param_shapes(x_dim: int, num_classes: int, use_roi: bool, roi_emb: int = 32, hidden: int = 192,
-                 gru_layers: int = 2) -> "OrderedDict[str, tuple]":
-    """Key -> shape in the reference's state_dict order."""
+                 gru_layers: int = 2, cnn_channels=(8, 16, 24)) -> "OrderedDict[str, tuple]":
+    """Key -> shape in the reference's state_dict order.  ``cnn_channels`` other than the reference's
+    (8, 16, 24) gives the build-defined wider CNN of BASELINE config 5 (conv blocks at Sequential indices 0, 3, 6, 9, ...)."""
     s = OrderedDict()
     if use_roi:
-        s["roi_cnn.net.0.weight"] = (8, 1, 3, 3)
-        s["roi_cnn.net.0.bias"] = (8,)
-        s["roi_cnn.net.3.weight"] = (16, 8, 3, 3)
-        s["roi_cnn.net.3.bias"] = (16,)
-        s["roi_cnn.net.6.weight"] = (24, 16, 3, 3)
-        s["roi_cnn.net.6.bias"] = (24,)
-        s["roi_cnn.fc.weight"] = (roi_emb, 24)
+        chans = (1,) + tuple(cnn_channels)
+        for i in range(len(cnn_channels)):
+            s[f"roi_cnn.net.{3 * i}.weight"] = (chans[i + 1], chans[i], 3, 3)
+            s[f"roi_cnn.net.{3 * i}.bias"] = (chans[i + 1],)
+        s["roi_cnn.fc.weight"] = (roi_emb, chans[-1])
         s["roi_cnn.fc.bias"] = (roi_emb,)
     in_dim = x_dim + (roi_emb if use_roi else 0)
     for l in range(gru_layers):
@@ -46,13 +45,13 @@ def param_shapes(x_dim: int, num_classes: int, use_roi: bool, roi_emb: int = 32,
 
 
 def make_state_dict(seed: int, x_dim: int, num_classes: int, use_roi: bool, roi_emb: int = 32,
-                    hidden: int = 192, gru_layers: int = 2, gain: float = 1.5) -> "OrderedDict[str, torch.Tensor]":
+                    hidden: int = 192, gru_layers: int = 2, gain: float = 1.5, cnn_channels=(8, 16, 24)) -> "OrderedDict[str, torch.Tensor]":
     """U(-a, a) with a = gain/sqrt(fan_in) per tensor (biases use the matching weight's fan-in,
     LayerNorm gamma is 1 + U(-.2,.2)).  ``gain`` > 1 keeps gates away from the trivial regime so
     parity errors are visible in the logits."""
     g = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
-    shapes = param_shapes(x_dim, num_classes, use_roi, roi_emb, hidden, gru_layers)
+    shapes = param_shapes(x_dim, num_classes, use_roi, roi_emb, hidden, gru_layers, cnn_channels)
     for k, shp in shapes.items():
         if k.startswith("gru."):
             fan = hidden

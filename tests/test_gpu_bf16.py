@@ -39,8 +39,9 @@ def test_gemm_bf16_layouts(L, akc, bkc, M, N, K):
     A_st = (A if akc else A.t()).contiguous().cuda()     # [M][K] or [K][M]
     B_st = (B.t() if bkc else B).contiguous().cuda()     # [N][K] or [K][N]
     C = torch.full((M, N), 7.0, device="cuda")
+    bias_d = bias.cuda()
     L.call("ss_gemm_bf16_batched", akc, bkc, M, N, K, A_st.data_ptr(), A_st.shape[1], INT_MAX, 0, 0, B_st.data_ptr(),
-           B_st.shape[1], INT_MAX, 0, 0, C.data_ptr(), N, bias.cuda().data_ptr(), 0, 1, 1, 0, 0, 0, 0, L.stream())
+           B_st.shape[1], INT_MAX, 0, 0, C.data_ptr(), N, bias_d.data_ptr(), 0, 1, 1, 0, 0, 0, 0, L.stream())
     torch.cuda.synchronize()
     err = float((C.cpu() - ref).abs().max())
     assert err < 2e-4 * max(1.0, float(ref.abs().max())), err
@@ -136,7 +137,8 @@ def test_gru_bf16_fwd_bwd(L, B, T, H):
     assert float((sv - torch.stack([s.detach() for s in saves])).abs().max()) < 5e-3
 
     dG = torch.full((2, N, 4, H), 9.0, device="cuda")
-    L.call("ss_gru_bf16_bwd", dev(d_out.reshape(N, 2 * H)).data_ptr(), out.data_ptr(), save.data_ptr(), wtb.data_ptr(),
+    d_out_d = dev(d_out.reshape(N, 2 * H))
+    L.call("ss_gru_bf16_bwd", d_out_d.data_ptr(), out.data_ptr(), save.data_ptr(), wtb.data_ptr(),
            lens.data_ptr(), B, T, H, dG.data_ptr(), 0.0, 0, 0, ws.data_ptr(), L.stream())
     torch.cuda.synchronize()
     dGc = dG.cpu().view(2, B, T, 4, H)
@@ -241,8 +243,9 @@ def test_c5_conv1_fwd(L, N, standardize):
     a1 = torch.empty(N, 48, 48, 16, device="cuda", dtype=torch.int16)
     i1 = torch.empty(N, 48, 48, 16, device="cuda", dtype=torch.uint8)
     st = torch.empty(N, 2, device="cuda")
-    L.call("ss_c5_conv1_fwd", R.cuda().data_ptr(), N, standardize, w1.cuda().data_ptr(), b1.cuda().data_ptr(), a1.data_ptr(),
-           i1.data_ptr(), st.data_ptr(), L.stream())
+    R_d, w_d, b_d = R.cuda(), w1.cuda(), b1.cuda()  # named: a temporary's memory is recycled before the kernel has run
+    L.call("ss_c5_conv1_fwd", R_d.data_ptr(), N, standardize, w_d.data_ptr(), b_d.data_ptr(), a1.data_ptr(), i1.data_ptr(),
+           st.data_ptr(), L.stream())
     torch.cuda.synchronize()
     if standardize:
         assert torch.equal(st[:, 0].cpu(), mu) and torch.equal(st[:, 1].cpu(), sd)
@@ -270,8 +273,8 @@ def test_c5_conv_fwd(L, layer, N):
     val, idx, gap = pool_ref(c, b)
     out = torch.empty(N, hw // 2, hw // 2, cout, device="cuda", dtype=torch.int16)
     io = torch.empty(N, hw // 2, hw // 2, cout, device="cuda", dtype=torch.uint8)
-    L.call("ss_c5_conv_fwd", layer, nhwc_bf16(a_in).data_ptr(), N, w.cuda().data_ptr(), b.cuda().data_ptr(), out.data_ptr(),
-           io.data_ptr(), L.stream())
+    a_d, w_d, b_d = nhwc_bf16(a_in), w.cuda(), b.cuda()
+    L.call("ss_c5_conv_fwd", layer, a_d.data_ptr(), N, w_d.data_ptr(), b_d.data_ptr(), out.data_ptr(), io.data_ptr(), L.stream())
     torch.cuda.synchronize()
     assert_bf16_close(f"a{layer}", from_nhwc(out), val)
     sure = (gap > 1e-3) & ((val > 1e-3) | (val == 0))
@@ -293,8 +296,9 @@ def test_c5_conv_last_fwd(L, N):
     z = torch.full((N, ld), 5.0, device="cuda")
     mask = torch.empty(N, 144, 96, device="cuda", dtype=torch.uint8)
     fo = torch.empty(N, 96, device="cuda")
-    L.call("ss_c5_conv_last_fwd", nhwc_bf16(a3).data_ptr(), N, w.cuda().data_ptr(), b.cuda().data_ptr(), wfc.cuda().data_ptr(),
-           bfc.cuda().data_ptr(), E, z.data_ptr() + 84 * 4, ld, mask.data_ptr(), fo.data_ptr(), L.stream())
+    a_d, w_d, b_d, wfc_d, bfc_d = nhwc_bf16(a3), w.cuda(), b.cuda(), wfc.cuda(), bfc.cuda()
+    L.call("ss_c5_conv_last_fwd", a_d.data_ptr(), N, w_d.data_ptr(), b_d.data_ptr(), wfc_d.data_ptr(), bfc_d.data_ptr(), E,
+           z.data_ptr() + 84 * 4, ld, mask.data_ptr(), fo.data_ptr(), L.stream())
     torch.cuda.synchronize()
     assert float((fo.cpu() - feat).abs().max()) < 2e-5
     assert float((z[:, 84:].cpu() - z_ref).abs().max()) < 5e-5 and float((z[:, :84] - 5.0).abs().max()) == 0.0
@@ -303,8 +307,8 @@ def test_c5_conv_last_fwd(L, N):
     assert torch.equal(mask.cpu().bool()[sure], m_ref[sure])
     # inference form: no stash
     z2 = torch.zeros(N, E, device="cuda")
-    L.call("ss_c5_conv_last_fwd", nhwc_bf16(a3).data_ptr(), N, w.cuda().data_ptr(), b.cuda().data_ptr(), wfc.cuda().data_ptr(),
-           bfc.cuda().data_ptr(), E, z2.data_ptr(), E, None, None, L.stream())
+    L.call("ss_c5_conv_last_fwd", a_d.data_ptr(), N, w_d.data_ptr(), b_d.data_ptr(), wfc_d.data_ptr(), bfc_d.data_ptr(), E,
+           z2.data_ptr(), E, None, None, L.stream())
     torch.cuda.synchronize()
     assert float((z2.cpu() - z_ref).abs().max()) < 5e-5
 
@@ -328,7 +332,8 @@ def test_c5_conv_bwd(L, layer, N):
     gb = torch.ones(cout, device="cuda")
     L.call("ss_c5_conv_wgrad", layer, a_d.data_ptr(), da_d.data_ptr(), idx_d.data_ptr(), N, gw.data_ptr(), gb.data_ptr(), L.stream())
     din = torch.empty(N, hw, hw, cin, device="cuda", dtype=torch.int16)
-    L.call("ss_c5_conv_dgrad", layer, da_d.data_ptr(), idx_d.data_ptr(), N, w.cuda().data_ptr(), din.data_ptr(), L.stream())
+    w_d = w.cuda()
+    L.call("ss_c5_conv_dgrad", layer, da_d.data_ptr(), idx_d.data_ptr(), N, w_d.data_ptr(), din.data_ptr(), L.stream())
     torch.cuda.synchronize()
     assert float((gw.cpu() - 1.0 - gw_ref).abs().max()) < 2e-4 * float(gw_ref.abs().max())
     assert float((gb.cpu() - 1.0 - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
@@ -362,7 +367,8 @@ def test_c5_conv_last_bwd(L, N):
     L.call("ss_c5_conv_last_wgrad", a_d.data_ptr(), dz_d.data_ptr() + 84 * 4, ld, E, wfc_d.data_ptr(), m_d.data_ptr(), feat_d.data_ptr(),
            N, gw.data_ptr(), gb.data_ptr(), gwfc.data_ptr(), gbfc.data_ptr(), L.stream())
     din = torch.empty(N, 12, 12, 64, device="cuda", dtype=torch.int16)
-    L.call("ss_c5_conv_last_dgrad", dz_d.data_ptr() + 84 * 4, ld, E, wfc_d.data_ptr(), m_d.data_ptr(), N, w.cuda().data_ptr(),
+    w_d = w.cuda()
+    L.call("ss_c5_conv_last_dgrad", dz_d.data_ptr() + 84 * 4, ld, E, wfc_d.data_ptr(), m_d.data_ptr(), N, w_d.data_ptr(),
            din.data_ptr(), L.stream())
     torch.cuda.synchronize()
     assert float((gw.cpu() - gw_ref).abs().max()) < 3e-4 * float(gw_ref.abs().max())
@@ -386,8 +392,9 @@ def test_c5_conv1_wgrad(L, N):
     st = torch.stack([mu, sd], 1).contiguous().cuda()
     gw = torch.zeros(16, 1, 3, 3, device="cuda")
     gb = torch.zeros(16, device="cuda")
-    L.call("ss_c5_conv1_wgrad", R.cuda().data_ptr(), N, 1, st.data_ptr(), nhwc_bf16(da).data_ptr(),
-           idx.permute(0, 2, 3, 1).contiguous().cuda().data_ptr(), gw.data_ptr(), gb.data_ptr(), L.stream())
+    R_d, da_d, idx_d = R.cuda(), nhwc_bf16(da), idx.permute(0, 2, 3, 1).contiguous().cuda()
+    L.call("ss_c5_conv1_wgrad", R_d.data_ptr(), N, 1, st.data_ptr(), da_d.data_ptr(), idx_d.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+           L.stream())
     torch.cuda.synchronize()
     assert float((gw.cpu() - gw_ref).abs().max()) < 2e-4 * float(gw_ref.abs().max())
     assert float((gb.cpu() - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
