@@ -24,7 +24,39 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: Peak BF16 MFMA, dense (AMD's 5 PF figure is 2:1 sparse)
 HBM_PEAK_GBS = 8000.0
+C5 = dict(channels=(16, 32, 64, 96), roi=96, emb=64, hidden=512, classes=100)  # BASELINE config 5 (build-defined widths)
+
+
+def c5_gflop_per_step(B, T, D):
+    """Algorithmic GFLOP (2 per MAC) per training step of every kernel family of the config-5 path, keyed by launch tag."""
+    N = B * T
+    c1, c2, c3, c4 = C5["channels"]
+    E, H = C5["emb"], C5["hidden"]
+    conv = {1: 96 * 96 * c1 * 9, 2: 48 * 48 * c2 * 9 * c1, 3: 24 * 24 * c3 * 9 * c2, 4: 12 * 12 * c4 * 9 * c3}
+    ih = (D + E) + 2 * H  # input widths of the two layers
+    f = lambda macs: 2.0 * macs / 1e9
+    return {
+        "ss_c5_conv1_fwd": f(N * conv[1]), "ss_c5_conv2_fwd": f(N * conv[2]), "ss_c5_conv3_fwd": f(N * conv[3]),
+        "ss_c5_conv_last_fwd": f(N * (conv[4] + c4 * E)),
+        "ss_c5_conv_last_wgrad": f(N * (conv[4] + c4 * E)), "ss_c5_conv_last_dgrad": f(N * (conv[4] + c4 * E)),
+        "ss_c5_conv3_wgrad": f(N * conv[3]), "ss_c5_conv3_dgrad": f(N * conv[3]),
+        "ss_c5_conv2_wgrad": f(N * conv[2]), "ss_c5_conv2_dgrad": f(N * conv[2]), "ss_c5_conv1_wgrad": f(N * conv[1]),
+        "gemm_bf16_ih": f(2 * N * 3 * H * ih), "gemm_bf16_dX": f(2 * N * 3 * H * (E + 2 * H)),
+        "gemm_bf16_dW": f(2 * N * 3 * H * ih + 2 * 2 * N * 3 * H * H),
+        "ss_gru_bf16_fwd": f(2 * 2 * N * 3 * H * H), "ss_gru_bf16_bwd": f(2 * 2 * N * 3 * H * H),
+    }
+
+
+def c5_step_gflop_per_clip(T, D, mid=128):
+    c1, c2, c3, c4 = C5["channels"]
+    E, H, C = C5["emb"], C5["hidden"], C5["classes"]
+    conv1 = 96 * 96 * c1 * 9
+    cnn = conv1 + 48 * 48 * c2 * 9 * c1 + 24 * 24 * c3 * 9 * c2 + 12 * 12 * c4 * 9 * c3 + c4 * E
+    gru = 2 * (3 * H * (D + E) + 3 * H * H) + 2 * (3 * H * 2 * H + 3 * H * H)
+    fwd = T * (cnn + gru) + 2 * H * mid + mid * C
+    return 2.0 * (3 * fwd - T * conv1) / 1e9
 
 
 def algorithmic_gflop(tag, B, T, D, E, H, C, roi):
@@ -44,7 +76,7 @@ def algorithmic_gflop(tag, B, T, D, E, H, C, roi):
     }.get(tag)
 
 
-def step_gflop_per_clip(T, D, E, H, C, roi, mid=128):
+def step_gflop_per_clip(T, D, E, H, C, roi, mid=128, fwd_only=False):
     """Algorithmic FLOPs (2 per MAC) of one clip's forward + backward, SURVEY.md section 8(d): backward = 2 x forward minus the
     input gradient of conv1.  0.591 GFLOP at config 2."""
     Hh, Ww = roi
@@ -54,13 +86,34 @@ def step_gflop_per_clip(T, D, E, H, C, roi, mid=128):
     gru = 2 * (3 * H * (D + E) + 3 * H * H) + 2 * (3 * H * 2 * H + 3 * H * H)  # both directions, two layers, per frame
     head = 2 * H * mid + mid * C
     fwd = T * (cnn + gru) + head
+    if fwd_only:
+        return 2.0 * fwd / 1e9
     return 2.0 * (3 * fwd - T * conv1) / 1e9
 
 
+PMC_TRAFFIC = os.path.join("profiles", "round2_a_pmc_traffic.json")
+PMC_MFMA = os.path.join("profiles", "round2_a_pmc_mfma.json")
+
+
+def pmc_mfma_busy(kernel_tag):
+    """MFMA-pipe busy fraction of a kernel from the committed rocprofv3 PMC summary (SQ_VALU_MFMA_BUSY_CYCLES over
+    SQ_BUSY_CU_CYCLES-equivalent time; tools/pmc_summary.py mfma)."""
+    path = os.path.join(ROOT, PMC_MFMA)
+    stem = {"ss_roi_cnn_bwd": "roi_cnn_bwd_kernel", "ss_roi_cnn_fwd_stash": "roi_cnn_fwd_kernel"}.get(kernel_tag)
+    if not stem or not os.path.exists(path):
+        return None
+    for name, d in json.load(open(path))["kernels"].items():
+        if stem in name:
+            return d
+    return None
+
+
 def pmc_traffic(kernel_tag):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (profiles/round1_g_pmc_traffic.json,
-    made by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
-    path = os.path.join(ROOT, "profiles", "round1_g_pmc_traffic.json")
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (made by tools/pmc_summary.py from
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
+    path = os.path.join(ROOT, PMC_TRAFFIC)
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "round1_g_pmc_traffic.json")
     stem = {"ss_roi_cnn_bwd": "roi_cnn_bwd_kernel", "ss_roi_cnn_fwd_stash": "roi_cnn_fwd_kernel", "ss_gru_fwd": "gru_split_fwd_kernel",
             "ss_gru_bwd": "gru_split_bwd_kernel"}.get(kernel_tag)
     if not stem or not os.path.exists(path):
@@ -84,17 +137,9 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("SS_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(args, D, C):
-    """Oracle (``port``) timed on the host cores: bounded sample of the same workload (smaller batch)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    import weights as W
+def _cpu_time_steps(sd, X, L, R, y, seconds, max_steps):
     from oracle import model_ref as MR
 
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    Bc = args.cpu_batch
-    sd = W.make_state_dict(0, D, C, True)
-    X, L, R, y = W.make_inputs(0, Bc, args.frames, D, C, (args.roi, args.roi), lengths=[args.frames] * Bc)
     state = {}
     t0 = time.perf_counter()
     MR.train_step(sd, state, X, L, R, y, impl="aten")  # warm-up
@@ -105,11 +150,78 @@ def cpu_baseline(args, D, C):
         MR.train_step(sd, state, X, L, R, y, impl="aten")
         n += 1
         el = time.perf_counter() - t0
-        if el > args.cpu_seconds or n >= 20 or (n == 1 and max(warm, el) > args.cpu_seconds):
+        if el > seconds or n >= max_steps or (n == 1 and max(warm, el) > seconds):
             break
-    return {"value": round(Bc * n / el, 2), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps (fwd+CE+bwd+clip+Adam, dropout off) of the CPU oracle at batch {Bc}, T={args.frames}, "
-                      f"{args.roi}x{args.roi} ROI, torch {torch.__version__} ATen CPU kernels, {cores} threads"}
+    return n, el
+
+
+def cpu_baseline(args, D, C, config):
+    """Oracle (``port``: the reference's own ATen CPU kernels behind the restated module) timed on the host cores, bounded
+    samples.  The headline object is the bench's own workload at its own batch (a few steps); SURVEY.md 8(d)'s other two
+    rows -- BASELINE config 1 (landmark-only, B = 8) and config 2 at B = 32 -- ride along under ``also``."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as W
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    T = args.frames
+    what = f"dropout off) of the CPU oracle, torch {torch.__version__} ATen CPU kernels, {cores} threads"
+    if config == 5:
+        kw = dict(roi_emb=C5["emb"], hidden=C5["hidden"], cnn_channels=C5["channels"])
+        Bc = min(args.batch, 32)
+        sd = W.make_state_dict(0, D, C, True, **kw)
+        X, L, R, y = W.make_inputs(0, Bc, T, D, C, (96, 96), lengths=[T] * Bc)
+        n, el = _cpu_time_steps(sd, X, L, R, y, args.cpu_seconds, 5)
+        return {"value": round(Bc * n / el, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+                "sample": f"{n} f32 train steps (fwd+CE+bwd+clip+Adam, {what}; config-5 widths (96x96 ROI, CNN 16/32/64/96, H=512, "
+                          f"100 words) at batch {Bc}, T={T}"}
+    out = None
+    also = []
+    for name, Bc, use_roi, secs, cap in (("config 2 at the bench batch", args.batch, True, args.cpu_seconds, 4),
+                                          ("config 2 at batch 32", args.cpu_batch, True, args.cpu_seconds / 3, 12),
+                                          ("config 1: landmark-only GRU, batch 8", 8, False, args.cpu_seconds / 5, 40)):
+        sd = W.make_state_dict(0, D, C, use_roi)
+        X, L, R, y = W.make_inputs(0, Bc, T, D, C, (args.roi, args.roi) if use_roi else None, lengths=[T] * Bc)
+        n, el = _cpu_time_steps(sd, X, L, R, y, secs, cap)
+        rec = {"value": round(Bc * n / el, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+               "sample": f"{n} train steps (fwd+CE+bwd+clip+Adam, {what}; {name}, T={T}"
+                         + (f", {args.roi}x{args.roi} ROI" if use_roi else ""), "ms_per_step": round(1000 * el / n, 1)}
+        if out is None:
+            out = rec
+        else:
+            also.append(rec)
+    out["also"] = also
+    return out
+
+
+def config4_block(ss, dev, D, C, roi, steps, warmup):
+    """BASELINE config 4 inside the default run: 4 096 sliding 60-frame windows, forward-only, one hipGraph replay per step
+    (softmax + top-3 included).  Whole-forward roofline: 0.4056 GFLOP per window against the f32-MFMA peak."""
+    B, T = 4096, 60
+    g = torch.Generator(device=dev).manual_seed(4321)
+    X = torch.randn(B, T, D, device=dev, generator=g)
+    R = torch.randint(0, 256, (B, T, roi, roi), device=dev, dtype=torch.uint8, generator=g)
+    lengths = torch.full((B,), T, device=dev, dtype=torch.int64)
+    model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).eval()
+    gi = ss.GraphedInference(model, B, T, (roi, roi), topk=3)
+    gi(X, lengths, R)
+    for _ in range(warmup):
+        gi()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gi()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    gpw = step_gflop_per_clip(T, D, 32, 192, C, (roi, roi), fwd_only=True)
+    tf = B * steps / el * gpw / 1e3
+    del gi, model, X, R
+    torch.cuda.empty_cache()
+    return {"metric": "windows/sec (60-frame, forward-only, hipGraph, softmax + top-3 on device)", "value": round(B * steps / el, 1),
+            "unit": "windows/s", "steps": steps, "warmup": warmup, "ms_per_step": round(1000 * el / steps, 3), "dtype": "f32",
+            "config": {"workload": f"BASELINE config 4: {B} sliding windows x T={T}, landmark + {roi}x{roi} ROI CNN + BiGRU, forward-only, hipGraph replay"},
+            "roofline": {"bound": "mfma", "gflop_per_window": round(gpw, 4), "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None}}
 
 
 def main():
@@ -129,7 +241,13 @@ def main():
     ap.add_argument("--mode", choices=["train", "infer", "assemble", "stream", "crop"], default="train",
                     help="train = the headline metric; infer = BASELINE config 4 (T=60, B=4096 windows, forward-only, hipGraph)")
     ap.add_argument("--micro-batches", type=int, default=1, help="slices of the per-GPU batch kept in flight on separate streams")
+    ap.add_argument("--config", type=int, choices=[2, 5], default=2,
+                    help="2 = the headline (f32, 64x64 ROI, H=192, 5 words); 5 = BASELINE config 5 (bf16 MFMA, 96x96 ROI, CNN "
+                         "16/32/64/96, H=512, 100 words)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 (hipGraph serving) block of the default run")
     args = ap.parse_args()
+    if args.config == 5:
+        args.roi, args.classes = C5["roi"], C5["classes"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,6 +269,8 @@ def main():
         args.batch, args.frames = 4096, 60
     B, T, K, C, roi = args.batch, args.frames, args.landmarks, args.classes, args.roi
     D, E, H = 2 * K + 4, 32, 192
+    if args.config == 5:
+        E, H = C5["emb"], C5["hidden"]
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     # synthetic clips: landmarks -> K1 feature fuse on device; uint8 ROI; full lengths
     base = torch.rand(B, 1, K, 2, device=dev, generator=g) * torch.tensor([0.4, 0.4], device=dev) + torch.tensor([0.3, 0.4], device=dev)
@@ -295,7 +415,10 @@ def main():
                                        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(u8_ms, 4)},
                           "kernels_ms": {k: round(v, 4) for k, v in k_ms.items()}}))
         return
-    model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).train()
+    if args.config == 5:
+        model = ss.BiGRUClassifier(D, C, use_roi=True, roi_emb=E, hidden=H, cnn_channels=C5["channels"], precision="bf16").to(dev).train()
+    else:
+        model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).train()
     if world > 1:
         dist.broadcast(model.flat_params, src=0)
     trainer = ss.Trainer(model, world_size=world, micro_batches=args.micro_batches)
@@ -305,12 +428,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gb = B * world
     for _ in range(args.warmup):
-        trainer.step(X, lengths, R, y)
+        trainer.step(X, lengths, R, y, global_batch=gb)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = trainer.step(X, lengths, R, y)
+        loss, _ = trainer.step(X, lengths, R, y, global_batch=gb)
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -339,36 +463,62 @@ def main():
             kernels[tag] = {"launches_per_step": len(ms) / args.steps, "avg_ms": sum(ms) / len(ms),
                             "ms_per_step": sum(ms) / args.steps}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        gf = algorithmic_gflop(dom, B, T, D, E, H, C, (roi, roi))
-        if gf is not None:
-            achieved = gf / kernels[dom]["avg_ms"]  # GFLOP / ms = TFLOP/s
-            roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic(dom) if (B, T, roi) == (256, 30, 64) else None,
-                    "algorithmic_gflop_per_launch": round(gf, 3), "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
+        if args.config == 5:
+            gfs = c5_gflop_per_step(B, T, D)
+            gf = gfs.get(dom)
+            if gf is not None:
+                achieved = gf / kernels[dom]["ms_per_step"]  # GFLOP per step / ms per step = TFLOP/s
+                roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "algorithmic_gflop_per_step": round(gf, 2), "launches_per_step": kernels[dom]["launches_per_step"],
+                        "ms_per_step": round(kernels[dom]["ms_per_step"], 4)}
+            kernel_tf = {k: round(gfs[k] / v["ms_per_step"], 1) for k, v in kernels.items() if k in gfs}
+        else:
+            gf = algorithmic_gflop(dom, B, T, D, E, H, C, (roi, roi))
+            if gf is not None:
+                achieved = gf / kernels[dom]["avg_ms"]  # GFLOP / ms = TFLOP/s
+                roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": pmc_traffic(dom) if (B, T, roi) == (256, 30, 64) else None,
+                        "algorithmic_gflop_per_launch": round(gf, 3), "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
+                mb_ = pmc_mfma_busy(dom) if (B, T, roi) == (256, 30, 64) else None
+                if mb_:
+                    roof["mfma_busy"] = mb_
 
+    if args.config == 5:
+        workload = (f"BASELINE config 5: landmark (K={K}, D={D}) + 96x96 uint8 ROI CNN (16,32,64,96) + 2-layer BiGRU({H}), T={T}, "
+                    f"C={C} words, bf16 MFMA operands / f32 accumulation and master weights, train step = fwd + CE(ls .05) + bwd + "
+                    "grad all-reduce + clip(1.0) + Adam, dropout on")
+        peak, gpc = BF16_MFMA_PEAK_TFLOPS, c5_step_gflop_per_clip(T, D)
+    else:
+        workload = (f"BASELINE config 2: landmark (K={K}, D={D}) + {roi}x{roi} uint8 ROI CNN + 2-layer BiGRU(192), "
+                    f"T={T}, C={C}, train step = fwd + CE(ls .05) + bwd + grad all-reduce + clip(1.0) + Adam, dropout on")
+        peak, gpc = F32_MFMA_PEAK_TFLOPS, step_gflop_per_clip(T, D, E, H, C, (roi, roi))
     out = {
         "metric": "clips/sec (30-frame, fwd+bwd)", "value": round(B * world * args.steps / elapsed, 1), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 2: landmark (K={K}, D={D}) + {roi}x{roi} uint8 ROI CNN + 2-layer BiGRU(192), "
-                               f"T={T}, C={C}, train step = fwd + CE(ls .05) + bwd + grad all-reduce + clip(1.0) + Adam, dropout on",
-                   "batch_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.config == 5 else "f32",
+        "data": "synthetic",
+        "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}",
                    "micro_batches_in_flight": args.micro_batches},
         "final_loss": round(final_loss, 5),
     }
     if roof:
         out["roofline"] = roof
-    # whole-step figure of SURVEY.md 8(d): clips/s x algorithmic GFLOP per clip against the dense f32-MFMA peak of the GPUs used
-    gpc = step_gflop_per_clip(T, D, E, H, C, (roi, roi))
+    # whole-step figure of SURVEY.md 8(d): clips/s x algorithmic GFLOP per clip against the dense MFMA peak (of the dtype) of the GPUs used
     tf = out["value"] * gpc / 1e3
     out["step_roofline"] = {"bound": "mfma", "gflop_per_clip": round(gpc, 4), "achieved": round(tf, 2),
-                            "peak": round(F32_MFMA_PEAK_TFLOPS * world, 1), "unit": "TFLOP/s",
-                            "frac": round(tf / (F32_MFMA_PEAK_TFLOPS * world), 4)}
+                            "peak": round(peak * world, 1), "unit": "TFLOP/s", "frac": round(tf / (peak * world), 4)}
     if kernels:
         out["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+        if args.config == 5:
+            out["kernels_tflops"] = kernel_tf
+    if rank == 0 and world == 1 and args.config == 2 and not args.no_config4:
+        del trainer, model
+        torch.cuda.empty_cache()
+        out["config4"] = config4_block(ss, dev, D, C, roi, 20, 3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, D, C)
+        out["cpu_baseline"] = cpu_baseline(args, D, C, args.config)
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
