@@ -54,8 +54,40 @@ def pmc(fetch_dir, write_dir, dst):
     print("wrote", dst, len(res), "kernels")
 
 
+def mfma(src_dir, dst, note=""):
+    """MFMA-pipe occupancy per kernel from one pass of
+        rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 \
+                        SQ_INSTS_MFMA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace ...
+    mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024): busy cycles summed over the 1 024 SIMDs against the
+    GPU-active cycles of the dispatch (rocprofv3's own MfmaUtil expression; GRBM_GUI_ACTIVE arrives summed over the 8 XCDs,
+    MI355X_MICROARCH.md 'DVFS give-back').  mfma_flops = MOPS x 512."""
+    f = (glob.glob(src_dir + "/*/*_counter_collection.csv") + glob.glob(src_dir + "/*_counter_collection.csv"))[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for k, d in agg.items():
+        if k.startswith(("void at::", "__amd")):
+            continue
+        avg = {c: sum(v) / len(v) for c, v in d.items()}
+        out = {"launches": len(next(iter(d.values()))), **{c + "_avg_per_launch": v for c, v in avg.items()}}
+        gui = avg.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if gui > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
+            out["mfma_busy_frac"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0)
+        fl = 512.0 * (avg.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) + avg.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0))
+        if fl:
+            out["mfma_gflop_per_launch_counted"] = fl / 1e9
+        res[k] = out
+    json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 "
+                         "SQ_INSTS_MFMA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE (one pass, kernel-trace only) " + note, "kernels": res},
+              open(dst, "w"), indent=1, sort_keys=True)
+    print("wrote", dst, len(res), "kernels")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3], " ".join(sys.argv[4:]))
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
