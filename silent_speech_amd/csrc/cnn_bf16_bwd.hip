@@ -14,7 +14,7 @@
 //          expands the gradient through its pool (argmax byte 4 = dead window).
 // dy is rebuilt in LDS from the pooled-grid gradient + the argmax bytes (pooled layers) or from d feat + the sign mask
 // (last layer).  Large maps are processed in row bands so that dy (dense, bf16) fits beside the other operand.
-//   conv1 wgrad: 1 input channel -- 9 FMAs per routed gradient on the VALU (4 % of the backward MACs).
+//   conv1 wgrad: 1 input channel -- a GEMM on the pooled grid against the 4 x 4 input patch under every pool window.
 #include "cnn_bf16.h"
 
 namespace {
@@ -338,64 +338,122 @@ struct Conv1BwdParams {
   float *g_w1, *g_b1;    // (16, 1, 3, 3), (16)
 };
 
+// conv1's weight gradient on the POOLED grid: the pool routes the gradient of a pooled pixel q to ONE of the four conv1
+// outputs of its window (slot e = argmax byte), so
+//   d W1[c][ky][kx] = sum_e sum_q [i1[q][c] == e] da1[q][c] * xn[2 yq + (e >> 1) + ky - 1][2 xq + (e & 1) + kx - 1]
+// is four GEMMs with K = pooled pixels (a quarter of the conv1 grid):  D_e[c][v] = sum_q A_e[q][c] * V[q][v],
+//   A_e = da1 masked to slot e (four bf16 images [q][16 channels], written once per band while the gradient map arrives),
+//   V[q][v = 4 vy + vx] = xn[2 yq - 1 + vy][2 xq - 1 + vx], the 4 x 4 input patch under the window,
+// and d W1[c][ky][kx] = sum_e D_e[c][4 ((e >> 1) + ky) + (e & 1) + kx].  Both operands are k-major, so both come from
+// ds_read_b64_tr_b16; a row of V is four CONSECUTIVE pixels of one image row = one 8-byte piece, handed in per lane.
+// The piece starts at haloed column 2 xq: 8-byte aligned for even xq only, so a second copy of the image, shifted by two
+// pixels, serves the odd ones.  288 MFMAs per frame instead of 83 k FMAs per lane-frame on the VALU (measured: 1.79 ms per
+// step for 4 % of the backward MACs).
+constexpr int C1_BR = 16;                       // pooled rows per band
+constexpr int C1_XS = 104;                      // row stride of the two haloed 98 x 98 images (elements)
+constexpr int C1_IMG = 98 * C1_XS;              // elements per image
+constexpr int C1_AE = C1_BR * 48 * C1;          // elements per masked image of a band
+constexpr int CONV1_WGRAD_LDS = 2 * C1_IMG * 2 + 4 * C1_AE * 2 + 256 * 4 + 16 * 16 * 4;
+
 __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
-  __shared__ float xh[98 * 100];   // haloed normalised frame, f32 (the weights' gradient keeps the un-rounded input)
-  __shared__ float s_xn[256];
-  __shared__ float s_red[NT / 16][16];
-  constexpr int HP = HW0 / 2, XS = 100;
-  const int tid = threadIdx.x, c = tid & 15, sub = tid >> 4;  // channel, pixel subset (32 of them)
-  for (int q = tid; q < 98 * XS; q += NT) xh[q] = 0.f;
-  float gw[9], gb = 0.f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HP = HW0 / 2;
+  bf16_t* imgE = reinterpret_cast<bf16_t*>(smem);           // imgE[r][c] = xn haloed (r, c)
+  bf16_t* imgO = imgE + C1_IMG;                             // imgO[r][c] = xn haloed (r, c + 2)
+  bf16_t* ae = imgO + C1_IMG;                               // [4][C1_BR * 48][16]
+  float* s_xn = reinterpret_cast<float*>(ae + 4 * C1_AE);   // [256]
+  float* s_red = s_xn + 256;                                // [16 c][16]: 9 weights + 1 bias per channel
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int q4 = li >> 2, p4 = li & 3;
+  zero_lds(smem, 2 * C1_IMG * 2, tid);
+  f32x4 acc[4];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) gw[k] = 0.f;
+  for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gb[8];  // bias gradient: this thread always stages the same 8 channels (item parity = channel half)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gb[k] = 0.f;
   __syncthreads();
+
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     if (tid < 256) {
       const float rr = (float)tid / 255.0f;
-      // rounded to bf16 as the forward kernel's image is: the gradient of the function that was actually computed
-      s_xn[tid] = from_bf16(to_bf16(p.standardize ? (rr - p.st[2 * (long)n]) / p.st[2 * (long)n + 1] : rr));
+      s_xn[tid] = p.standardize ? (rr - p.st[2 * (long)n]) / p.st[2 * (long)n + 1] : rr;
     }
     __syncthreads();
     const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
     for (int q = tid; q < HW0 * HW0 / 16; q += NT) {
       const uint4 v = src[q];
-      const int lin = q * 16;
-      float* dst = xh + (lin / HW0 + 1) * XS + (lin % HW0) + 1;
+      const int lin = q * 16, r = lin / HW0 + 1, c0 = lin % HW0 + 1;
       const unsigned wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) dst[4 * e + b] = s_xn[(wds[e] >> (8 * b)) & 255u];
+        for (int b = 0; b < 4; ++b) {
+          const bf16_t xv = to_bf16(s_xn[(wds[e] >> (8 * b)) & 255u]);  // bf16 as in the forward kernel's image
+          const int c = c0 + 4 * e + b;
+          imgE[r * C1_XS + c] = xv;
+          if (c >= 2) imgO[r * C1_XS + c - 2] = xv;
+        }
     }
-    __syncthreads();
     const bf16_t* da = p.da1 + (long)n * HP * HP * C1;
     const uint8_t* ix = p.i1 + (long)n * HP * HP * C1;
-    for (int pp = sub; pp < HP * HP; pp += NT / 16) {
-      const unsigned e = ix[pp * C1 + c];
-      if (e < 4u) {
-        const float gval = from_bf16(da[pp * C1 + c]);
-        const int y = 2 * (pp / HP) + (int)(e >> 1), x = 2 * (pp % HP) + (int)(e & 1);
-        const float* xp = xh + y * XS + x;  // haloed (y-1+1, x-1+1)
-        gb += gval;
+    for (int r0 = 0; r0 < HP; r0 += C1_BR) {
+      // ---- the band's gradients, split by window slot
+      for (int q = tid; q < C1_BR * HP * 2; q += NT) {
+        const int half = q & 1, pp = q >> 1;
+        const long so = ((long)r0 * HP + pp) * C1 + 8 * half;
+        const uint4 dv = *reinterpret_cast<const uint4*>(da + so);
+        const uint2 iv = *reinterpret_cast<const uint2*>(ix + so);
+        const unsigned d[4] = {dv.x, dv.y, dv.z, dv.w};
+        unsigned o[4][4];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int k = 0; k < 4; ++k) {
+          const unsigned ib = (k < 2 ? iv.x : iv.y) >> (16 * (k & 1));
+          const unsigned ia = ib & 255u, ic = (ib >> 8) & 255u;
+          const unsigned lo = d[k] & 0xffffu, hi = d[k] & 0xffff0000u;
+          if (ia < 4u) gb[2 * k] += __uint_as_float(lo << 16);
+          if (ic < 4u) gb[2 * k + 1] += __uint_as_float(hi);
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) gw[3 * ky + kx] += gval * xp[ky * XS + kx];
+          for (unsigned e = 0; e < 4; ++e) o[e][k] = (ia == e ? lo : 0u) | (ic == e ? hi : 0u);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<uint4*>(ae + e * C1_AE + pp * C1 + 8 * half) = uint4{o[e][0], o[e][1], o[e][2], o[e][3]};
       }
+      __syncthreads();
+      for (int ch = wv; ch < C1_BR * HP / 32; ch += NW) {
+        const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;  // this lane's two pooled pixels of the k step
+        const int y0 = r0 + P0 / HP, x0 = P0 % HP, y1 = r0 + P1 / HP, x1 = P1 % HP;
+        // patch row vy = p4 of the window: haloed image row 2 yq + p4, haloed columns 2 xq .. 2 xq + 3
+        const bf16_t* v0 = ((x0 & 1) ? imgO - 2 : imgE) + (2 * y0 + p4) * C1_XS + 2 * x0;
+        const bf16_t* v1 = ((x1 & 1) ? imgO - 2 : imgE) + (2 * y1 + p4) * C1_XS + 2 * x1;
+        const s16x8 fb = tr_pair(v0, v1);
+        const bf16_t* a0 = ae + P0 * C1 + 4 * p4;
+        const bf16_t* a1 = ae + P1 * C1 + 4 * p4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = mfma_bf16(tr_pair(a0 + e * C1_AE, a1 + e * C1_AE), fb, acc[e]);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
-  // reduce the 32 pixel subsets of every channel
-  for (int k = 0; k < 10; ++k) {
-    s_red[sub][c] = k < 9 ? gw[k] : gb;
-    __syncthreads();
-    if (tid < 16) {
-      float s = 0.f;
-      for (int j = 0; j < NT / 16; ++j) s += s_red[j][tid];
-      if (k < 9) atomicAdd(p.g_w1 + tid * 9 + k, s);
-      else atomicAdd(p.g_b1 + tid, s);
-    }
-    __syncthreads();
+  // ---- D_e[c = 4 g + r][v = li]: fold the slots into the 3 x 3 taps, the waves through LDS, one atomic per element
+  for (int q = tid; q < 16 * 16; q += NT) s_red[q] = 0.f;
+  __syncthreads();
+  const int vy = li >> 2, vx = li & 3;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ky = vy - (e >> 1), kx = vx - (e & 1);
+    if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&s_red[(4 * g + r) * 16 + 3 * ky + kx], acc[e][r]);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) atomicAdd(&s_red[(8 * (tid & 1) + k) * 16 + 9], gb[k]);
+  __syncthreads();
+  if (tid < 16 * 16) {
+    const int c = tid >> 4, k = tid & 15;
+    if (k < 9) atomicAdd(p.g_w1 + c * 9 + k, s_red[tid]);
+    else if (k == 9) atomicAdd(p.g_b1 + c, s_red[tid]);
   }
 }
 
@@ -462,5 +520,5 @@ extern "C" int ss_c5_conv1_wgrad(const uint8_t* R, int N, int standardize, const
                                  float* g_w1, float* g_b1, ss_stream_t stream) {
   SS_REQUIRE(R && st && da1 && i1 && g_w1 && g_b1 && N > 0, SS_ERR_ARG);
   Conv1BwdParams p{R, N, standardize, st, da1, i1, g_w1, g_b1};
-  return launch_persistent(conv1_wgrad_kernel, p, 0, N, static_cast<hipStream_t>(stream));
+  return launch_persistent(conv1_wgrad_kernel, p, CONV1_WGRAD_LDS, N, static_cast<hipStream_t>(stream));
 }

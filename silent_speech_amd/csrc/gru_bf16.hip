@@ -48,39 +48,64 @@ struct StepFwdParams {
   bf16_t* hb_out;         // (2, B, H)
 };
 
+template <int H>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
   __shared__ __attribute__((aligned(16))) float red[4 * 4 * 3 * 64 * 4];  // [wave][clip tile][gate][lane][4]
-  const int H = p.H, B = p.B, T = p.T;
+  const int B = p.B, T = p.T;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
   const int dir = blockIdx.y;
-  const int nut = H / 16;
+  constexpr int nut = H / 16;
   const int ut = blockIdx.x % nut, cg = blockIdx.x / nut;
   const int t = dir ? (T - 1 - p.s) : p.s;
   const long N = (long)B * T;
+  constexpr int KS = H / 128;  // 32-deep k steps of this wave's quarter of the contraction
+
+  // ---- everything the gate phase needs is requested first: one memory round trip under the MFMA loop instead of a second
+  // one behind it (a step is latency, not bandwidth)
+  const int bq = CG * cg + 16 * wv + li;        // the clip this lane finishes (clip tile wv)
+  const int u = 16 * ut + 4 * g;                // its 4 hidden units
+  const bool live = bq < B;
+  const long row = (long)(live ? bq : 0) * T + t;
+  const bool valid = live && t < p.lengths[live ? bq : 0];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 gir = z4, giz = z4, gin = z4, br = z4, bz = z4, bn = z4, hp = z4;
+  if (valid) {
+    const float* gi = p.gi + ((long)dir * N + row) * 3 * H;
+    const float* bhh = dir ? p.bhh_r : p.bhh_f;
+    gir = *reinterpret_cast<const f32x4*>(gi + u); giz = *reinterpret_cast<const f32x4*>(gi + H + u);
+    gin = *reinterpret_cast<const f32x4*>(gi + 2 * H + u);
+    br = *reinterpret_cast<const f32x4*>(bhh + u); bz = *reinterpret_cast<const f32x4*>(bhh + H + u);
+    bn = *reinterpret_cast<const f32x4*>(bhh + 2 * H + u);
+    const int tp = dir ? t + 1 : t - 1;
+    if (p.s > 0 && tp >= 0 && tp < T) hp = *reinterpret_cast<const f32x4*>(p.out + ((long)bq * T + tp) * 2 * H + dir * H + u);
+  }
 
   f32x4 acc[4][3];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 3; ++q) acc[c][q] = z4;
   if (p.s > 0) {
     const bf16_t* W = p.whh + (long)dir * 3 * H * H;
     const bf16_t* hb = p.hb_in + (long)dir * B * H;
-    const int kq = H / 4;  // this wave's quarter of the contraction
-    for (int k0 = wv * kq; k0 < (wv + 1) * kq; k0 += 32) {
-      s16x8 fa[3], fb[4];
+    s16x8 fa[KS][3], fb[KS][4];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const s16x8*>(W + (long)(q * H + 16 * ut + li) * H + k0 + 8 * g);
+    for (int ks = 0; ks < KS; ++ks) {  // all operand loads of the wave in flight together
+      const int k0 = wv * (H / 4) + 32 * ks;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fa[ks][q] = *reinterpret_cast<const s16x8*>(W + (long)(q * H + 16 * ut + li) * H + k0 + 8 * g);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int b = CG * cg + 16 * c + li;
-        fb[c] = b < B ? *reinterpret_cast<const s16x8*>(hb + (long)b * H + k0 + 8 * g) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        fb[ks][c] = b < B ? *reinterpret_cast<const s16x8*>(hb + (long)b * H + k0 + 8 * g) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
       }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) acc[c][q] = mfma_bf16(fa[q], fb[c], acc[c][q]);
-    }
+        for (int q = 0; q < 3; ++q) acc[c][q] = mfma_bf16(fa[ks][q], fb[ks][c], acc[c][q]);
   }
   // K slices -> LDS; wave w then owns clip tile w
 #pragma unroll
@@ -91,27 +116,14 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
   f32x4 gh[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s = z4;
 #pragma unroll
     for (int w = 0; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(red + (((w * 4 + wv) * 3 + q) * 64 + lane) * 4);
     gh[q] = s;
   }
-  const int b = CG * cg + 16 * wv + li;
-  if (b >= B) return;
-  const int u = 16 * ut + 4 * g;  // this lane's 4 hidden units
-  const bool valid = t < p.lengths[b];
-  const long row = (long)b * T + t;
-  f32x4 hn = {0.f, 0.f, 0.f, 0.f};
+  if (!live) return;
+  f32x4 hn = z4;
   if (valid) {
-    const float* gi = p.gi + ((long)dir * N + row) * 3 * H;
-    const float* bhh = dir ? p.bhh_r : p.bhh_f;
-    const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + u), giz = *reinterpret_cast<const f32x4*>(gi + H + u),
-                gin = *reinterpret_cast<const f32x4*>(gi + 2 * H + u);
-    const f32x4 br = *reinterpret_cast<const f32x4*>(bhh + u), bz = *reinterpret_cast<const f32x4*>(bhh + H + u),
-                bn = *reinterpret_cast<const f32x4*>(bhh + 2 * H + u);
-    f32x4 hp = {0.f, 0.f, 0.f, 0.f};
-    const int tp = dir ? t + 1 : t - 1;
-    if (p.s > 0 && tp >= 0 && tp < T) hp = *reinterpret_cast<const f32x4*>(p.out + ((long)b * T + tp) * 2 * H + dir * H + u);
     f32x4 rr, zz, nn, hh;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
     }
   }
   *reinterpret_cast<f32x4*>(p.out + row * 2 * H + dir * H + u) = hn;
-  *reinterpret_cast<uint2*>(p.hb_out + ((long)dir * B + b) * H + u) = pack_bf16x4(hn[0], hn[1], hn[2], hn[3]);
+  *reinterpret_cast<uint2*>(p.hb_out + ((long)dir * B + bq) * H + u) = pack_bf16x4(hn[0], hn[1], hn[2], hn[3]);
 }
 
 struct StepBwdParams {
@@ -149,60 +161,78 @@ struct StepBwdParams {
   uint64_t seed, offset;
 };
 
+template <int H>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
   __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];  // [wave][clip tile][lane][4]
-  const int H = p.H, B = p.B, T = p.T;
+  const int B = p.B, T = p.T;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
   const int dir = blockIdx.y;
-  const int nut = H / 16;
+  constexpr int nut = H / 16;
   const int ut = blockIdx.x % nut, cg = blockIdx.x / nut;
   // BPTT walks the forward order backwards: forward direction t = T-1-s, reverse direction t = s
   const int t = dir ? p.s : (T - 1 - p.s);
   const long N = (long)B * T;
+  constexpr int KS = 3 * H / 128;  // 32-deep k steps of this wave's quarter of the contraction (K = 3H)
+  constexpr int KB = 4;            // k steps whose operands are in flight together
+
+  // ---- the element-wise phase's operands first (see the forward kernel)
+  const int bq = CG * cg + 16 * wv + li;
+  const int u = 16 * ut + 4 * g;
+  const bool live = bq < B;
+  const long row = (long)(live ? bq : 0) * T + t;
+  const bool valid = live && t < p.lengths[live ? bq : 0];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dh = z4, r = z4, z = z4, n = z4, hpre = z4, hp = z4, dhz_in = z4;
+  float* dhz = p.dhz + ((long)dir * B + (live ? bq : 0)) * H + u;
+  if (live && p.s > 0) dhz_in = *reinterpret_cast<const f32x4*>(dhz);
+  if (valid) {
+    dh = *reinterpret_cast<const f32x4*>(p.d_out + row * 2 * H + dir * H + u);
+    const float* sv = p.save + ((long)dir * N + row) * 4 * H;
+    r = *reinterpret_cast<const f32x4*>(sv + u); z = *reinterpret_cast<const f32x4*>(sv + H + u);
+    n = *reinterpret_cast<const f32x4*>(sv + 2 * H + u); hpre = *reinterpret_cast<const f32x4*>(sv + 3 * H + u);
+    const int tp = dir ? t + 1 : t - 1;  // the step before this one in forward order
+    if (tp >= 0 && tp < T) hp = *reinterpret_cast<const f32x4*>(p.out + ((long)bq * T + tp) * 2 * H + dir * H + u);
+  }
 
   f32x4 acc[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < 4; ++c) acc[c] = z4;
   if (p.s > 0) {
     const bf16_t* Wt = p.whht + (long)dir * 3 * H * H;
     const bf16_t* dg = p.dgh_in + (long)dir * B * 3 * H;
-    const int kq = 3 * H / 4;
-    for (int k0 = wv * kq; k0 < (wv + 1) * kq; k0 += 32) {
-      const s16x8 fa = *reinterpret_cast<const s16x8*>(Wt + (long)(16 * ut + li) * 3 * H + k0 + 8 * g);
-      s16x8 fb[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int b = CG * cg + 16 * c + li;
-        fb[c] = b < B ? *reinterpret_cast<const s16x8*>(dg + (long)b * 3 * H + k0 + 8 * g) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int kb = 0; kb < KS; kb += KB) {
+      s16x8 fa[KB], fb[KB][4];
+#pragma unroll
+      for (int ks = 0; ks < KB; ++ks) {
+        if (kb + ks >= KS) break;  // compile-time: KS need not be a multiple of KB
+        const int k0 = wv * (3 * H / 4) + 32 * (kb + ks);
+        fa[ks] = *reinterpret_cast<const s16x8*>(Wt + (long)(16 * ut + li) * 3 * H + k0 + 8 * g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int b = CG * cg + 16 * c + li;
+          fb[ks][c] = b < B ? *reinterpret_cast<const s16x8*>(dg + (long)b * 3 * H + k0 + 8 * g) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = mfma_bf16(fa, fb[c], acc[c]);
+      for (int ks = 0; ks < KB; ++ks) {
+        if (kb + ks >= KS) break;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = mfma_bf16(fa[ks], fb[ks][c], acc[c]);
+      }
     }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(red + ((wv * 4 + c) * 64 + lane) * 4) = acc[c];
   __syncthreads();
-  f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+  f32x4 carry = dhz_in;
 #pragma unroll
   for (int w = 0; w < 4; ++w) carry += *reinterpret_cast<const f32x4*>(red + ((w * 4 + wv) * 64 + lane) * 4);
-  const int b = CG * cg + 16 * wv + li;
-  if (b >= B) return;
-  const int u = 16 * ut + 4 * g;
-  float* dhz = p.dhz + ((long)dir * B + b) * H + u;
-  if (p.s > 0) carry += *reinterpret_cast<const f32x4*>(dhz);
-  const bool valid = t < p.lengths[b];
-  const long row = (long)b * T + t;
-  f32x4 drp = {0.f, 0.f, 0.f, 0.f}, dzp = drp, dnp = drp, dhn = drp, keep = carry;
+  if (!live) return;
+  f32x4 drp = z4, dzp = z4, dnp = z4, dhn = z4, keep = carry;
   if (valid) {
-    f32x4 dh = *reinterpret_cast<const f32x4*>(p.d_out + row * 2 * H + dir * H + u);
     if (p.drop_p > 0.f) dh *= drop_scale4((row * 2 * H + dir * H + u) >> 2, p.drop_p, p.seed, p.offset);
     dh += carry;
-    const float* sv = p.save + ((long)dir * N + row) * 4 * H;
-    const f32x4 r = *reinterpret_cast<const f32x4*>(sv + u), z = *reinterpret_cast<const f32x4*>(sv + H + u),
-                n = *reinterpret_cast<const f32x4*>(sv + 2 * H + u), hpre = *reinterpret_cast<const f32x4*>(sv + 3 * H + u);
-    f32x4 hp = {0.f, 0.f, 0.f, 0.f};
-    const int tp = dir ? t + 1 : t - 1;  // the step before this one in forward order
-    if (tp >= 0 && tp < T) hp = *reinterpret_cast<const f32x4*>(p.out + ((long)b * T + tp) * 2 * H + dir * H + u);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float dn = dh[e] * (1.0f - z[e]);
@@ -219,11 +249,36 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
   *reinterpret_cast<f32x4*>(dG + H + u) = dzp;
   *reinterpret_cast<f32x4*>(dG + 2 * H + u) = dnp;
   *reinterpret_cast<f32x4*>(dG + 3 * H + u) = dhn;
-  bf16_t* dgo = p.dgh_out + ((long)dir * B + b) * 3 * H;
+  bf16_t* dgo = p.dgh_out + ((long)dir * B + bq) * 3 * H;
   *reinterpret_cast<uint2*>(dgo + u) = pack_bf16x4(drp[0], drp[1], drp[2], drp[3]);
   *reinterpret_cast<uint2*>(dgo + H + u) = pack_bf16x4(dzp[0], dzp[1], dzp[2], dzp[3]);
   *reinterpret_cast<uint2*>(dgo + 2 * H + u) = pack_bf16x4(dhn[0], dhn[1], dhn[2], dhn[3]);
   *reinterpret_cast<f32x4*>(dhz) = keep;
+}
+
+// H-templated launchers: the kernels want compile-time trip counts (every operand load of a wave issued up front)
+template <int H>
+void launch_fwd_steps(StepFwdParams p, bf16_t* hb, int T, hipStream_t stream) {
+  const long slot = 2L * p.B * H;
+  dim3 grid((H / 16) * ceil_div(p.B, CG), 2);
+  for (int s = 0; s < T; ++s) {
+    p.s = s;
+    p.hb_in = hb + ((s + 1) & 1) * slot;
+    p.hb_out = hb + (s & 1) * slot;
+    hipLaunchKernelGGL(gru_step_fwd_kernel<H>, grid, dim3(256), 0, stream, p);
+  }
+}
+
+template <int H>
+void launch_bwd_steps(StepBwdParams p, bf16_t* base, int T, hipStream_t stream) {
+  const long slot = 2L * p.B * 3 * H;
+  dim3 grid((H / 16) * ceil_div(p.B, CG), 2);
+  for (int s = 0; s < T; ++s) {
+    p.s = s;
+    p.dgh_in = base + ((s + 1) & 1) * slot;
+    p.dgh_out = base + (s & 1) * slot;
+    hipLaunchKernelGGL(gru_step_bwd_kernel<H>, grid, dim3(256), 0, stream, p);
+  }
 }
 
 }  // namespace
@@ -248,18 +303,19 @@ extern "C" int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const 
                                const int32_t* lengths, int B, int T, int H, float* out, float* save, void* ws,
                                ss_stream_t stream) {
   SS_REQUIRE(gi && whh_bf16 && b_hh_f && b_hh_r && lengths && out && ws, SS_ERR_ARG);
-  SS_REQUIRE(B > 0 && T > 0 && H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);  // four waves x whole 32-deep k steps
+  SS_REQUIRE(B > 0 && T > 0 && H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);  // four waves x whole 32-deep k steps; built: 128..512, 1024
   StepFwdParams p;
   p.gi = gi; p.whh = whh_bf16; p.bhh_f = b_hh_f; p.bhh_r = b_hh_r; p.lengths = lengths;
   p.B = B; p.T = T; p.H = H; p.out = out; p.save = save;
   bf16_t* hb = static_cast<bf16_t*>(ws);
-  const long slot = 2L * B * H;
-  dim3 grid((H / 16) * ceil_div(B, CG), 2);
-  for (int s = 0; s < T; ++s) {
-    p.s = s;
-    p.hb_in = hb + ((s + 1) & 1) * slot;
-    p.hb_out = hb + (s & 1) * slot;
-    hipLaunchKernelGGL(gru_step_fwd_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (H) {
+    case 128: launch_fwd_steps<128>(p, hb, T, st); break;
+    case 256: launch_fwd_steps<256>(p, hb, T, st); break;
+    case 384: launch_fwd_steps<384>(p, hb, T, st); break;
+    case 512: launch_fwd_steps<512>(p, hb, T, st); break;
+    case 1024: launch_fwd_steps<1024>(p, hb, T, st); break;
+    default: return SS_ERR_UNSUPPORTED;
   }
   return ss_launch_status();
 }
@@ -276,12 +332,14 @@ extern "C" int ss_gru_bf16_bwd(const float* d_out, const float* out, const float
   bf16_t* base = static_cast<bf16_t*>(ws) + 2L * 2 * B * H;  // behind the two forward state slots
   const long slot = 2L * B * 3 * H;
   p.dhz = reinterpret_cast<float*>(base + 2 * slot);
-  dim3 grid((H / 16) * ceil_div(B, CG), 2);
-  for (int s = 0; s < T; ++s) {
-    p.s = s;
-    p.dgh_in = base + ((s + 1) & 1) * slot;
-    p.dgh_out = base + (s & 1) * slot;
-    hipLaunchKernelGGL(gru_step_bwd_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (H) {
+    case 128: launch_bwd_steps<128>(p, base, T, st); break;
+    case 256: launch_bwd_steps<256>(p, base, T, st); break;
+    case 384: launch_bwd_steps<384>(p, base, T, st); break;
+    case 512: launch_bwd_steps<512>(p, base, T, st); break;
+    case 1024: launch_bwd_steps<1024>(p, base, T, st); break;
+    default: return SS_ERR_UNSUPPORTED;
   }
   return ss_launch_status();
 }

@@ -207,12 +207,9 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         else:
             lin, ld_in = (ws.out_drop[l - 1] if use_drop else ws.out[l - 1]).data_ptr(), 2 * H
         dg = ws.dG[l].data_ptr()
-        # ---- bias gradients: column sums of d_g (r | z | n | hn)
-        for d, suf in enumerate(("", "_reverse")):
-            base = dg + d * N * 4 * H * 4
-            L.call("ss_colsum_f32", base, N, 3 * H, 4 * H, G[f"gru.bias_ih_l{l}{suf}"].data_ptr(), s)
-            L.call("ss_colsum_f32", base, N, 2 * H, 4 * H, G[f"gru.bias_hh_l{l}{suf}"].data_ptr(), s)
-            L.call("ss_colsum_f32", base + 3 * H * 4, N, H, 4 * H, _addr(G[f"gru.bias_hh_l{l}{suf}"], 2 * H), s)
+        # ---- bias gradients: column sums of d_g (r | z | n | hn), both directions in one launch
+        L.call("ss_gru_bias_grad", dg, N, H, G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
+               G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), s)
         # ---- d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r (both directions in one launch, float atomics into a cleared buffer)
         need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
         wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
