@@ -50,4 +50,120 @@ struct Wmat {
   static constexpr int ELEMS = CN * LD, BYTES = ELEMS * 2;
 };
 
+// ---- HBM -> registers -> LDS in two steps: ``issue`` starts the global loads of the NEXT frame / band before the MFMA
+// phase of the current one, ``commit`` writes them into the (single-buffered) LDS images behind it.  The per-layer kernels
+// are HBM-bound (a layer's whole input and output cross HBM once per frame); with load and compute back to back a
+// workgroup idles through every load phase (first version: conv2 forward 0.42 ms for 0.2 ms of HBM time).
+
+// rows [y0, y0 + ROWS) of an NHWC frame (HF rows) -> rows lrow0, lrow0 + 1, ... of a haloed image; rows outside the frame: zeros
+template <class IM, int HF, int ROWS>
+struct BandLoad {
+  static constexpr int CH = IM::C / 8, ITEMS = ROWS * IM::W * CH, NV = (ITEMS + NT - 1) / NT;
+  uint4 v[NV];
+  __device__ __forceinline__ void issue(const bf16_t* __restrict__ src, int y0, int tid) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int q = tid + k * NT;
+      const int c8 = q % CH, x = (q / CH) % IM::W, y = y0 + q / (CH * IM::W);
+      uint4 t = {0u, 0u, 0u, 0u};
+      if (q < ITEMS && y >= 0 && y < HF) t = *reinterpret_cast<const uint4*>(src + ((long)y * IM::W + x) * IM::C + 8 * c8);
+      v[k] = t;
+    }
+  }
+  __device__ __forceinline__ void commit(bf16_t* img, int lrow0, int tid) const {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int q = tid + k * NT;
+      if (q < ITEMS) {
+        const int c8 = q % CH, x = (q / CH) % IM::W, yl = q / (CH * IM::W);
+        *reinterpret_cast<uint4*>(img + IM::at(yl + lrow0, x) + 8 * c8) = v[k];
+      }
+    }
+  }
+};
+
+// dense gradient rows [y0, y0 + ROWS) of a pooled layer (H x W before the pool) from the pooled-grid gradient + argmax bytes:
+//   dst(yl, x) = img + off0 + yl * RS + x * PS;  rows outside the frame: zeros
+template <int COUT, int H, int W, int ROWS>
+struct ExpandLoad {
+  static constexpr int WO = W / 2, CH = COUT / 8, ITEMS = ROWS * WO * CH, NV = (ITEMS + NT - 1) / NT;
+  uint4 d[NV];
+  uint2 ix[NV];
+  __device__ __forceinline__ void issue(const bf16_t* __restrict__ da, const uint8_t* __restrict__ idx, int y0, int tid) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int q = tid + k * NT;
+      const int c8 = q % CH, xp = (q / CH) % WO, y = y0 + q / (CH * WO);
+      uint4 t = {0u, 0u, 0u, 0u};
+      uint2 u = {0x04040404u, 0x04040404u};
+      if (q < ITEMS && y >= 0 && y < H) {
+        const long src = ((long)(y >> 1) * WO + xp) * COUT + 8 * c8;
+        t = *reinterpret_cast<const uint4*>(da + src);
+        u = *reinterpret_cast<const uint2*>(idx + src);
+      }
+      d[k] = t;
+      ix[k] = u;
+    }
+  }
+  __device__ __forceinline__ void commit(bf16_t* img, int off0, int RS, int PS, int y0, int tid) const {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int q = tid + k * NT;
+      if (q < ITEMS) {
+        const int c8 = q % CH, xp = (q / CH) % WO, yl = q / (CH * WO);
+        const unsigned dd[4] = {d[k].x, d[k].y, d[k].z, d[k].w};
+        const unsigned e0 = (unsigned)((y0 + yl) & 1) * 2u;
+        unsigned o0[4], o1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // channels 2j, 2j+1
+          const unsigned ib = (j < 2 ? ix[k].x : ix[k].y) >> (16 * (j & 1));
+          const unsigned ia = ib & 255u, ic = (ib >> 8) & 255u;
+          const unsigned lo = dd[j] & 0xffffu, hi = dd[j] & 0xffff0000u;
+          o0[j] = (ia == e0 ? lo : 0u) | (ic == e0 ? hi : 0u);
+          o1[j] = (ia == e0 + 1u ? lo : 0u) | (ic == e0 + 1u ? hi : 0u);
+        }
+        bf16_t* dst = img + off0 + yl * RS + (2 * xp) * PS + 8 * c8;
+        *reinterpret_cast<uint4*>(dst) = uint4{o0[0], o0[1], o0[2], o0[3]};
+        *reinterpret_cast<uint4*>(dst + PS) = uint4{o1[0], o1[1], o1[2], o1[3]};
+      }
+    }
+  }
+};
+
+// last layer: sign mask of all NPIX pixels (8 bytes per item) + this thread's piece of the d z row and of the averaged features
+template <int COUT, int NPIX>
+struct MaskLoad {
+  static constexpr int CH = COUT / 8, ITEMS = NPIX * CH, NV = (ITEMS + NT - 1) / NT;
+  uint2 m[NV];
+  float dz, ft;
+  __device__ __forceinline__ void issue(const uint8_t* __restrict__ mask, const float* __restrict__ dzrow, int E,
+                                        const float* __restrict__ featrow, int tid) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int q = tid + k * NT;
+      m[k] = q < ITEMS ? *reinterpret_cast<const uint2*>(mask + (long)(q / CH) * COUT + 8 * (q % CH)) : uint2{0u, 0u};
+    }
+    dz = tid < E ? dzrow[tid] : 0.f;
+    ft = (featrow && tid < COUT) ? featrow[tid] : 0.f;
+  }
+  // dy[P][co] = mask ? dfeat[co] : 0
+  __device__ __forceinline__ void commit(const float* s_dfeat, bf16_t* img, int off0, int RS, int PS, int W, int tid) const {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int q = tid + k * NT;
+      if (q < ITEMS) {
+        const int c8 = q % CH, P = q / CH;
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned mb = (j < 2 ? m[k].x : m[k].y) >> (16 * (j & 1));
+          const float a = (mb & 255u) ? s_dfeat[8 * c8 + 2 * j] : 0.f, b = ((mb >> 8) & 255u) ? s_dfeat[8 * c8 + 2 * j + 1] : 0.f;
+          o[j] = pack_bf16(a, b);
+        }
+        *reinterpret_cast<uint4*>(img + off0 + (P / W) * RS + (P % W) * PS + 8 * c8) = uint4{o[0], o[1], o[2], o[3]};
+      }
+    }
+  }
+};
+
 }  // namespace c5

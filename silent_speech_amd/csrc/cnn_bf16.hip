@@ -233,11 +233,14 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
   constexpr int UNITS = (MTILES / MT) * (NTILES / NTL);
   const int chunk = (CIN >= 32) ? g : (g & 1), hi = (CIN >= 32) ? 0 : (g >> 1);
 
+  BandLoad<IM, H, H> pre;  // the next frame, on its way while this one is computed
+  if ((int)blockIdx.x < p.N) pre.issue(p.in + (long)blockIdx.x * H * W * CIN, 0, tid);
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
-    load_image<IM>(p.in + (long)n * H * W * CIN, img, tid);
+    pre.commit(img, 0, tid);
     if (LAST)
       for (int q = tid; q < COUT; q += NT) s_feat[q] = 0.f;
     __syncthreads();
+    if (n + (int)gridDim.x < p.N) pre.issue(p.in + (long)(n + gridDim.x) * H * W * CIN, 0, tid);
     for (int u = wv; u < UNITS; u += NW) {
       const int mg = u % (MTILES / MT), ng = u / (MTILES / MT);
       int base[MT];
@@ -369,7 +372,7 @@ extern "C" int ss_c5_conv_fwd(int layer, const uint16_t* in, int N, const float*
   ConvFwdParams p{};
   p.in = in; p.N = N; p.w = w; p.b = b; p.out = out; p.idx = idx;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (layer == 2) return launch_persistent(conv_fwd_kernel<C1, C2, 48, 48, false, 6, 2>, p, conv_fwd_lds<C1, C2, 48, 48, false>(), N, s);
+  if (layer == 2) return launch_persistent(conv_fwd_kernel<C1, C2, 48, 48, false, 3, 2>, p, conv_fwd_lds<C1, C2, 48, 48, false>(), N, s);
   if (layer == 3) return launch_persistent(conv_fwd_kernel<C2, C3, 24, 24, false, 9, 2>, p, conv_fwd_lds<C2, C3, 24, 24, false>(), N, s);
   return SS_ERR_UNSUPPORTED;
 }

@@ -171,24 +171,45 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
   for (int k = 0; k < FCN; ++k) fcw[k] = 0.f;
   __syncthreads();
 
+  // units = (frame, band), band-minor; the operands of unit u + 1 are in flight (registers) while unit u is multiplied
+  ExpandLoad<COUT, H, W, BH> pe;
+  MaskLoad<COUT, H * W> pm;
+  BandLoad<IA, H, BH + 2> pa;
+  auto issue = [&](int n, int y0) {
+    if (LAST) pm.issue(p.mask + (long)n * H * W * COUT, p.dz + (long)n * p.ld_dz, p.E, p.feat + (long)n * COUT, tid);
+    else pe.issue(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, y0, tid);
+    pa.issue(p.a_in + (long)n * H * W * CIN, y0 - 1, tid);
+  };
+  if ((int)blockIdx.x < p.N) issue(blockIdx.x, 0);
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
-    if (LAST) {
-      last_dfeat<COUT>(p, n, s_dz, s_dfeat, 1.0f / (float)(H * W), tid);
-      for (int c = tid; c < COUT; c += NT) s_feat[c] = p.feat[(long)n * COUT + c];
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < FCN; ++k) {
-        const int q = tid + k * NT;
-        if (q < p.E * COUT) fcw[k] += s_dz[q / COUT] * s_feat[q % COUT];
-      }
-      if (tid < p.E) fcb += s_dz[tid];
-    }
     for (int y0 = 0; y0 < H; y0 += BH) {
-      if (LAST) expand_dy_last<COUT, H * W>(p.mask + (long)n * H * W * COUT, s_dfeat, dyi, 0, RSD, PSD, W, tid);
-      else expand_dy<COUT, H, W>(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, dyi, 0, RSD,
-                                 PSD, y0, BH, tid);
-      load_band<IA, H>(p.a_in + (long)n * H * W * CIN, ai, y0 - 1, BH + 2, tid);
+      if (LAST) {
+        if (tid < p.E) s_dz[tid] = pm.dz;
+        if (tid < COUT) s_feat[tid] = pm.ft;
+        __syncthreads();
+        for (int c = tid; c < COUT; c += NT) {  // d feat[co] = sum_e dz[e] wfc[e][co] / (H*W)
+          float s = 0.f;
+          for (int e = 0; e < p.E; ++e) s += s_dz[e] * p.wfc[e * COUT + c];
+          s_dfeat[c] = s * (1.0f / (float)(H * W));
+        }
+#pragma unroll
+        for (int k = 0; k < FCN; ++k) {
+          const int q = tid + k * NT;
+          if (q < p.E * COUT) fcw[k] += s_dz[q / COUT] * s_feat[q % COUT];
+        }
+        if (tid < p.E) fcb += s_dz[tid];
+        __syncthreads();
+        pm.commit(s_dfeat, dyi, 0, RSD, PSD, W, tid);
+      } else {
+        pe.commit(dyi, 0, RSD, PSD, y0, tid);
+      }
+      pa.commit(ai, -1, tid);
       __syncthreads();
+      {  // the next unit's loads fly under the MFMAs below
+        const bool last_band = y0 + BH >= H;
+        const int nn = last_band ? n + (int)gridDim.x : n;
+        if (nn < p.N) issue(nn, last_band ? 0 : y0 + BH);
+      }
       for (int ch = wk; ch < NCH; ch += WK) {
         // this lane's two pixels of the k step: rows q4 and q4 + 4 of its 8-pixel group
         const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;
@@ -220,7 +241,14 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
       __syncthreads();
     }
   }
-  // ---- hand the register-resident gradients over: D row 4 g + r = co, column li = ci
+  // ---- hand the register-resident gradients over: D row 4 g + r = co, column li = ci.  The WK waves that share a tile set
+  // (K split) are first summed through LDS: 256 workgroups x 8 waves of float atomics onto the 4.6 k addresses of a small
+  // layer's gradient serialise at the memory side
+  float* redw = reinterpret_cast<float*>(smem);  // [COUT][CIN][9] + [COUT]: the operand images are dead
+  if (WK > 1) {
+    for (int q = tid; q < COUT * CIN * 9 + COUT; q += NT) redw[q] = 0.f;
+    __syncthreads();
+  }
 #pragma unroll
   for (int a = 0; a < NCO; ++a) {
     const int co0 = 16 * (wco * NCO + a) + 4 * g;
@@ -230,11 +258,23 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(p.g_w + ((long)(co0 + r) * CIN + ci) * 9 + t, acc[a][b][t][r]);
+        for (int r = 0; r < 4; ++r) {
+          const long o = ((long)(co0 + r) * CIN + ci) * 9 + t;
+          if (WK > 1) atomicAdd(redw + o, acc[a][b][t][r]);
+          else atomicAdd(p.g_w + o, acc[a][b][t][r]);
+        }
     }
     if (wci == 0 && li == 0)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(p.g_b + co0 + r, accb[a][r]);
+      for (int r = 0; r < 4; ++r) {
+        if (WK > 1) atomicAdd(redw + COUT * CIN * 9 + co0 + r, accb[a][r]);
+        else atomicAdd(p.g_b + co0 + r, accb[a][r]);
+      }
+  }
+  if (WK > 1) {
+    __syncthreads();
+    for (int q = tid; q < COUT * CIN * 9; q += NT) atomicAdd(p.g_w + q, redw[q]);
+    for (int q = tid; q < COUT; q += NT) atomicAdd(p.g_b + q, redw[COUT * CIN * 9 + q]);
   }
   if (LAST) {
 #pragma unroll
@@ -278,16 +318,34 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
   static_assert(MTILES % MT == 0, "unit split");
   constexpr int UNITS = (MTILES / MT) * NTILES;
 
+  ExpandLoad<COUT, H, W, BH + 2> pe;
+  MaskLoad<COUT, H * W> pm;
+  auto issue = [&](int n, int y0) {
+    if (LAST) pm.issue(p.mask + (long)n * H * W * COUT, p.dz + (long)n * p.ld_dz, p.E, nullptr, tid);
+    else pe.issue(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, y0 - 1, tid);
+  };
+  if ((int)blockIdx.x < p.N) issue(blockIdx.x, 0);
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
-    if (LAST) {
-      last_dfeat<COUT>(p, n, s_dz, s_dfeat, 1.0f / (float)(H * W), tid);
-      __syncthreads();
-    }
     for (int y0 = 0; y0 < H; y0 += BH) {
-      if (LAST) expand_dy_last<COUT, H * W>(p.mask + (long)n * H * W * COUT, s_dfeat, dyi, ID::at(0, 0), ID::RS, ID::PS, W, tid);
-      else expand_dy<COUT, H, W>(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, dyi,
-                                 ID::at(-1, 0), ID::RS, ID::PS, y0 - 1, BH + 2, tid);
+      if (LAST) {
+        if (tid < p.E) s_dz[tid] = pm.dz;
+        __syncthreads();
+        for (int c = tid; c < COUT; c += NT) {
+          float s = 0.f;
+          for (int e = 0; e < p.E; ++e) s += s_dz[e] * p.wfc[e * COUT + c];
+          s_dfeat[c] = s * (1.0f / (float)(H * W));
+        }
+        __syncthreads();
+        pm.commit(s_dfeat, dyi, ID::at(0, 0), ID::RS, ID::PS, W, tid);
+      } else {
+        pe.commit(dyi, ID::at(-1, 0), ID::RS, ID::PS, y0 - 1, tid);
+      }
       __syncthreads();
+      {
+        const bool last_band = y0 + BH >= H;
+        const int nn = last_band ? n + (int)gridDim.x : n;
+        if (nn < p.N) issue(nn, last_band ? 0 : y0 + BH);
+      }
       for (int u = wv; u < UNITS; u += NW) {
         const int mg = u % (MTILES / MT), nt = u / (MTILES / MT);
         int base[MT];
@@ -317,7 +375,7 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
       if (STAGE) {
         uint4* dst = reinterpret_cast<uint4*>(p.da_in + ((long)n * H + y0) * W * CIN);
         for (int q = tid; q < BH * W * CIN * 2 / 16; q += NT) dst[q] = reinterpret_cast<const uint4*>(oa)[q];
-        __syncthreads();  // the next band's expansion overwrites dy, its epilogue the staging area
+        // no barrier: the next band's commit rewrites dy only; its epilogue writes the staging area behind the barrier after that
       }
     }
   }

@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
   const int u = 16 * ut + 4 * g;                // its 4 hidden units
   const bool live = bq < B;
   const long row = (long)(live ? bq : 0) * T + t;
-  const bool valid = live && t < p.lengths[live ? bq : 0];
+  const int len = p.lengths[live ? bq : 0];
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 gir = z4, giz = z4, gin = z4, br = z4, bz = z4, bn = z4, hp = z4;
-  if (valid) {
+  if (live) {  // not ``valid``: the loads must not wait for the clip length to arrive (a row past the clip's end is just unused)
     const float* gi = p.gi + ((long)dir * N + row) * 3 * H;
     const float* bhh = dir ? p.bhh_r : p.bhh_f;
     gir = *reinterpret_cast<const f32x4*>(gi + u); giz = *reinterpret_cast<const f32x4*>(gi + H + u);
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) acc[c][q] = mfma_bf16(fa[ks][q], fb[ks][c], acc[c][q]);
   }
+  const bool valid = live && t < len;
   // K slices -> LDS; wave w then owns clip tile w
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -180,12 +181,12 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
   const int u = 16 * ut + 4 * g;
   const bool live = bq < B;
   const long row = (long)(live ? bq : 0) * T + t;
-  const bool valid = live && t < p.lengths[live ? bq : 0];
+  const int len = p.lengths[live ? bq : 0];
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 dh = z4, r = z4, z = z4, n = z4, hpre = z4, hp = z4, dhz_in = z4;
   float* dhz = p.dhz + ((long)dir * B + (live ? bq : 0)) * H + u;
   if (live && p.s > 0) dhz_in = *reinterpret_cast<const f32x4*>(dhz);
-  if (valid) {
+  if (live) {  // unconditional of the clip length (see the forward kernel); rows past a clip's end hold zeros / are ignored
     dh = *reinterpret_cast<const f32x4*>(p.d_out + row * 2 * H + dir * H + u);
     const float* sv = p.save + ((long)dir * N + row) * 4 * H;
     r = *reinterpret_cast<const f32x4*>(sv + u); z = *reinterpret_cast<const f32x4*>(sv + H + u);
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
       }
     }
   }
+  const bool valid = live && t < len;
 #pragma unroll
   for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(red + ((wv * 4 + c) * 64 + lane) * 4) = acc[c];
   __syncthreads();
