@@ -241,40 +241,48 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
       __syncthreads();
     }
   }
-  // ---- hand the register-resident gradients over: D row 4 g + r = co, column li = ci.  The WK waves that share a tile set
-  // (K split) are first summed through LDS: 256 workgroups x 8 waves of float atomics onto the 4.6 k addresses of a small
-  // layer's gradient serialise at the memory side
-  float* redw = reinterpret_cast<float*>(smem);  // [COUT][CIN][9] + [COUT]: the operand images are dead
-  if (WK > 1) {
-    for (int q = tid; q < COUT * CIN * 9 + COUT; q += NT) redw[q] = 0.f;
+  // ---- hand the register-resident gradients over: D row 4 g + r = co, column li = ci.  Always through LDS, in [co][ci][tap]
+  // order: (i) the WK waves that share a tile set (K split) are summed there first -- 256 workgroups x 8 waves of float atomics
+  // onto the 4.6 k addresses of a small layer serialise at the memory side; (ii) an accumulator register holds elements that lie
+  // 36 bytes apart (ci) in 4 rows (co): as global atomics that is 64 scattered dwords per wave instruction, 17x below the rate of
+  // 256 contiguous bytes (MI355X_MICROARCH.md, global float atomics: 0.7 ms of the last layer's 1.0 ms).  The image holds
+  // COUT/HALVES output channels at a time so that the last layer's 221 KB of gradients fit.
+  float* redw = reinterpret_cast<float*>(smem);  // the operand images are dead
+  constexpr int HALVES = (COUT * CIN * 9 * 4 > 120 * 1024) ? 2 : 1, CO_H = COUT / HALVES;
+  static_assert(CO_H % 16 == 0 && CO_H * CIN * 9 * 4 <= 150 * 1024, "gradient image");
+#pragma unroll
+  for (int hf = 0; hf < HALVES; ++hf) {
     __syncthreads();
-  }
+    for (int q = tid; q < CO_H * CIN * 9; q += NT) redw[q] = 0.f;
+    __syncthreads();
 #pragma unroll
-  for (int a = 0; a < NCO; ++a) {
-    const int co0 = 16 * (wco * NCO + a) + 4 * g;
+    for (int a = 0; a < NCO; ++a) {
+      const int co0 = 16 * (wco * NCO + a) + 4 * g - hf * CO_H;  // first of this lane's 4 rows, relative to the half
+      if (co0 >= 0 && co0 < CO_H) {
 #pragma unroll
-    for (int b = 0; b < NCI; ++b) {
-      const int ci = 16 * (wci * NCI + b) + li;
+        for (int b = 0; b < NCI; ++b) {
+          const int ci = 16 * (wci * NCI + b) + li;
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+          for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long o = ((long)(co0 + r) * CIN + ci) * 9 + t;
-          if (WK > 1) atomicAdd(redw + o, acc[a][b][t][r]);
-          else atomicAdd(p.g_w + o, acc[a][b][t][r]);
+            for (int r = 0; r < 4; ++r) atomicAdd(redw + ((co0 + r) * CIN + ci) * 9 + t, acc[a][b][t][r]);
         }
-    }
-    if (wci == 0 && li == 0)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (WK > 1) atomicAdd(redw + COUT * CIN * 9 + co0 + r, accb[a][r]);
-        else atomicAdd(p.g_b + co0 + r, accb[a][r]);
       }
-  }
-  if (WK > 1) {
+    }
     __syncthreads();
-    for (int q = tid; q < COUT * CIN * 9; q += NT) atomicAdd(p.g_w + q, redw[q]);
-    for (int q = tid; q < COUT; q += NT) atomicAdd(p.g_b + q, redw[COUT * CIN * 9 + q]);
+    for (int q = tid; q < CO_H * CIN * 9; q += NT) atomicAdd(p.g_w + (long)hf * CO_H * CIN * 9 + q, redw[q]);
+  }
+  {  // bias gradients: every column of accb holds the same sum
+    __syncthreads();
+    for (int q = tid; q < COUT; q += NT) redw[q] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NCO; ++a)
+      if (wci == 0 && li == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(redw + 16 * (wco * NCO + a) + 4 * g + r, accb[a][r]);
+    __syncthreads();
+    for (int q = tid; q < COUT; q += NT) atomicAdd(p.g_b + q, redw[q]);
   }
   if (LAST) {
 #pragma unroll
@@ -288,7 +296,10 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
 
 template <int CIN, int COUT, int W, int BH>
 constexpr int wgrad_lds() {
-  return BH * W * (COUT + 8) * 2 + Img<CIN, BH, W>::BYTES + 256 + (64 + 96 + 96) * 4;
+  const int operands = BH * W * (COUT + 8) * 2 + Img<CIN, BH, W>::BYTES + 256 + (64 + 96 + 96) * 4;
+  const int halves = (COUT * CIN * 9 * 4 > 120 * 1024) ? 2 : 1;
+  const int flush = COUT / halves * CIN * 9 * 4;  // the [co][ci][tap] image the gradients leave through
+  return operands > flush ? operands : flush;
 }
 
 // ================================================================================================ dgrad

@@ -16,7 +16,9 @@
 
 namespace {
 
-constexpr int CG = 64;  // clips per workgroup (4 MFMA column tiles)
+// clips per workgroup = CT MFMA column tiles.  32 clips: 2 * (H/16) * ceil(B/32) workgroups = 512 at B = 256, H = 512 -- two
+// per CU, so a step has 8 waves per CU issuing loads instead of 4 (a step is one memory round trip: more of it in flight)
+constexpr int CT = 2, CG = 16 * CT;
 
 // ---- W_hh (f32, [3H][H]) of both directions -> bf16 copy and bf16 transpose [H][3H]
 __global__ __launch_bounds__(256) void whh_prep_kernel(const float* __restrict__ w_f, const float* __restrict__ w_r, int H,
@@ -50,7 +52,7 @@ struct StepFwdParams {
 
 template <int H>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 4 * 3 * 64 * 4];  // [wave][clip tile][gate][lane][4]
+  __shared__ __attribute__((aligned(16))) float red[4 * CT * 3 * 64 * 4];  // [wave][clip tile][gate][lane][4]
   const int B = p.B, T = p.T;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
   const int dir = blockIdx.y;
@@ -62,9 +64,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
 
   // ---- everything the gate phase needs is requested first: one memory round trip under the MFMA loop instead of a second
   // one behind it (a step is latency, not bandwidth)
-  const int bq = CG * cg + 16 * wv + li;        // the clip this lane finishes (clip tile wv)
+  const int bq = CG * cg + 16 * wv + li;        // the clip this lane finishes (clip tile wv; waves >= CT only multiply)
   const int u = 16 * ut + 4 * g;                // its 4 hidden units
-  const bool live = bq < B;
+  const bool live = wv < CT && bq < B;
   const long row = (long)(live ? bq : 0) * T + t;
   const int len = p.lengths[live ? bq : 0];
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -80,22 +82,22 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
     if (p.s > 0 && tp >= 0 && tp < T) hp = *reinterpret_cast<const f32x4*>(p.out + ((long)bq * T + tp) * 2 * H + dir * H + u);
   }
 
-  f32x4 acc[4][3];
+  f32x4 acc[CT][3];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < CT; ++c)
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[c][q] = z4;
   if (p.s > 0) {
     const bf16_t* W = p.whh + (long)dir * 3 * H * H;
     const bf16_t* hb = p.hb_in + (long)dir * B * H;
-    s16x8 fa[KS][3], fb[KS][4];
+    s16x8 fa[KS][3], fb[KS][CT];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {  // all operand loads of the wave in flight together
       const int k0 = wv * (H / 4) + 32 * ks;
 #pragma unroll
       for (int q = 0; q < 3; ++q) fa[ks][q] = *reinterpret_cast<const s16x8*>(W + (long)(q * H + 16 * ut + li) * H + k0 + 8 * g);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < CT; ++c) {
         const int b = CG * cg + 16 * c + li;
         fb[ks][c] = b < B ? *reinterpret_cast<const s16x8*>(hb + (long)b * H + k0 + 8 * g) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
       }
@@ -103,26 +105,26 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int q = 0; q < 3; ++q) acc[c][q] = mfma_bf16(fa[ks][q], fb[ks][c], acc[c][q]);
   }
   const bool valid = live && t < len;
   // K slices -> LDS; wave w then owns clip tile w
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<f32x4*>(red + (((wv * 4 + c) * 3 + q) * 64 + lane) * 4) = acc[c][q];
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<f32x4*>(red + (((wv * CT + c) * 3 + q) * 64 + lane) * 4) = acc[c][q];
   __syncthreads();
+  if (!live) return;
   f32x4 gh[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     f32x4 s = z4;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(red + (((w * 4 + wv) * 3 + q) * 64 + lane) * 4);
+    for (int w = 0; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(red + (((w * CT + wv) * 3 + q) * 64 + lane) * 4);
     gh[q] = s;
   }
-  if (!live) return;
   f32x4 hn = z4;
   if (valid) {
     f32x4 rr, zz, nn, hh;
@@ -164,7 +166,7 @@ struct StepBwdParams {
 
 template <int H>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];  // [wave][clip tile][lane][4]
+  __shared__ __attribute__((aligned(16))) float red[4 * CT * 64 * 4];  // [wave][clip tile][lane][4]
   const int B = p.B, T = p.T;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
   const int dir = blockIdx.y;
@@ -174,12 +176,12 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
   const int t = dir ? p.s : (T - 1 - p.s);
   const long N = (long)B * T;
   constexpr int KS = 3 * H / 128;  // 32-deep k steps of this wave's quarter of the contraction (K = 3H)
-  constexpr int KB = 4;            // k steps whose operands are in flight together
+  constexpr int KB = 6;            // k steps whose operands are in flight together
 
   // ---- the element-wise phase's operands first (see the forward kernel)
   const int bq = CG * cg + 16 * wv + li;
   const int u = 16 * ut + 4 * g;
-  const bool live = bq < B;
+  const bool live = wv < CT && bq < B;
   const long row = (long)(live ? bq : 0) * T + t;
   const int len = p.lengths[live ? bq : 0];
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -195,22 +197,22 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
     if (tp >= 0 && tp < T) hp = *reinterpret_cast<const f32x4*>(p.out + ((long)bq * T + tp) * 2 * H + dir * H + u);
   }
 
-  f32x4 acc[4];
+  f32x4 acc[CT];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = z4;
+  for (int c = 0; c < CT; ++c) acc[c] = z4;
   if (p.s > 0) {
     const bf16_t* Wt = p.whht + (long)dir * 3 * H * H;
     const bf16_t* dg = p.dgh_in + (long)dir * B * 3 * H;
 #pragma unroll
     for (int kb = 0; kb < KS; kb += KB) {
-      s16x8 fa[KB], fb[KB][4];
+      s16x8 fa[KB], fb[KB][CT];
 #pragma unroll
       for (int ks = 0; ks < KB; ++ks) {
         if (kb + ks >= KS) break;  // compile-time: KS need not be a multiple of KB
         const int k0 = wv * (3 * H / 4) + 32 * (kb + ks);
         fa[ks] = *reinterpret_cast<const s16x8*>(Wt + (long)(16 * ut + li) * 3 * H + k0 + 8 * g);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < CT; ++c) {
           const int b = CG * cg + 16 * c + li;
           fb[ks][c] = b < B ? *reinterpret_cast<const s16x8*>(dg + (long)b * 3 * H + k0 + 8 * g) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
@@ -219,18 +221,18 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
       for (int ks = 0; ks < KB; ++ks) {
         if (kb + ks >= KS) break;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = mfma_bf16(fa[ks], fb[ks][c], acc[c]);
+        for (int c = 0; c < CT; ++c) acc[c] = mfma_bf16(fa[ks], fb[ks][c], acc[c]);
       }
     }
   }
   const bool valid = live && t < len;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(red + ((wv * 4 + c) * 64 + lane) * 4) = acc[c];
+  for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4*>(red + ((wv * CT + c) * 64 + lane) * 4) = acc[c];
   __syncthreads();
+  if (!live) return;
   f32x4 carry = dhz_in;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) carry += *reinterpret_cast<const f32x4*>(red + ((w * 4 + wv) * 64 + lane) * 4);
-  if (!live) return;
+  for (int w = 0; w < 4; ++w) carry += *reinterpret_cast<const f32x4*>(red + ((w * CT + wv) * 64 + lane) * 4);
   f32x4 drp = z4, dzp = z4, dnp = z4, dhn = z4, keep = carry;
   if (valid) {
     if (p.drop_p > 0.f) dh *= drop_scale4((row * 2 * H + dir * H + u) >> 2, p.drop_p, p.seed, p.offset);

@@ -113,11 +113,21 @@ __device__ __forceinline__ bool sweep_granules(rsrc_t rs, int pair0, unsigned ta
   }
 }
 
-__device__ __forceinline__ void finish_launch(unsigned* sync, unsigned gen) {
+// sync[2] counts bounded waits that gave up (never reset: the host reads it where it synchronises anyway, see
+// engine.check_gru_sync); sync[4] = its value at the end of the previous launch.  A workgroup that loses a partner poisons
+// element 0 of the result itself, but that element belongs to one (clip 0, t = 0) workgroup which may store it AFTER the
+// poison; so the LAST workgroup of the launch -- every other one has issued its stores by then -- poisons it again whenever the
+// counter moved during this launch.
+__device__ __forceinline__ void finish_launch(unsigned* sync, unsigned gen, float* poison) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned done = atomicAdd(&sync[1], 1u);
     if (done == gridDim.x - 1) {
+      const unsigned errs = __hip_atomic_load(&sync[2], __ATOMIC_RELAXED, SS_AGENT);
+      if (errs != sync[4]) {
+        *poison = __builtin_nanf("");
+        sync[4] = errs;
+      }
       __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, SS_AGENT);
       __hip_atomic_store(&sync[0], gen + 1u, __ATOMIC_RELEASE, SS_AGENT);
     }
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   }
   if (dead && lane == 0) p.out[0] = __builtin_nanf("");
   STAMP_FLUSH();
-  finish_launch(sync, gen);
+  finish_launch(sync, gen, p.out);
 }
 
 // xg: [2 step parity][pairs][P dest parts][P source parts][16 clips][UP]  partial dh_prev granules
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   if (dead && lane == 0) p.d_g[0] = __builtin_nanf("");
   if (owner) bacc.flush(p, dir, H, j0, i);  // owner is wave-uniform
   STAMP_FLUSH();
-  finish_launch(sync, gen);
+  finish_launch(sync, gen, p.d_g);
 }
 
 // sync_ws sections, in granules

@@ -137,6 +137,16 @@ def _addr(t: torch.Tensor, offset_elems: int = 0) -> int:
     return t.data_ptr() + offset_elems * t.element_size()
 
 
+def check_gru_sync(ws) -> None:
+    """Raise if a bounded wait of the multi-CU GRU recurrence ever gave up on this workspace (a partner workgroup was not
+    co-resident: the kernels then poison their result with NaN and count the event in word 2 of the sync header).  Reads
+    one int from the device: call it where the host synchronises anyway (end of an epoch, ``evaluate``)."""
+    sync = getattr(ws, "gru_sync", None)
+    if sync is not None and int(sync[2]) != 0:
+        raise RuntimeError(f"multi-CU GRU recurrence: {int(sync[2])} exchange waits timed out (a partner workgroup never "
+                           "arrived); results since then are poisoned with NaN")
+
+
 def make_workspace(cfg: Config, B: int, T: int, roi_hw, device, train: bool):
     if cfg.precision == "bf16":
         from .engine_bf16 import WorkspaceBf16

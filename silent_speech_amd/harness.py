@@ -112,6 +112,7 @@ def evaluate(model: BiGRUClassifier, store: DeviceClipStore, batch_size: int = B
         y_true += y.cpu().tolist()
         y_pred += top[:, 0].cpu().tolist()
     model.train(was_training)
+    model.check_health()  # the loop above has synchronised anyway
     n = max(1, len(store))
     return float(loss_sum) / n, int(correct) / n, y_true, y_pred
 

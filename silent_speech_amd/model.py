@@ -239,6 +239,12 @@ class BiGRUClassifier(nn.Module):
             self._ws_cache[key] = ws
         return ws
 
+    def check_health(self) -> None:
+        """Raises if any kernel of this module reported a failure it could not return as a status code (today: a lost
+        partner in the multi-CU GRU recurrence).  One small device read per workspace -- for points that synchronise anyway."""
+        for ws in self._ws_cache.values():
+            E.check_gru_sync(ws)
+
     def _stash_workspace(self, X, R) -> E.Workspace:
         """Training workspace for an autograd forward: the first one of this shape whose stash is not waiting for a
         backward pass.  ``la = m(Xa); lb = m(Xb); (la + lb).backward()`` therefore gets two workspaces; when
