@@ -16,9 +16,10 @@
 
 namespace {
 
-// clips per workgroup = CT MFMA column tiles.  32 clips: 2 * (H/16) * ceil(B/32) workgroups = 512 at B = 256, H = 512 -- two
-// per CU, so a step has 8 waves per CU issuing loads instead of 4 (a step is one memory round trip: more of it in flight)
-constexpr int CT = 2, CG = 16 * CT;
+// clips per workgroup = CT MFMA column tiles: 64 clips -> 2 * (H/16) * ceil(B/64) workgroups = 256 at B = 256, H = 512, one per
+// CU.  (CT = 2, two workgroups per CU with half the accumulators each, was measured: 5 % slower per step -- W_hh is read twice
+// as often and a step is one memory round trip either way.)
+constexpr int CT = 4, CG = 16 * CT;
 
 // ---- W_hh (f32, [3H][H]) of both directions -> bf16 copy and bf16 transpose [H][3H]
 __global__ __launch_bounds__(256) void whh_prep_kernel(const float* __restrict__ w_f, const float* __restrict__ w_r, int H,
