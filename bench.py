@@ -447,16 +447,16 @@ def main():
     # ---- per-kernel launch durations over K more steps, HIP events on the launch stream
     kernels, roof = {}, None
     if not args.no_kernel_times:
-        from silent_speech_amd import engine
+        from silent_speech_amd import engine, engine_bf16
 
-        engine.USE_SIDE_STREAM = False  # one stream, so each event pair brackets exactly one kernel
+        engine.USE_SIDE_STREAM = engine_bf16.USE_SIDE_STREAM = False  # one stream, so each event pair brackets exactly one kernel
         mb, trainer.micro_batches = trainer.micro_batches, 1
         L.PROFILE = {}
         for _ in range(args.steps):
             trainer.step(X, lengths, R, y)
         torch.cuda.synchronize()
         prof, L.PROFILE = L.PROFILE, None
-        engine.USE_SIDE_STREAM = True
+        engine.USE_SIDE_STREAM = engine_bf16.USE_SIDE_STREAM = True
         trainer.micro_batches = mb
         for tag, evs in prof.items():
             ms = [a.elapsed_time(b) for a, b in evs]

@@ -22,6 +22,7 @@ import torch
 from . import _lib as L
 
 INT_MAX = 2**31 - 1
+USE_SIDE_STREAM = True  # bench.py turns it off for its per-kernel timing pass (HIP-event pairs need one stream)
 CNN_CHANNELS = (16, 32, 64, 96)
 ROI_HW = (96, 96)
 _IDENT = (INT_MAX, 0, 0)
@@ -67,6 +68,11 @@ class WorkspaceBf16:
         self.cfg, self.B, self.T, self.roi_hw, self.train = cfg, B, T, roi_hw, train
         self.stash_gen, self.stash_live = 0, False
         self.stagger = False
+        # weight-gradient GEMMs of a layer run on a side stream beside the BPTT steps of the layer below (a step is a tiny,
+        # latency-bound launch that leaves the matrix pipes idle)
+        self.side = torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[0]) if train else None
+        self.ev_fork = torch.cuda.Event() if train else None
+        self.ev_join = torch.cuda.Event() if train else None
         N, H = B * T, cfg.hidden
         f32 = dict(device=device, dtype=torch.float32)
         u8 = dict(device=device, dtype=torch.uint8)
@@ -207,12 +213,31 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         else:
             lin, ld_in = (ws.out_drop[l - 1] if use_drop else ws.out[l - 1]).data_ptr(), 2 * H
         dg = ws.dG[l].data_ptr()
-        # ---- bias gradients: column sums of d_g (r | z | n | hn), both directions in one launch
-        L.call("ss_gru_bias_grad", dg, N, H, G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
-               G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), s)
-        # ---- d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r (both directions in one launch, float atomics into a cleared buffer)
-        need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
         wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
+
+        def param_grads(l=l, K=K, lin=lin, ld_in=ld_in, dg=dg, wi=wi, wir=wir):
+            # ---- bias gradients: column sums of d_g (r | z | n | hn), both directions in one launch
+            L.call("ss_gru_bias_grad", dg, N, H, G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
+                   G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.stream())
+            # ---- weight gradients: d W_ih = dGi^T . layer_in;  d W_hh = dGh^T . h_prev (rows r|z from columns [0,2H), rows n from [3H,4H))
+            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
+                 splits=split_k(3 * H, K, N, 2), batch=2, strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0), tag="gemm_bf16_dW")
+            if T > 1:
+                wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
+                Kh = B * (T - 1)
+                am, bm = (T - 1, T, 1), (T - 1, T, 0)
+                # forward direction pairs dG[b][t] with out[b][t-1]; the reverse direction dG[b][t] with out[b][t+1]: the same
+                # pairing seen from one row earlier in dG and one row later in out (two pointer shifts = the batch strides)
+                sa, sb, sc = N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr)
+                hp = ws.out[l].data_ptr()
+                gemm(0, 0, 2 * H, H, Kh, dg, 4 * H, hp, 2 * H, G[wh].data_ptr(), H, accumulate=True, atomic=True,
+                     splits=split_k(2 * H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
+                gemm(0, 0, H, H, Kh, dg + 3 * H * 4, 4 * H, hp, 2 * H, _addr(G[wh], 2 * H * H), H, accumulate=True, atomic=True,
+                     splits=split_k(H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
+
+        # ---- d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r (both directions in one launch, float atomics into a cleared buffer):
+        # on the critical path (the layer below / the CNN backward waits for it), so it goes first
+        need_dx = (l > 0) or cfg.use_roi or (d_X is not None)
         if need_dx:
             if l > 0:
                 dst, ld_dst, c0 = ws.d_lower[l].data_ptr(), 2 * H, 0
@@ -226,21 +251,13 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
                 dst, ld_dst, c0 = d_X.data_ptr(), cfg.x_dim, 0
             gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(P[wi], c0), K, dst, ld_dst, accumulate=True, atomic=True, batch=2,
                  strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0), tag="gemm_bf16_dX")
-        # ---- weight gradients: d W_ih = dGi^T . layer_in;  d W_hh = dGh^T . h_prev (rows r|z from columns [0,2H), rows n from [3H,4H))
-        gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
-             splits=split_k(3 * H, K, N, 2), batch=2, strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0), tag="gemm_bf16_dW")
-        if T > 1:
-            wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
-            Kh = B * (T - 1)
-            am, bm = (T - 1, T, 1), (T - 1, T, 0)
-            # forward direction pairs dG[b][t] with out[b][t-1]; the reverse direction dG[b][t] with out[b][t+1]: the same
-            # pairing seen from one row earlier in dG and one row later in out (two pointer shifts = the batch strides)
-            sa, sb, sc = N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr)
-            hp = ws.out[l].data_ptr()
-            gemm(0, 0, 2 * H, H, Kh, dg, 4 * H, hp, 2 * H, G[wh].data_ptr(), H, accumulate=True, atomic=True,
-                 splits=split_k(2 * H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
-            gemm(0, 0, H, H, Kh, dg + 3 * H * 4, 4 * H, hp, 2 * H, _addr(G[wh], 2 * H * H), H, accumulate=True, atomic=True,
-                 splits=split_k(H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
+        if USE_SIDE_STREAM:
+            ws.ev_fork.record()
+            with torch.cuda.stream(ws.side):
+                ws.side.wait_event(ws.ev_fork)
+                param_grads()
+        else:
+            param_grads()
     if cfg.use_roi:
         if d_X is not None:
             L.call("ss_copy_rows_f32", ws.dZ.data_ptr(), cfg.in_dim, d_X.data_ptr(), cfg.x_dim, N, cfg.x_dim, s)
@@ -258,3 +275,6 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         L.call("ss_c5_conv_dgrad", 2, ws.da2.data_ptr(), ws.i2.data_ptr(), N, w[1], ws.da1.data_ptr(), s, tag="ss_c5_conv2_dgrad")
         L.call("ss_c5_conv1_wgrad", R.data_ptr(), N, int(cfg.roi_standardize), ws.st.data_ptr(), ws.da1.data_ptr(), ws.i1.data_ptr(),
                gw[0], gb[0], s)
+    if USE_SIDE_STREAM:  # the caller's next kernels (all-reduce, clip, Adam) read every gradient
+        ws.ev_join.record(ws.side)
+        torch.cuda.current_stream().wait_event(ws.ev_join)
