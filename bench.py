@@ -6,6 +6,11 @@ BiGRU(192), T=30, batch 256 per GPU, fp32 -- on synthetic clips resident in HBM.
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --config 5        # BASELINE config 5: 100 words, 96x96 ROI, CNN 16/32/64/96, BiGRU(512), bf16 MFMA
+
+The default (config 2, one GPU) line also carries ``config4`` (BASELINE config 4: 4 096 x T=60 windows, forward-only,
+hipGraph replay, softmax + top-3 on device, with its own roofline) and ``cpu_baseline`` for config 2 at the bench batch
+(``also``: config 2 at batch 32 and config 1, landmark-only at batch 8 -- SURVEY.md 8d's three CPU rows).
 
 One JSON line on rank 0.  ``value`` = clips of all ranks / max-over-ranks wall time of exactly K steps.
 ``roofline`` prices the slowest kernel of the step against the f32-MFMA peak with its ALGORITHMIC FLOPs
@@ -91,8 +96,8 @@ def step_gflop_per_clip(T, D, E, H, C, roi, mid=128, fwd_only=False):
     return 2.0 * (3 * fwd - T * conv1) / 1e9
 
 
-PMC_TRAFFIC = os.path.join("profiles", "round2_a_pmc_traffic.json")
-PMC_MFMA = os.path.join("profiles", "round2_a_pmc_mfma.json")
+PMC_TRAFFIC = os.path.join("profiles", "round2_b_pmc_traffic.json")
+PMC_MFMA = os.path.join("profiles", "round2_b_pmc_mfma.json")
 
 
 def pmc_mfma_busy(kernel_tag):

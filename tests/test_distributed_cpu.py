@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, B=8):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
     from oracle import model_ref as MR
     import silent_speech_amd as ss
 
-    B, T = 8, 6
+    T = 6
     sd = W.make_state_dict(5, 84, 5, True)
     X, L, R, y = W.make_inputs(5, B, T, 84, 5, (64, 64))
     lo, hi = ss.shard_range(B, rank, world)
@@ -62,11 +62,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_flat_bucket_allreduce_equals_full_batch():
+@pytest.mark.parametrize("B", [8, 7])  # 7: shards of 4 and 3 clips -- the loss is divided by the GLOBAL batch (Trainer.step(global_batch=))
+def test_two_rank_flat_bucket_allreduce_equals_full_batch(B):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, B)) for r in range(2)]
     for p in procs:
         p.start()
     worst, dloss, n = q.get(timeout=240)
