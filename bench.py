@@ -43,11 +43,11 @@ def c5_gflop_per_step(B, T, D):
     ih = (D + E) + 2 * H  # input widths of the two layers
     f = lambda macs: 2.0 * macs / 1e9
     return {
-        "ss_c5_conv1_fwd": f(N * conv[1]), "ss_c5_conv2_fwd": f(N * conv[2]), "ss_c5_conv3_fwd": f(N * conv[3]),
+        "ss_c5_conv12_fwd": f(N * (conv[1] + conv[2])), "ss_c5_conv3_fwd": f(N * conv[3]),
         "ss_c5_conv_last_fwd": f(N * (conv[4] + c4 * E)),
         "ss_c5_conv_last_wgrad": f(N * (conv[4] + c4 * E)), "ss_c5_conv_last_dgrad": f(N * (conv[4] + c4 * E)),
         "ss_c5_conv3_wgrad": f(N * conv[3]), "ss_c5_conv3_dgrad": f(N * conv[3]),
-        "ss_c5_conv2_wgrad": f(N * conv[2]), "ss_c5_conv2_dgrad": f(N * conv[2]), "ss_c5_conv1_wgrad": f(N * conv[1]),
+        "ss_c5_conv2_wgrad_rc": f(N * conv[2]), "ss_c5_conv2_dgrad": f(N * conv[2]), "ss_c5_conv1_wgrad": f(N * conv[1]),
         "gemm_bf16_ih": f(2 * N * 3 * H * ih), "gemm_bf16_dX": f(2 * N * 3 * H * (E + 2 * H)),
         "gemm_bf16_dW": f(2 * N * 3 * H * ih + 2 * 2 * N * 3 * H * H),
         "ss_gru_bf16_fwd": f(2 * 2 * N * 3 * H * H), "ss_gru_bf16_bwd": f(2 * 2 * N * 3 * H * H),

@@ -265,7 +265,7 @@ int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, con
  * Backward (gradients ACCUMULATE into g_*; d a maps are UNMASKED, the argmax byte of the layer below applies its ReLU):
  *   ss_c5_conv_last_wgrad  d z (N,E at ld_dz) -> g_w4, g_b4, g_wfc, g_bfc;   ss_c5_conv_last_dgrad -> da3 (N,12,12,64)
  *   ss_c5_conv_wgrad / ss_c5_conv_dgrad  layer 3: (a2, da3, i3) -> g_w3, g_b3 / da2;  layer 2: (a1, da2, i2) -> g_w2, g_b2 / da1
- *   ss_c5_conv1_wgrad      (R, st, da1, i1) -> g_w1, g_b1 */
+ *   ss_c5_conv1_wgrad      (R, st, da1, i1 | w1, b1) -> g_w1, g_b1 */
 int ss_c5_conv1_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, uint16_t* a1, uint8_t* i1,
                     float* st, ss_stream_t stream);
 int ss_c5_conv_fwd(int layer, const uint16_t* in, int N, const float* w, const float* b, uint16_t* out, uint8_t* idx,
@@ -281,7 +281,16 @@ int ss_c5_conv_last_wgrad(const uint16_t* a_in, const float* dz, int ld_dz, int 
 int ss_c5_conv_last_dgrad(const float* dz, int ld_dz, int E, const float* wfc, const uint8_t* mask, int N, const float* w,
                           uint16_t* da_in, ss_stream_t stream);
 int ss_c5_conv1_wgrad(const uint8_t* R, int N, int standardize, const float* st, const uint16_t* da1, const uint8_t* i1,
-                      float* g_w1, float* g_b1, ss_stream_t stream);
+                      const float* w1, const float* b1, float* g_w1, float* g_b1, ss_stream_t stream);
+/* The fused forms the engine uses (the pooled conv1 map -- 74 KB per frame + 37 KB of argmax bytes, the largest tensor of the
+ * net -- never reaches HBM):
+ *   ss_c5_conv12_fwd      R -> a2 (N,24,24,32), i2, st: conv1 lands in conv2's LDS image
+ *   ss_c5_conv2_wgrad_rc  layer 2's weight gradient with a1 recomputed per band from R and st (conv1: w1, b1)
+ *   ss_c5_conv1_wgrad     with i1 == NULL recomputes conv1's pool winners from R (needs w1, b1) */
+int ss_c5_conv12_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, const float* w2, const float* b2,
+                     uint16_t* a2, uint8_t* i2, float* st, ss_stream_t stream);
+int ss_c5_conv2_wgrad_rc(const uint8_t* R, const float* st, int standardize, const float* w1, const float* b1,
+                         const uint16_t* da_out, const uint8_t* idx, int N, float* g_w, float* g_b, ss_stream_t stream);
 
 /* ---- a7: one bidirectional GRU layer, recurrence only ---------------------------------------
  * replaces pack_padded_sequence -> nn.GRU -> pad_packed_sequence (train_model_official.py:301-305).

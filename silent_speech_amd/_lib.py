@@ -44,7 +44,9 @@ SIGNATURES = {
     "ss_c5_conv_dgrad": [_i, _vp, _vp, _i, _vp, _vp, _vp],
     "ss_c5_conv_last_wgrad": [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "ss_c5_conv_last_dgrad": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
-    "ss_c5_conv1_wgrad": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ss_c5_conv1_wgrad": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ss_c5_conv12_fwd": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ss_c5_conv2_wgrad_rc": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "ss_gru_bf16_prep": [_vp, _vp, _i, _vp, _vp, _vp],
     "ss_gru_bf16_ws_bytes": [_i, _i, _vp],
     "ss_gru_bf16_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -50,6 +50,51 @@ struct Wmat {
   static constexpr int ELEMS = CN * LD, BYTES = ELEMS * 2;
 };
 
+constexpr int RS0 = 104;  // row stride of the 98 x 98 haloed one-channel normalised image (elements)
+
+// The 12 constant B fragments of the conv1 patch GEMM (cnn_bf16.hip): output position q = (oy, ox) of a 4 x 8 patch reads patch
+// cell (oy + ky, ox + kx); lane (g = patch row, li = channel) holds the 8 cells of its row.
+__device__ __forceinline__ s16x8 conv1_bfrag(const float* __restrict__ w1, int q, int g, int li) {
+  const int oy = q / 6, ox = q % 6;
+  s16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ky = g - oy, kx = j - ox;
+    f[j] = (short)to_bf16((ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) ? w1[li * 9 + ky * 3 + kx] : 0.f);
+  }
+  return f;
+}
+
+// conv1 of the row pairs [yp0, yp1) of a frame whose normalised bf16 image sits at img ([98][RS0]): pooled ReLU output
+// (bf16) into dst(yp, xp)[c], dst(yp, xp) = a1 + off0 + (yp - ypb) * RS + xp * PS; optionally the argmax bytes into
+// ib[((yp - ypb) * 48 + xp) * 16 + c].  bq = the 12 constant B fragments (output position q of a patch).
+template <class GETB>
+__device__ __forceinline__ void conv1_rows(const bf16_t* img, GETB getb, float bias, int yp0, int yp1, int ypb, bf16_t* a1, int off0,
+                                           int RS, int PS, uint8_t* ib, int wv, int g, int li) {
+  for (int yp = yp0 + wv; yp < yp1; yp += NW) {
+    const unsigned* ap = reinterpret_cast<const unsigned*>(img + (2 * yp + g) * RS0 + 6 * li);
+    const s16x8 fa = __builtin_bit_cast(s16x8, uint4{ap[0], ap[1], ap[2], ap[3]});
+    f32x4 acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = mfma_bf16(fa, getb(q), f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        float best = acc[2 * w][r];
+        int bi = 0;
+        if (acc[2 * w + 1][r] > best) { best = acc[2 * w + 1][r]; bi = 1; }
+        if (acc[6 + 2 * w][r] > best) { best = acc[6 + 2 * w][r]; bi = 2; }
+        if (acc[6 + 2 * w + 1][r] > best) { best = acc[6 + 2 * w + 1][r]; bi = 3; }
+        const float v = fmaxf(best + bias, 0.f);
+        const int xp = 3 * (4 * g + r) + w;
+        if (a1) a1[off0 + (yp - ypb) * RS + xp * PS + li] = to_bf16(v);
+        if (ib) ib[((yp - ypb) * 48 + xp) * C1 + li] = (uint8_t)(v > 0.f ? bi : IDX_DEAD);
+      }
+  }
+}
+
+
 // ---- HBM -> registers -> LDS in two steps: ``issue`` starts the global loads of the NEXT frame / band before the MFMA
 // phase of the current one, ``commit`` writes them into the (single-buffered) LDS images behind it.  The per-layer kernels
 // are HBM-bound (a layer's whole input and output cross HBM once per frame); with load and compute back to back a

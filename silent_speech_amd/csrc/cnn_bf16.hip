@@ -32,7 +32,6 @@ struct Conv1Params {
   float* st;          // (N, 2): mean, std of the frame (backward reuses them) or null
 };
 
-constexpr int RS0 = 104;  // row stride of the 98 x 98 haloed one-channel image (elements)
 
 __global__ __launch_bounds__(NT, 2) void conv1_fwd_kernel(Conv1Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -356,7 +355,193 @@ int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s)
   return ss_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------ conv1 + conv2 fused
+// The pooled conv1 map (73.7 KB per frame as bf16, plus 36.9 KB of argmax bytes) is the largest tensor of the net and was 43 % of
+// the CNN's HBM traffic when every layer was its own kernel.  Here it is born in conv2's haloed LDS image and never leaves the
+// CU: uint8 frame -> statistics -> bf16 image -> conv1 (patch GEMM) + ReLU + pool -> [LDS] -> conv2 + ReLU + pool -> a2, i2.
+// The backward pass recomputes it (and conv1's pool winners) from the 9 KB frame: 576 MFMAs per frame (cnn_bf16_bwd.hip).
+struct Conv12Params {
+  const uint8_t* R;   // (N, 96, 96)
+  int N, standardize;
+  const float *w1, *b1, *w2, *b2;
+  bf16_t* a2;         // (N, 24, 24, 32)
+  uint8_t* i2;        // (N, 24, 24, 32)
+  float* st;          // (N, 2) mean, std or null
+};
+
+__global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using IM = Img<C1, 48, 48>;
+  using WM = Wmat<C1, C2>;
+  constexpr int HO = 24, WO = 24, HH = 12;                     // conv2's pooled output, rows per flush
+  bf16_t* img = reinterpret_cast<bf16_t*>(smem);               // [98][RS0]
+  constexpr int o_tab = round_up(98 * RS0 * 2, 16);
+  float* s_xn = reinterpret_cast<float*>(smem + o_tab);        // [256]
+  float* s_misc = s_xn + 256;                                  // [64]
+  constexpr int o_a1 = o_tab + (256 + 64) * 4;
+  bf16_t* a1 = reinterpret_cast<bf16_t*>(smem + o_a1);         // Img<16,48,48>
+  bf16_t* wl = reinterpret_cast<bf16_t*>(smem + o_a1 + IM::BYTES);
+  constexpr int o_out = o_a1 + IM::BYTES + round_up(WM::BYTES, 16);
+  bf16_t* oa = reinterpret_cast<bf16_t*>(smem + o_out);        // [HH][WO][32]
+  uint8_t* oi = smem + o_out + HH * WO * C2 * 2;               // [HH][WO][32]
+  float* s_bias = reinterpret_cast<float*>(smem + o_out + HH * WO * C2 * 3);  // [32]
+  unsigned* s_red = reinterpret_cast<unsigned*>(s_misc);
+  float* s_stat = s_misc + 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  zero_lds(smem, o_tab, tid);
+  zero_lds(a1, IM::BYTES, tid);
+  stage_weights<C1, C2>(p.w2, wl, tid);
+  if (tid < C2) s_bias[tid] = p.b2[tid];
+  s16x8 bq[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    const int oy = q / 6, ox = q % 6;
+    s16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ky = g - oy, kx = j - ox;
+      f[j] = (short)to_bf16((ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) ? p.w1[li * 9 + ky * 3 + kx] : 0.f);
+    }
+    bq[q] = f;
+  }
+  const float bias1 = p.b1[li];
+  const int chunk = g & 1, hi = g >> 1;
+  uint4 px[2];
+  auto load_px = [&](int n) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
+    px[0] = src[tid];
+    px[1] = (tid + NT < HW0 * HW0 / 16) ? src[tid + NT] : uint4{0u, 0u, 0u, 0u};
+  };
+  if ((int)blockIdx.x < p.N) load_px(blockIdx.x);
+  __syncthreads();
+
+  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    // ---- statistics, table, bf16 image (as conv1_fwd_kernel)
+    unsigned su = 0, sq = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const unsigned u = (wds[e] >> (8 * b)) & 255u;
+          su += u;
+          sq += u * u;
+        }
+    }
+    su = wave_sum_u32(su);
+    sq = wave_sum_u32(sq);
+    if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long tsu = 0, tsq = 0;
+      for (int k = 0; k < NW; ++k) { tsu += s_red[2 * k]; tsq += s_red[2 * k + 1]; }
+      float mu = 0.f, sd = 1.f;
+      if (p.standardize) {
+        const double nn = (double)(HW0 * HW0);
+        mu = (float)((double)tsu / nn) / 255.0f;
+        const double var = ((double)tsq - (double)tsu * (double)tsu / nn) / (nn - 1.0);
+        sd = fmaxf((float)(sqrt(var > 0.0 ? var : 0.0) / 255.0), 1e-6f);
+      }
+      s_stat[0] = mu;
+      s_stat[1] = sd;
+      if (p.st) { p.st[2 * (long)n] = mu; p.st[2 * (long)n + 1] = sd; }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const float rr = (float)tid / 255.0f;
+      s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + k * NT;
+      if (q < HW0 * HW0 / 16) {
+        const int lin = q * 16;
+        bf16_t* dst = img + (lin / HW0 + 1) * RS0 + (lin % HW0) + 1;
+        const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) dst[4 * e + b] = to_bf16(s_xn[(wds[e] >> (8 * b)) & 255u]);
+      }
+    }
+    __syncthreads();
+    if (n + (int)gridDim.x < p.N) load_px(n + gridDim.x);  // the next frame's bytes, under both convolutions
+    // ---- conv1 -> conv2's haloed input image
+    conv1_rows(img, [&](int q) { return bq[q]; }, bias1, 0, 48, 0, a1, IM::at(0, 0), IM::RS, IM::PS, nullptr, wv, g, li);
+    __syncthreads();
+    // ---- conv2 in two halves of 12 pooled rows (the staging area holds one)
+    for (int half = 0; half < 2; ++half) {
+      constexpr int MT = 3, UNITS = HH * 6 / MT;  // 72 m tiles of 2 rows x 8 columns per half
+      for (int u = wv; u < UNITS; u += NW) {
+        int base[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          const int mt = half * HH * 6 + u * MT + a;
+          const int yp = mt / 6, xt = mt % 6;
+          const int y = 2 * yp + ((li >> 1) & 1), x = 8 * xt + 2 * (li >> 2) + (li & 1);
+          base[a] = IM::at(y - 1, x - 1) + 8 * chunk;
+        }
+        f32x4 acc[MT][2];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < WM::KSTEPS; ++s) {
+          const int off = hi ? koff<IM>(s, 1) : koff<IM>(s, 0);
+          s16x8 fa[MT], fb[2];
+#pragma unroll
+          for (int a = 0; a < MT; ++a) fa[a] = lds_frag(a1 + base[a] + off);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) fb[b] = lds_frag(wl + (16 * b + li) * WM::LD + 32 * s + 8 * g);
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int co = 16 * b + li;
+          const float bias = s_bias[co];
+#pragma unroll
+          for (int a = 0; a < MT; ++a) {
+            const int mt = u * MT + a;  // within the half
+            const f32x4 v = acc[a][b];
+            float best = v[0];
+            int bi = 0;
+            if (v[1] > best) { best = v[1]; bi = 1; }
+            if (v[2] > best) { best = v[2]; bi = 2; }
+            if (v[3] > best) { best = v[3]; bi = 3; }
+            const float x = fmaxf(best + bias, 0.f);
+            const int o = ((mt / 6) * WO + 4 * (mt % 6) + g) * C2 + co;
+            oa[o] = to_bf16(x);
+            oi[o] = (uint8_t)(x > 0.f ? bi : IDX_DEAD);
+          }
+        }
+      }
+      __syncthreads();
+      uint4* da = reinterpret_cast<uint4*>(p.a2 + ((long)n * HO + half * HH) * WO * C2);
+      for (int q = tid; q < HH * WO * C2 * 2 / 16; q += NT) da[q] = reinterpret_cast<const uint4*>(oa)[q];
+      uint4* di = reinterpret_cast<uint4*>(p.i2 + ((long)n * HO + half * HH) * WO * C2);
+      for (int q = tid; q < HH * WO * C2 / 16; q += NT) di[q] = reinterpret_cast<const uint4*>(oi)[q];
+      __syncthreads();  // the second half's (and the next frame's) epilogues rewrite the staging area
+    }
+  }
+}
+
+constexpr int CONV12_LDS = round_up(98 * RS0 * 2, 16) + (256 + 64) * 4 + Img<C1, 48, 48>::BYTES + round_up(Wmat<C1, C2>::BYTES, 16) +
+                           12 * 24 * C2 * 3 + C2 * 4;
+
 }  // namespace
+
+extern "C" int ss_c5_conv12_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, const float* w2,
+                                const float* b2, uint16_t* a2, uint8_t* i2, float* st, ss_stream_t stream) {
+  SS_REQUIRE(R && w1 && b1 && w2 && b2 && a2 && i2 && N > 0, SS_ERR_ARG);
+  Conv12Params p{R, N, standardize, w1, b1, w2, b2, a2, i2, st};
+  return launch_persistent(conv12_fwd_kernel, p, CONV12_LDS, N, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int ss_c5_conv1_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, uint16_t* a1,
                                uint8_t* i1, float* st, ss_stream_t stream) {

@@ -46,6 +46,11 @@ struct ConvBwdParams {
   float *g_w, *g_b;       // gradient accumulators (wgrad), +=
   float *g_wfc, *g_bfc;   // (E, COUT), (E)  (last layer's wgrad)
   bf16_t* da_in;          // (N, H, W, CIN) (dgrad)
+  // recompute form of layer 2's weight gradient (RC): a_in is not stored, it is rebuilt from the frame
+  const uint8_t* R;       // (N, 96, 96)
+  const float* st;        // (N, 2) mean, std
+  int standardize;
+  const float *w1, *b1;   // conv1
 };
 
 // dense dy rows [y0, y0 + rows) of a pooled layer into an LDS image whose local row 0 is y0 (rows outside the frame: zeros)
@@ -129,9 +134,12 @@ __device__ __forceinline__ void last_dfeat(const ConvBwdParams& p, int n, float*
 // ================================================================================================ wgrad
 // BH = rows of a band; WCO x WCI x WK = 8 waves: a wave owns COUT/16/WCO co tiles x CIN/16/WCI ci tiles (all 9 taps) and
 // every WK-th 32-pixel k step
-template <int CIN, int COUT, int H, int W, bool LAST, int BH, int WCO, int WCI, int WK>
+// RC (layer 2 only): the layer's input a1 = pool(ReLU(conv1(frame))) is not read from HBM but recomputed per band from the 9 KB
+// uint8 frame (conv1 patch GEMM of cnn_bf16.hip: 12 MFMAs per row pair) -- it was the largest tensor of the net.
+template <int CIN, int COUT, int H, int W, bool LAST, int BH, int WCO, int WCI, int WK, bool RC = false>
 __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
   static_assert(WCO * WCI * WK == NW && H % BH == 0, "wave split");
+  static_assert(!RC || (CIN == C1 && H == 48 && W == 48 && !LAST), "recompute form: layer 2");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using IA = Img<CIN, BH, W>;
   constexpr int PSD = COUT + 8, RSD = W * PSD;           // dense dy band, no halo
@@ -145,10 +153,30 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
   float* s_dz = reinterpret_cast<float*>(smem + DY_BYTES + IA::BYTES + ZB);  // [64]
   float* s_dfeat = s_dz + 64;                                                // [COUT]
   float* s_feat = s_dfeat + 96;                                              // [COUT]
+  // RC: normalised bf16 frame [98][RS0], grey-level table, the 12 conv1 B fragments as [q][lane][8]
+  constexpr int o_rc = DY_BYTES + IA::BYTES + ZB + (64 + 96 + 96) * 4;
+  bf16_t* ximg = reinterpret_cast<bf16_t*>(smem + o_rc);
+  float* s_xn = reinterpret_cast<float*>(smem + o_rc + round_up(98 * RS0 * 2, 16));
+  bf16_t* bqs = reinterpret_cast<bf16_t*>(s_xn + 256);
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
   const int q4 = li >> 2, p4 = li & 3;
   const int wco = wv % WCO, wci = (wv / WCO) % WCI, wk = wv / (WCO * WCI);
+  float bias1 = 0.f;
+  uint4 px[2];
+  auto load_px = [&](int n) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
+    px[0] = src[tid];
+    px[1] = (tid + NT < HW0 * HW0 / 16) ? src[tid + NT] : uint4{0u, 0u, 0u, 0u};
+  };
+  if (RC) {
+    zero_lds(ximg, round_up(98 * RS0 * 2, 16), tid);
+    if (wv == 0)
+#pragma unroll
+      for (int q = 0; q < 12; ++q) *reinterpret_cast<s16x8*>(bqs + (q * 64 + lane) * 8) = conv1_bfrag(p.w1, q, g, li);
+    bias1 = p.b1[li];
+    if ((int)blockIdx.x < p.N) load_px(blockIdx.x);
+  }
   static_assert((COUT + 8) * 2 <= ZB, "zero pixel");
   zero_lds(smem, DY_BYTES + IA::BYTES + ZB, tid);
 
@@ -178,10 +206,32 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
   auto issue = [&](int n, int y0) {
     if (LAST) pm.issue(p.mask + (long)n * H * W * COUT, p.dz + (long)n * p.ld_dz, p.E, p.feat + (long)n * COUT, tid);
     else pe.issue(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, y0, tid);
-    pa.issue(p.a_in + (long)n * H * W * CIN, y0 - 1, tid);
+    if (!RC) pa.issue(p.a_in + (long)n * H * W * CIN, y0 - 1, tid);
   };
   if ((int)blockIdx.x < p.N) issue(blockIdx.x, 0);
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    if (RC) {  // the frame's normalised image (statistics from the forward pass), once per frame
+      if (tid < 256) {
+        const float rr = (float)tid / 255.0f;
+        s_xn[tid] = p.standardize ? (rr - p.st[2 * (long)n]) / p.st[2 * (long)n + 1] : rr;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int q = tid + k * NT;
+        if (q < HW0 * HW0 / 16) {
+          const int lin = q * 16;
+          bf16_t* dst = ximg + (lin / HW0 + 1) * RS0 + (lin % HW0) + 1;
+          const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dst[4 * e + b] = to_bf16(s_xn[(wds[e] >> (8 * b)) & 255u]);
+        }
+      }
+      if (n + (int)gridDim.x < p.N) load_px(n + gridDim.x);
+      __syncthreads();
+    }
     for (int y0 = 0; y0 < H; y0 += BH) {
       if (LAST) {
         if (tid < p.E) s_dz[tid] = pm.dz;
@@ -203,7 +253,18 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
       } else {
         pe.commit(dyi, 0, RSD, PSD, y0, tid);
       }
-      pa.commit(ai, -1, tid);
+      if (RC) {
+        // a1 rows y0-1 .. y0+BH of the band: recomputed inside the frame, zero outside it
+        const int yp0 = y0 > 0 ? y0 - 1 : 0, yp1 = y0 + BH + 1 < H ? y0 + BH + 1 : H;
+        conv1_rows(ximg, [&](int q) { return lds_frag(bqs + (q * 64 + lane) * 8); }, bias1, yp0, yp1, y0, ai, IA::at(0, 0), IA::RS,
+                   IA::PS, nullptr, wv, g, li);
+        if (y0 == 0)
+          for (int q = tid; q < W * CIN / 8; q += NT) *reinterpret_cast<uint4*>(ai + IA::at(-1, 0) + 8 * q) = uint4{0u, 0u, 0u, 0u};
+        if (y0 + BH == H)
+          for (int q = tid; q < W * CIN / 8; q += NT) *reinterpret_cast<uint4*>(ai + IA::at(BH, 0) + 8 * q) = uint4{0u, 0u, 0u, 0u};
+      } else {
+        pa.commit(ai, -1, tid);
+      }
       __syncthreads();
       {  // the next unit's loads fly under the MFMAs below
         const bool last_band = y0 + BH >= H;
@@ -294,9 +355,10 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
   }
 }
 
-template <int CIN, int COUT, int W, int BH>
+template <int CIN, int COUT, int W, int BH, bool RC = false>
 constexpr int wgrad_lds() {
-  const int operands = BH * W * (COUT + 8) * 2 + Img<CIN, BH, W>::BYTES + 256 + (64 + 96 + 96) * 4;
+  const int operands = BH * W * (COUT + 8) * 2 + Img<CIN, BH, W>::BYTES + 256 + (64 + 96 + 96) * 4 +
+                       (RC ? round_up(98 * RS0 * 2, 16) + 256 * 4 + 12 * 64 * 16 : 0);
   const int halves = (COUT * CIN * 9 * 4 > 120 * 1024) ? 2 : 1;
   const int flush = COUT / halves * CIN * 9 * 4;  // the [co][ci][tap] image the gradients leave through
   return operands > flush ? operands : flush;
@@ -403,7 +465,8 @@ struct Conv1BwdParams {
   int N, standardize;
   const float* st;       // (N, 2) mean, std from the forward
   const bf16_t* da1;     // (N, 48, 48, 16) unmasked
-  const uint8_t* i1;     // (N, 48, 48, 16)
+  const uint8_t* i1;     // (N, 48, 48, 16), or null: conv1's pool winners are recomputed from the frame (needs w1, b1)
+  const float *w1, *b1;
   float *g_w1, *g_b1;    // (16, 1, 3, 3), (16)
 };
 
@@ -422,7 +485,7 @@ constexpr int C1_BR = 16;                       // pooled rows per band
 constexpr int C1_XS = 104;                      // row stride of the two haloed 98 x 98 images (elements)
 constexpr int C1_IMG = 98 * C1_XS;              // elements per image
 constexpr int C1_AE = C1_BR * 48 * C1;          // elements per masked image of a band
-constexpr int CONV1_WGRAD_LDS = 2 * C1_IMG * 2 + 4 * C1_AE * 2 + 256 * 4 + 16 * 16 * 4;
+constexpr int CONV1_WGRAD_LDS = 2 * C1_IMG * 2 + 4 * C1_AE * 2 + 256 * 4 + 16 * 16 * 4 + C1_BR * 48 * C1;
 
 __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -432,8 +495,18 @@ __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
   bf16_t* ae = imgO + C1_IMG;                               // [4][C1_BR * 48][16]
   float* s_xn = reinterpret_cast<float*>(ae + 4 * C1_AE);   // [256]
   float* s_red = s_xn + 256;                                // [16 c][16]: 9 weights + 1 bias per channel
+  uint8_t* ibl = reinterpret_cast<uint8_t*>(s_red + 16 * 16);  // [C1_BR][48][16] recomputed pool winners of the band
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
   const int q4 = li >> 2, p4 = li & 3;
+  const bool rc = p.i1 == nullptr;
+  static_assert(C1_XS == RS0, "conv1_rows reads the image with row stride RS0");
+  s16x8 bq[12];
+  float bias1 = 0.f;
+  if (rc) {
+#pragma unroll
+    for (int q = 0; q < 12; ++q) bq[q] = conv1_bfrag(p.w1, q, g, li);
+    bias1 = p.b1[li];
+  }
   zero_lds(smem, 2 * C1_IMG * 2, tid);
   f32x4 acc[4];
 #pragma unroll
@@ -465,14 +538,19 @@ __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
         }
     }
     const bf16_t* da = p.da1 + (long)n * HP * HP * C1;
-    const uint8_t* ix = p.i1 + (long)n * HP * HP * C1;
+    const uint8_t* ix = rc ? nullptr : p.i1 + (long)n * HP * HP * C1;
     for (int r0 = 0; r0 < HP; r0 += C1_BR) {
+      if (rc) {  // conv1 again for the band's row pairs: only the pool winners are kept
+        __syncthreads();  // the image is complete (first band) / the previous band's bytes have been consumed
+        conv1_rows(imgE, [&](int q) { return bq[q]; }, bias1, r0, r0 + C1_BR, r0, nullptr, 0, 0, 0, ibl, wv, g, li);
+        __syncthreads();
+      }
       // ---- the band's gradients, split by window slot
       for (int q = tid; q < C1_BR * HP * 2; q += NT) {
         const int half = q & 1, pp = q >> 1;
         const long so = ((long)r0 * HP + pp) * C1 + 8 * half;
         const uint4 dv = *reinterpret_cast<const uint4*>(da + so);
-        const uint2 iv = *reinterpret_cast<const uint2*>(ix + so);
+        const uint2 iv = rc ? *reinterpret_cast<const uint2*>(ibl + pp * C1 + 8 * half) : *reinterpret_cast<const uint2*>(ix + so);
         const unsigned d[4] = {dv.x, dv.y, dv.z, dv.w};
         unsigned o[4][4];
 #pragma unroll
@@ -551,6 +629,16 @@ extern "C" int ss_c5_conv_wgrad(int layer, const uint16_t* a_in, const uint16_t*
   return SS_ERR_UNSUPPORTED;
 }
 
+// layer 2's weight gradient with its input recomputed from the frame (no a1 in HBM): R (N,96,96) u8, st (N,2) from the forward
+extern "C" int ss_c5_conv2_wgrad_rc(const uint8_t* R, const float* st, int standardize, const float* w1, const float* b1,
+                                    const uint16_t* da_out, const uint8_t* idx, int N, float* g_w, float* g_b, ss_stream_t stream) {
+  SS_REQUIRE(R && st && w1 && b1 && da_out && idx && g_w && g_b && N > 0, SS_ERR_ARG);
+  ConvBwdParams p{};
+  p.N = N; p.da_out = da_out; p.idx = idx; p.g_w = g_w; p.g_b = g_b; p.R = R; p.st = st; p.standardize = standardize; p.w1 = w1; p.b1 = b1;
+  return launch_persistent(conv_wgrad_kernel<C1, C2, 48, 48, false, 16, 1, 1, 8, true>, p, wgrad_lds<C1, C2, 48, 16, true>(), N,
+                           static_cast<hipStream_t>(stream));
+}
+
 extern "C" int ss_c5_conv_dgrad(int layer, const uint16_t* da_out, const uint8_t* idx, int N, const float* w, uint16_t* da_in,
                                 ss_stream_t stream) {
   SS_REQUIRE(da_out && idx && w && da_in && N > 0, SS_ERR_ARG);
@@ -586,8 +674,9 @@ extern "C" int ss_c5_conv_last_dgrad(const float* dz, int ld_dz, int E, const fl
 }
 
 extern "C" int ss_c5_conv1_wgrad(const uint8_t* R, int N, int standardize, const float* st, const uint16_t* da1, const uint8_t* i1,
-                                 float* g_w1, float* g_b1, ss_stream_t stream) {
-  SS_REQUIRE(R && st && da1 && i1 && g_w1 && g_b1 && N > 0, SS_ERR_ARG);
-  Conv1BwdParams p{R, N, standardize, st, da1, i1, g_w1, g_b1};
+                                 const float* w1, const float* b1, float* g_w1, float* g_b1, ss_stream_t stream) {
+  SS_REQUIRE(R && st && da1 && g_w1 && g_b1 && N > 0, SS_ERR_ARG);
+  SS_REQUIRE(i1 || (w1 && b1), SS_ERR_ARG);  // stored pool winners, or the conv1 parameters to recompute them
+  Conv1BwdParams p{R, N, standardize, st, da1, i1, w1, b1, g_w1, g_b1};
   return launch_persistent(conv1_wgrad_kernel, p, CONV1_WGRAD_LDS, N, static_cast<hipStream_t>(stream));
 }

@@ -3,8 +3,9 @@
 Same contract as ``engine.py`` (explicit forward / backward over raw device buffers, no aten compute op, no CPU
 fallback); what differs is the kernel set:
 
-    ROI CNN      ss_c5_conv1_fwd -> ss_c5_conv_fwd(2) -> ss_c5_conv_fwd(3) -> ss_c5_conv_last_fwd   (cnn_bf16.hip)
-                 pooled maps between the layers: NHWC bf16 in HBM + one argmax byte per element (the training stash)
+    ROI CNN      ss_c5_conv12_fwd (conv1 + conv2 fused) -> ss_c5_conv_fwd(3) -> ss_c5_conv_last_fwd   (cnn_bf16.hip)
+                 pooled maps a2, a3 between the layers: NHWC bf16 in HBM + one argmax byte per element (the training stash);
+                 the pooled conv1 map stays in LDS and is recomputed from the frame by the backward kernels that need it
     GRU layers   ss_gemm_bf16_batched (input projections, d layer_in, weight gradients) + ss_gru_bf16_fwd / _bwd
                  (one launch per time step, both directions; W_hh as bf16 copies made once per step by ss_gru_bf16_prep)
     tail         the f32 fused AttnPool / head / CE kernels of the f32 path (0.1 % of the FLOPs)
@@ -95,8 +96,7 @@ class WorkspaceBf16:
         self.mid = torch.empty(B, cfg.head_mid, **f32)
         if cfg.use_roi:
             c1, c2, c3, c4 = CNN_CHANNELS
-            self.a1 = torch.empty(N, 48, 48, c1, **i16)
-            self.i1 = torch.empty(N, 48, 48, c1, **u8)
+            # (the pooled conv1 map never reaches HBM: conv1 lands in conv2's LDS image and is recomputed in the backward pass)
             self.a2 = torch.empty(N, 24, 24, c2, **i16)
             self.i2 = torch.empty(N, 24, 24, c2, **u8)
             self.a3 = torch.empty(N, 12, 12, c3, **i16)
@@ -136,9 +136,8 @@ def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
             L.call("ss_copy_rows_f32", X.data_ptr(), cfg.x_dim, ws.Z.data_ptr(), cfg.in_dim, N, cfg.x_dim, s)
         w = [P[k + ".weight"].data_ptr() for k in _CONV]
         b = [P[k + ".bias"].data_ptr() for k in _CONV]
-        L.call("ss_c5_conv1_fwd", R.data_ptr(), N, int(cfg.roi_standardize), w[0], b[0], ws.a1.data_ptr(), ws.i1.data_ptr(),
+        L.call("ss_c5_conv12_fwd", R.data_ptr(), N, int(cfg.roi_standardize), w[0], b[0], w[1], b[1], ws.a2.data_ptr(), ws.i2.data_ptr(),
                ws.st.data_ptr() if stash else None, s)
-        L.call("ss_c5_conv_fwd", 2, ws.a1.data_ptr(), N, w[1], b[1], ws.a2.data_ptr(), ws.i2.data_ptr(), s, tag="ss_c5_conv2_fwd")
         L.call("ss_c5_conv_fwd", 3, ws.a2.data_ptr(), N, w[2], b[2], ws.a3.data_ptr(), ws.i3.data_ptr(), s, tag="ss_c5_conv3_fwd")
         L.call("ss_c5_conv_last_fwd", ws.a3.data_ptr(), N, w[3], b[3], P["roi_cnn.fc.weight"].data_ptr(), P["roi_cnn.fc.bias"].data_ptr(),
                cfg.roi_emb, _addr(ws.Z, cfg.x_dim), cfg.in_dim, ws.m4.data_ptr() if stash else None,
@@ -271,9 +270,11 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         L.call("ss_c5_conv_last_dgrad", dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), N, w[3], ws.da3.data_ptr(), s)
         L.call("ss_c5_conv_wgrad", 3, ws.a2.data_ptr(), ws.da3.data_ptr(), ws.i3.data_ptr(), N, gw[2], gb[2], s, tag="ss_c5_conv3_wgrad")
         L.call("ss_c5_conv_dgrad", 3, ws.da3.data_ptr(), ws.i3.data_ptr(), N, w[2], ws.da2.data_ptr(), s, tag="ss_c5_conv3_dgrad")
-        L.call("ss_c5_conv_wgrad", 2, ws.a1.data_ptr(), ws.da2.data_ptr(), ws.i2.data_ptr(), N, gw[1], gb[1], s, tag="ss_c5_conv2_wgrad")
+        bb = [P[k + ".bias"].data_ptr() for k in _CONV]
+        L.call("ss_c5_conv2_wgrad_rc", R.data_ptr(), ws.st.data_ptr(), int(cfg.roi_standardize), w[0], bb[0], ws.da2.data_ptr(),
+               ws.i2.data_ptr(), N, gw[1], gb[1], s)
         L.call("ss_c5_conv_dgrad", 2, ws.da2.data_ptr(), ws.i2.data_ptr(), N, w[1], ws.da1.data_ptr(), s, tag="ss_c5_conv2_dgrad")
-        L.call("ss_c5_conv1_wgrad", R.data_ptr(), N, int(cfg.roi_standardize), ws.st.data_ptr(), ws.da1.data_ptr(), ws.i1.data_ptr(),
+        L.call("ss_c5_conv1_wgrad", R.data_ptr(), N, int(cfg.roi_standardize), ws.st.data_ptr(), ws.da1.data_ptr(), None, w[0], bb[0],
                gw[0], gb[0], s)
     if USE_SIDE_STREAM:  # the caller's next kernels (all-reduce, clip, Adam) read every gradient
         ws.ev_join.record(ws.side)

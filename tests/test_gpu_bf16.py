@@ -393,8 +393,76 @@ def test_c5_conv1_wgrad(L, N):
     gw = torch.zeros(16, 1, 3, 3, device="cuda")
     gb = torch.zeros(16, device="cuda")
     R_d, da_d, idx_d = R.cuda(), nhwc_bf16(da), idx.permute(0, 2, 3, 1).contiguous().cuda()
-    L.call("ss_c5_conv1_wgrad", R_d.data_ptr(), N, 1, st.data_ptr(), da_d.data_ptr(), idx_d.data_ptr(), gw.data_ptr(), gb.data_ptr(),
-           L.stream())
+    L.call("ss_c5_conv1_wgrad", R_d.data_ptr(), N, 1, st.data_ptr(), da_d.data_ptr(), idx_d.data_ptr(), None, None, gw.data_ptr(),
+           gb.data_ptr(), L.stream())
     torch.cuda.synchronize()
     assert float((gw.cpu() - gw_ref).abs().max()) < 2e-4 * float(gw_ref.abs().max())
     assert float((gb.cpu() - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
+
+
+@pytest.mark.parametrize("N", [3, 300])
+def test_c5_conv12_fused_forward_and_recomputing_backward(L, N):
+    """The fused forms the engine runs: conv1 + conv2 in one kernel (the pooled conv1 map stays in LDS), layer 2's weight gradient
+    with that map recomputed from the frame, conv1's weight gradient with its pool winners recomputed -- against the same
+    references as the per-layer kernels."""
+    g = torch.Generator().manual_seed(N + 3)
+    R = torch.randint(0, 256, (N, 96, 96), generator=g, dtype=torch.uint8)
+    R[0] = 30
+    w1 = torch.randn(16, 1, 3, 3, generator=g) * 0.4
+    b1 = torch.randn(16, generator=g) * 0.2
+    w2 = torch.randn(32, 16, 3, 3, generator=g) / 12.0
+    b2 = torch.randn(32, generator=g) * 0.1
+    xn, mu, sd = normalise_like_kernel(R)
+    c1 = F.conv2d(bf(xn).unsqueeze(1).double(), bf(w1).double(), padding=1).float()
+    a1, i1, gap1 = pool_ref(c1, b1)
+    a1 = bf(a1)
+    c2 = F.conv2d(a1.double(), bf(w2).double(), padding=1).float()
+    a2, i2, gap2 = pool_ref(c2, b2)
+    R_d, w1_d, b1_d, w2_d, b2_d = R.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda()
+    a2_d = torch.empty(N, 24, 24, 32, device="cuda", dtype=torch.int16)
+    i2_d = torch.empty(N, 24, 24, 32, device="cuda", dtype=torch.uint8)
+    st = torch.empty(N, 2, device="cuda")
+    L.call("ss_c5_conv12_fwd", R_d.data_ptr(), N, 1, w1_d.data_ptr(), b1_d.data_ptr(), w2_d.data_ptr(), b2_d.data_ptr(), a2_d.data_ptr(),
+           i2_d.data_ptr(), st.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(st[:, 0].cpu(), mu) and torch.equal(st[:, 1].cpu(), sd)
+    # a rounding flip of a conv1 output (1 bf16 ulp) moves the conv2 sums by ~1e-3 of their size: looser than the per-layer test
+    got = from_nhwc(a2_d)
+    err = (got - a2).abs()
+    assert bool((err <= 2.0 ** -6 * a2.abs() + 2e-3 * float(a2.abs().max())).all()), float(err.max())
+    sure = (gap2 > 2e-2) & ((a2 > 2e-2) | (a2 == 0))
+    assert (i2_d.cpu().permute(0, 3, 1, 2)[sure] != i2[sure]).float().mean() < 1e-3
+
+    # ---- layer 2's weight gradient from recomputed a1
+    da2 = bf(torch.randn(N, 32, 24, 24, generator=g))
+    idx2 = torch.randint(0, 5, (N, 32, 24, 24), generator=g).to(torch.uint8)
+    dy2 = expand_ref(da2, idx2)
+    gw_ref = torch.nn.grad.conv2d_weight(a1.double(), w2.shape, dy2.double(), padding=1).float()
+    gb_ref = dy2.double().sum(dim=(0, 2, 3)).float()
+    da2_d, idx2_d = nhwc_bf16(da2), idx2.permute(0, 2, 3, 1).contiguous().cuda()
+    gw = torch.zeros(32, 16, 3, 3, device="cuda")
+    gb = torch.zeros(32, device="cuda")
+    L.call("ss_c5_conv2_wgrad_rc", R_d.data_ptr(), st.data_ptr(), 1, w1_d.data_ptr(), b1_d.data_ptr(), da2_d.data_ptr(), idx2_d.data_ptr(),
+           N, gw.data_ptr(), gb.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert float((gw.cpu() - gw_ref).abs().max()) < 1e-3 * float(gw_ref.abs().max())
+    assert float((gb.cpu() - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
+
+    # ---- conv1's weight gradient with recomputed pool winners
+    da1 = bf(torch.randn(N, 16, 48, 48, generator=g))
+    dy1 = expand_ref(da1, i1)
+    # where conv1's winner is nearly tied the recomputation may pick the other slot: compare where it is clear
+    win1 = c1.reshape(N, 16, 48, 2, 48, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, 16, 48, 48, 4)
+    pre1 = win1.max(dim=-1).values + b1.view(1, -1, 1, 1)      # pooled value before the ReLU
+    clear = (pre1 < -1e-3) | ((pre1 > 1e-3) & (gap1 > 1e-3))    # dead in both, or alive with an unambiguous winner
+    dy1 = dy1 * clear.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    da1c = da1 * clear
+    g1_ref = torch.nn.grad.conv2d_weight(bf(xn).unsqueeze(1).double(), (16, 1, 3, 3), dy1.double(), padding=1).float()
+    da1_d = nhwc_bf16(da1c)
+    g1 = torch.zeros(16, 1, 3, 3, device="cuda")
+    gb1 = torch.zeros(16, device="cuda")
+    L.call("ss_c5_conv1_wgrad", R_d.data_ptr(), N, 1, st.data_ptr(), da1_d.data_ptr(), None, w1_d.data_ptr(), b1_d.data_ptr(), g1.data_ptr(),
+           gb1.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert float((g1.cpu() - g1_ref).abs().max()) < 3e-4 * float(g1_ref.abs().max())
+    assert float((gb1.cpu() - dy1.double().sum(dim=(0, 2, 3)).float()).abs().max()) < 3e-4 * float(gb1.abs().max())
