@@ -250,22 +250,10 @@ int ss_gru_bf16_prep(const float* w_hh_f, const float* w_hh_r, int H, uint16_t* 
                      ss_stream_t stream);
 int ss_gru_bf16_ws_bytes(int B, int H, long* bytes);
 int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const float* b_hh_f, const float* b_hh_r,
-                    const int32_t* lengths, int B, int T, int H, float* out, float* save, uint16_t* out_bf16, void* ws,
-                    ss_stream_t stream);
+                    const int32_t* lengths, int B, int T, int H, float* out, float* save, void* ws, ss_stream_t stream);
 int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, const uint16_t* whh_t_bf16,
-                    const int32_t* lengths, int B, int T, int H, float* d_g, uint16_t* d_g_bf16, float drop_p, uint64_t seed,
+                    const int32_t* lengths, int B, int T, int H, float* d_g, float drop_p, uint64_t seed,
                     uint64_t offset, void* ws, ss_stream_t stream);
-/* out_bf16 (N,2H) / d_g_bf16 (2,N,4,H), each may be NULL: bf16 copies of out / d_g written by the step kernels for the GEMMs that
- * take them as operands (ss_gemm_bf16_batched_ex with a_is_bf16 / b_is_bf16): those GEMMs are bound by their operand bytes.
- * ss_dropout_bf16: y_bf16 = bf16(dropout(x)) on the ss_dropout stream (p = 0: a cast) -- nn.GRU's inter-layer dropout straight
- *   into the operand of the next layer's GEMMs; n % 4 == 0.
- * ss_gemm_bf16_batched_ex: ss_gemm_bf16_batched with operands that already are bf16 in HBM (built: A f32 / B f32, A bf16 / B f32,
- *   A bf16 / B bf16; ld and strides in elements). */
-int ss_dropout_bf16(const float* x, uint16_t* y_bf16, long n, float p, uint64_t seed, uint64_t offset, ss_stream_t stream);
-int ss_gemm_bf16_batched_ex(int a_kcontig, int b_kcontig, int a_is_bf16, int b_is_bf16, int M, int N, int K, const void* A, int lda,
-                            int a_group, int a_gstride, int a_off, const void* B, int ldb, int b_group, int b_gstride, int b_off,
-                            float* C, int ldc, const float* bias, int flags, int splits, int batch, long stride_a, long stride_b,
-                            long stride_c, long stride_bias, ss_stream_t stream);
 
 /* bf16 ROI-CNN of config 5: 96x96 uint8 frame -> normalise -> [conv3x3 + ReLU + maxpool2] x 3 (1->16->32->64) ->
  * conv3x3 64->96 + ReLU -> global average -> Linear(96 -> E): TinyROICNN (train_model_official.py:209-229) with a fourth

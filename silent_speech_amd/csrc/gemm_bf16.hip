@@ -21,8 +21,8 @@ constexpr int TILE_ELEMS = (BM * LDK > BK * LDR) ? BM * LDK : BK * LDR;
 
 struct GemmBfParams {
   int M, N, K;
-  const void* A; int lda, a_group, a_gstride, a_off;   // f32 or bf16 elements (template)
-  const void* B; int ldb, b_group, b_gstride, b_off;
+  const float* A; int lda, a_group, a_gstride, a_off;
+  const float* B; int ldb, b_group, b_gstride, b_off;
   float* C; int ldc;
   const float* bias;
   int flags, splits;
@@ -36,47 +36,42 @@ __device__ __forceinline__ long remap_row(int r, int group, int gstride, int off
 // One operand tile (128 rows x 32 k) from HBM into 4 float4 registers per thread.
 // KC = 1: storage [row][k]: thread -> (row = idx / 8, k = 4 (idx % 8)), idx = tid + 256 i.
 // KC = 0: storage [k][row]: thread -> (k = idx / 32, row = 4 (idx % 32)).
-// BF = 1: the operand already is bf16 in HBM (a copy its producer wrote): 8-byte loads, no conversion -- half the bytes of the
-// f32 form, and the GRU-layer GEMMs are bound by exactly those bytes (128 x 128 x 32 tiles of f32 operands: 32 FLOP per byte)
-template <int KC, int BF>
-struct TileRegs {
-  f32x4 f[BF ? 1 : 4];
-  uint2 h[BF ? 4 : 1];
-  __device__ __forceinline__ void load(const void* __restrict__ srcv, int ld, int group, int gstride, int off, int row0, int rows, int k0,
-                                       int k_end, int tid) {
+template <int KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int group, int gstride, int off, int row0, int rows,
+                                          int k0, int k_end, int tid, f32x4 v[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i;
-      long o = -1;
-      if (KC) {
-        const int r = row0 + (idx >> 3), k = k0 + 4 * (idx & 7);
-        if (r < rows && k < k_end) o = remap_row(r, group, gstride, off) * ld + k;
-      } else {
-        const int k = k0 + (idx >> 5), r = row0 + 4 * (idx & 31);
-        if (k < k_end && r < rows) o = remap_row(k, group, gstride, off) * ld + r;
-      }
-      if (BF) h[i] = o >= 0 ? *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(srcv) + o) : uint2{0u, 0u};
-      else f[i] = o >= 0 ? *reinterpret_cast<const f32x4*>(static_cast<const float*>(srcv) + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (KC) {
+      const int r = row0 + (idx >> 3), k = k0 + 4 * (idx & 7);
+      if (r < rows && k < k_end) x = *reinterpret_cast<const f32x4*>(src + remap_row(r, group, gstride, off) * ld + k);
+    } else {
+      const int k = k0 + (idx >> 5), r = row0 + 4 * (idx & 31);
+      if (k < k_end && r < rows) x = *reinterpret_cast<const f32x4*>(src + remap_row(k, group, gstride, off) * ld + r);
     }
+    v[i] = x;
   }
-  __device__ __forceinline__ void store(bf16_t* tile, int tid) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i;
-      bf16_t* dst = KC ? tile + (idx >> 3) * LDK + 4 * (idx & 7) : tile + (idx >> 5) * LDR + 4 * (idx & 31);
-      *reinterpret_cast<uint2*>(dst) = BF ? h[i] : pack_bf16x4(f[i][0], f[i][1], f[i][2], f[i][3]);
-    }
-  }
-};
+}
 
-template <int AKC, int BKC, int ABF, int BBF>
+template <int KC>
+__device__ __forceinline__ void store_tile(bf16_t* tile, int tid, const f32x4 v[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    bf16_t* dst = KC ? tile + (idx >> 3) * LDK + 4 * (idx & 7) : tile + (idx >> 5) * LDR + 4 * (idx & 31);
+    *reinterpret_cast<uint2*>(dst) = pack_bf16x4(v[i][0], v[i][1], v[i][2], v[i][3]);
+  }
+}
+
+template <int AKC, int BKC>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // A0 B0 A1 B1
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int batch = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
-  const void* A = static_cast<const char*>(p.A) + batch * p.sa * (ABF ? 2 : 4);
-  const void* B = static_cast<const char*>(p.B) + batch * p.sb * (BBF ? 2 : 4);
+  const float* A = p.A + batch * p.sa;
+  const float* B = p.B + batch * p.sb;
   float* C = p.C + batch * p.sc;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   // K range of this split, in whole k tiles
@@ -92,12 +87,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (kt0 < kt1) {
-    TileRegs<AKC, ABF> va;
-    TileRegs<BKC, BBF> vb;
-    va.load(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, kt0 * BK, p.K, tid);
-    vb.load(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, kt0 * BK, p.K, tid);
-    va.store(lds, tid);
-    vb.store(lds + TILE_ELEMS, tid);
+    f32x4 va[4], vb[4];
+    load_tile<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, kt0 * BK, p.K, tid, va);
+    load_tile<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, kt0 * BK, p.K, tid, vb);
+    store_tile<AKC>(lds, tid, va);
+    store_tile<BKC>(lds + TILE_ELEMS, tid, vb);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
       const int cur = (kt - kt0) & 1;
@@ -105,8 +99,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
       const bf16_t* Bs = lds + (2 * cur + 1) * TILE_ELEMS;
       const bool more = kt + 1 < kt1;
       if (more) {
-        va.load(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, (kt + 1) * BK, p.K, tid);
-        vb.load(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, (kt + 1) * BK, p.K, tid);
+        load_tile<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, (kt + 1) * BK, p.K, tid, va);
+        load_tile<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, (kt + 1) * BK, p.K, tid, vb);
       }
       s16x8 fa[4], fb[4];
 #pragma unroll
@@ -119,8 +113,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
       if (more) {
-        va.store(lds + (2 * (cur ^ 1)) * TILE_ELEMS, tid);
-        vb.store(lds + (2 * (cur ^ 1) + 1) * TILE_ELEMS, tid);
+        store_tile<AKC>(lds + (2 * (cur ^ 1)) * TILE_ELEMS, tid, va);
+        store_tile<BKC>(lds + (2 * (cur ^ 1) + 1) * TILE_ELEMS, tid, vb);
       }
       __syncthreads();
     }
@@ -151,21 +145,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
 
 }  // namespace
 
-extern "C" int ss_gemm_bf16_batched_ex(int a_kcontig, int b_kcontig, int a_is_bf16, int b_is_bf16, int M, int N, int K, const void* A,
-                                       int lda, int a_group, int a_gstride, int a_off, const void* B, int ldb, int b_group,
-                                       int b_gstride, int b_off, float* C, int ldc, const float* bias, int flags, int splits, int batch,
-                                       long stride_a, long stride_b, long stride_c, long stride_bias, ss_stream_t stream) {
+extern "C" int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
+                                    int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
+                                    float* C, int ldc, const float* bias, int flags, int splits, int batch, long stride_a,
+                                    long stride_b, long stride_c, long stride_bias, ss_stream_t stream) {
   SS_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && splits > 0, SS_ERR_ARG);
   SS_REQUIRE(a_group > 0 && b_group > 0, SS_ERR_ARG);
   SS_REQUIRE(!(flags & ~5), SS_ERR_UNSUPPORTED);                 // bit0 accumulate, bit2 atomics
   SS_REQUIRE(splits == 1 || (flags & 1), SS_ERR_ARG);            // K slices add into a C the caller initialised
   SS_REQUIRE(!(flags & 4) || (flags & 1), SS_ERR_ARG);
-  SS_REQUIRE(!b_is_bf16 || a_is_bf16, SS_ERR_UNSUPPORTED);       // built: (f32, f32), (bf16, f32), (bf16, bf16)
-  // 16-byte (f32) / 8-byte (bf16) loads along the contiguous dimension of either layout
+  // 16-byte loads along the contiguous dimension of either layout
   SS_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && stride_a % 4 == 0 && stride_b % 4 == 0, SS_ERR_UNSUPPORTED);
   SS_REQUIRE((a_kcontig ? K : M) % 4 == 0 && (b_kcontig ? K : N) % 4 == 0, SS_ERR_UNSUPPORTED);
-  SS_REQUIRE((reinterpret_cast<uintptr_t>(A) & (a_is_bf16 ? 7 : 15)) == 0 && (reinterpret_cast<uintptr_t>(B) & (b_is_bf16 ? 7 : 15)) == 0,
-             SS_ERR_UNSUPPORTED);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0, SS_ERR_UNSUPPORTED);
   GemmBfParams p;
   p.M = M; p.N = N; p.K = K;
   p.A = A; p.lda = lda; p.a_group = a_group; p.a_gstride = a_gstride; p.a_off = a_off;
@@ -176,24 +168,9 @@ extern "C" int ss_gemm_bf16_batched_ex(int a_kcontig, int b_kcontig, int a_is_bf
   p.sa = stride_a; p.sb = stride_b; p.sc = stride_c; p.sbias = stride_bias;
   dim3 grid(ceil_div(N, BN), ceil_div(M, BM), batch * p.splits);
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define SS_GEMM_CASE(AK, BK_, AB, BB)                                                  \
-  if (!!a_kcontig == AK && !!b_kcontig == BK_ && !!a_is_bf16 == AB && !!b_is_bf16 == BB) { \
-    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, AB, BB>), grid, dim3(256), 0, s, p);  \
-    return ss_launch_status();                                                         \
-  }
-#define SS_GEMM_LAYOUTS(AB, BB) SS_GEMM_CASE(1, 1, AB, BB) SS_GEMM_CASE(1, 0, AB, BB) SS_GEMM_CASE(0, 1, AB, BB) SS_GEMM_CASE(0, 0, AB, BB)
-  SS_GEMM_LAYOUTS(0, 0)
-  SS_GEMM_LAYOUTS(1, 0)
-  SS_GEMM_LAYOUTS(1, 1)
-#undef SS_GEMM_LAYOUTS
-#undef SS_GEMM_CASE
-  return SS_ERR_UNSUPPORTED;
-}
-
-extern "C" int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
-                                    int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
-                                    float* C, int ldc, const float* bias, int flags, int splits, int batch, long stride_a,
-                                    long stride_b, long stride_c, long stride_bias, ss_stream_t stream) {
-  return ss_gemm_bf16_batched_ex(a_kcontig, b_kcontig, 0, 0, M, N, K, A, lda, a_group, a_gstride, a_off, B, ldb, b_group, b_gstride,
-                                 b_off, C, ldc, bias, flags, splits, batch, stride_a, stride_b, stride_c, stride_bias, stream);
+  if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, dim3(256), 0, s, p);
+  else if (a_kcontig) hipLaunchKernelGGL((gemm_bf16_kernel<1, 0>), grid, dim3(256), 0, s, p);
+  else if (b_kcontig) hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, dim3(256), 0, s, p);
+  return ss_launch_status();
 }

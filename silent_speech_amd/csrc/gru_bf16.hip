@@ -39,17 +39,6 @@ __global__ __launch_bounds__(256) void whh_prep_kernel(const float* __restrict__
     wtb[(long)dir * 3 * H * H + (long)(c0 + i) * 3 * H + r0 + tx] = to_bf16(tile[tx][i]);
 }
 
-// inter-layer dropout of nn.GRU (train_model_official.py:266) straight into the bf16 operand the next layer's GEMMs read: the
-// ss_dropout stream (one Philox counter per 4 elements), no f32 copy of the dropped-out tensor
-__global__ __launch_bounds__(256) void dropout_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long quads, float p,
-                                                           uint64_t seed, uint64_t offset) {
-  for (long q = blockIdx.x * 256L + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
-    f32x4 v = reinterpret_cast<const f32x4*>(x)[q];
-    if (p > 0.f) v *= drop_scale4(q, p, seed, offset);
-    reinterpret_cast<uint2*>(y)[q] = pack_bf16x4(v[0], v[1], v[2], v[3]);
-  }
-}
-
 struct StepFwdParams {
   const float* gi;        // (2, N, 3H) f32: W_ih x + b_ih
   const bf16_t* whh;      // (2, 3H, H) bf16
@@ -60,7 +49,6 @@ struct StepFwdParams {
   float* save;            // (2, N, 4, H) f32 or null
   const bf16_t* hb_in;    // (2, B, H) bf16 state after step s-1 (unused at s = 0)
   bf16_t* hb_out;         // (2, B, H)
-  bf16_t* out_b;          // (N, 2H) bf16 copy of out for the GEMMs that take it as an operand, or null
 };
 
 template <int H>
@@ -159,9 +147,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwdParams p) {
     }
   }
   *reinterpret_cast<f32x4*>(p.out + row * 2 * H + dir * H + u) = hn;
-  const uint2 hb16 = pack_bf16x4(hn[0], hn[1], hn[2], hn[3]);
-  *reinterpret_cast<uint2*>(p.hb_out + ((long)dir * B + bq) * H + u) = hb16;
-  if (p.out_b) *reinterpret_cast<uint2*>(p.out_b + row * 2 * H + dir * H + u) = hb16;
+  *reinterpret_cast<uint2*>(p.hb_out + ((long)dir * B + bq) * H + u) = pack_bf16x4(hn[0], hn[1], hn[2], hn[3]);
 }
 
 struct StepBwdParams {
@@ -172,7 +158,6 @@ struct StepBwdParams {
   const int* lengths;
   int B, T, H, s;
   float* dG;              // (2, N, 4, H) f32: d gi_r, d gi_z, d gi_n, d(W_hn h + b_hn)
-  bf16_t* dG_b;           // the same as bf16 (operand of the d layer_in / weight-gradient GEMMs), or null
   const bf16_t* dgh_in;   // (2, B, 3H) bf16: d gh_r | d gh_z | d gh_n of step s-1
   bf16_t* dgh_out;
   float* dhz;             // (2, B, H) f32: the part of d h carried on without passing W_hh (dh * z, or all of it past a clip's end)
@@ -269,19 +254,10 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwdParams p) {
   *reinterpret_cast<f32x4*>(dG + H + u) = dzp;
   *reinterpret_cast<f32x4*>(dG + 2 * H + u) = dnp;
   *reinterpret_cast<f32x4*>(dG + 3 * H + u) = dhn;
-  const uint2 b_r = pack_bf16x4(drp[0], drp[1], drp[2], drp[3]), b_z = pack_bf16x4(dzp[0], dzp[1], dzp[2], dzp[3]),
-              b_n = pack_bf16x4(dnp[0], dnp[1], dnp[2], dnp[3]), b_h = pack_bf16x4(dhn[0], dhn[1], dhn[2], dhn[3]);
   bf16_t* dgo = p.dgh_out + ((long)dir * B + bq) * 3 * H;
-  *reinterpret_cast<uint2*>(dgo + u) = b_r;
-  *reinterpret_cast<uint2*>(dgo + H + u) = b_z;
-  *reinterpret_cast<uint2*>(dgo + 2 * H + u) = b_h;
-  if (p.dG_b) {
-    bf16_t* db = p.dG_b + ((long)dir * N + row) * 4 * H;
-    *reinterpret_cast<uint2*>(db + u) = b_r;
-    *reinterpret_cast<uint2*>(db + H + u) = b_z;
-    *reinterpret_cast<uint2*>(db + 2 * H + u) = b_n;
-    *reinterpret_cast<uint2*>(db + 3 * H + u) = b_h;
-  }
+  *reinterpret_cast<uint2*>(dgo + u) = pack_bf16x4(drp[0], drp[1], drp[2], drp[3]);
+  *reinterpret_cast<uint2*>(dgo + H + u) = pack_bf16x4(dzp[0], dzp[1], dzp[2], dzp[3]);
+  *reinterpret_cast<uint2*>(dgo + 2 * H + u) = pack_bf16x4(dhn[0], dhn[1], dhn[2], dhn[3]);
   *reinterpret_cast<f32x4*>(dhz) = keep;
 }
 
@@ -320,16 +296,6 @@ extern "C" int ss_gru_bf16_prep(const float* w_hh_f, const float* w_hh_r, int H,
   return ss_launch_status();
 }
 
-extern "C" int ss_dropout_bf16(const float* x, uint16_t* y_bf16, long n, float p, uint64_t seed, uint64_t offset, ss_stream_t stream) {
-  SS_REQUIRE(x && y_bf16 && n > 0 && (n & 3) == 0 && p >= 0.f && p < 1.f, SS_ERR_ARG);
-  const long quads = n / 4;
-  int blocks = (int)((quads + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, y_bf16, quads, p, seed,
-                     offset);
-  return ss_launch_status();
-}
-
 extern "C" int ss_gru_bf16_ws_bytes(int B, int H, long* bytes) {
   SS_REQUIRE(bytes && B > 0 && H > 0, SS_ERR_ARG);
   // two state slots (2,B,H) bf16, two gate-gradient slots (2,B,3H) bf16, one (2,B,H) f32 carry
@@ -339,13 +305,13 @@ extern "C" int ss_gru_bf16_ws_bytes(int B, int H, long* bytes) {
 
 // All T steps of one layer, both directions (T launches on ``stream``).
 extern "C" int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const float* b_hh_f, const float* b_hh_r,
-                               const int32_t* lengths, int B, int T, int H, float* out, float* save, uint16_t* out_bf16, void* ws,
+                               const int32_t* lengths, int B, int T, int H, float* out, float* save, void* ws,
                                ss_stream_t stream) {
   SS_REQUIRE(gi && whh_bf16 && b_hh_f && b_hh_r && lengths && out && ws, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0 && H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);  // four waves x whole 32-deep k steps; built: 128..512, 1024
   StepFwdParams p;
   p.gi = gi; p.whh = whh_bf16; p.bhh_f = b_hh_f; p.bhh_r = b_hh_r; p.lengths = lengths;
-  p.B = B; p.T = T; p.H = H; p.out = out; p.save = save; p.out_b = out_bf16;
+  p.B = B; p.T = T; p.H = H; p.out = out; p.save = save;
   bf16_t* hb = static_cast<bf16_t*>(ws);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {
@@ -360,14 +326,14 @@ extern "C" int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const 
 }
 
 extern "C" int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, const uint16_t* whh_t_bf16,
-                               const int32_t* lengths, int B, int T, int H, float* d_g, uint16_t* d_g_bf16, float drop_p,
-                               uint64_t seed, uint64_t offset, void* ws, ss_stream_t stream) {
+                               const int32_t* lengths, int B, int T, int H, float* d_g, float drop_p, uint64_t seed,
+                               uint64_t offset, void* ws, ss_stream_t stream) {
   SS_REQUIRE(d_out && out && save && whh_t_bf16 && lengths && d_g && ws, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
   SS_REQUIRE(H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);
   StepBwdParams p;
   p.d_out = d_out; p.out = out; p.save = save; p.whht = whh_t_bf16; p.lengths = lengths;
-  p.B = B; p.T = T; p.H = H; p.dG = d_g; p.dG_b = d_g_bf16; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
+  p.B = B; p.T = T; p.H = H; p.dG = d_g; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
   bf16_t* base = static_cast<bf16_t*>(ws) + 2L * 2 * B * H;  // behind the two forward state slots
   const long slot = 2L * B * 3 * H;
   p.dhz = reinterpret_cast<float*>(base + 2 * slot);

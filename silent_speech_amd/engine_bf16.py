@@ -30,11 +30,10 @@ _IDENT = (INT_MAX, 0, 0)
 
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, atomic=False, splits=1, a_map=_IDENT,
-         b_map=_IDENT, batch=1, strides=(0, 0, 0, 0), tag="gemm_bf16", a_bf16=False, b_bf16=False):
-    """``a_bf16`` / ``b_bf16``: the operand is a bf16 copy in HBM (ld and strides in elements either way)."""
+         b_map=_IDENT, batch=1, strides=(0, 0, 0, 0), tag="gemm_bf16"):
     flags = (1 if accumulate else 0) | (4 if atomic else 0)
-    L.call("ss_gemm_bf16_batched_ex", int(a_kc), int(b_kc), int(a_bf16), int(b_bf16), M, N, K, A, lda, *a_map, B, ldb, *b_map, Cm, ldc,
-           bias, flags, splits, batch, *strides, L.stream(), tag=tag)
+    L.call("ss_gemm_bf16_batched", int(a_kc), int(b_kc), M, N, K, A, lda, *a_map, B, ldb, *b_map, Cm, ldc, bias, flags, splits,
+           batch, *strides, L.stream(), tag=tag)
 
 
 def split_k(M, N, K, batch, target_wgs=768):
@@ -83,10 +82,7 @@ class WorkspaceBf16:
         self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
         self.gi = [torch.empty(2, N, 3 * H, **f32) for _ in range(cfg.gru_layers)]
         self.out = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers)]
-        # bf16 copies of what the GEMMs read as operands (they are bound by operand bytes): layer outputs (written by the step
-        # kernels), the dropped-out layer-0 output (ss_dropout_bf16: no f32 copy of it exists) and, for training, the gate gradients
-        self.out_b = [torch.empty(N, 2 * H, **i16) for _ in range(cfg.gru_layers)]
-        self.out_drop_b = [torch.empty(N, 2 * H, **i16) for _ in range(cfg.gru_layers - 1)]
+        self.out_drop = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers - 1)]
         self.whh = [torch.empty(2, 3 * H, H, **i16) for _ in range(cfg.gru_layers)]
         self.whht = [torch.empty(2, H, 3 * H, **i16) for _ in range(cfg.gru_layers)]
         nb = C.c_long(0)
@@ -108,7 +104,6 @@ class WorkspaceBf16:
         if train:
             self.save = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
             self.dG = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
-            self.dG_b = [torch.empty(2, N, 4, H, **i16) for _ in range(cfg.gru_layers)]
             self.d_out = torch.empty(N, 2 * H, **f32)
             self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
             self.xhat = torch.empty(B, 2 * H, **f32)
@@ -150,7 +145,6 @@ def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
         layer_in, ld_in = ws.Z.data_ptr(), cfg.in_dim
     else:
         layer_in, ld_in = X.data_ptr(), cfg.x_dim
-    in_bf16 = False
     for l in range(cfg.gru_layers):
         K = cfg.in_dim if l == 0 else 2 * H
         wf, wr = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
@@ -158,14 +152,15 @@ def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
                ws.whh[l].data_ptr(), ws.whht[l].data_ptr(), s)
         gemm(1, 1, N, 3 * H, K, layer_in, ld_in, P[wf].data_ptr(), K, ws.gi[l].data_ptr(), 3 * H, bias=P[f"gru.bias_ih_l{l}"].data_ptr(),
              batch=2, strides=(0, _pstride(P, wf, wr), N * 3 * H, _pstride(P, f"gru.bias_ih_l{l}", f"gru.bias_ih_l{l}_reverse")),
-             tag="gemm_bf16_ih", a_bf16=in_bf16)
+             tag="gemm_bf16_ih")
         L.call("ss_gru_bf16_fwd", ws.gi[l].data_ptr(), ws.whh[l].data_ptr(), P[f"gru.bias_hh_l{l}"].data_ptr(),
                P[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.lengths.data_ptr(), B, T, H, ws.out[l].data_ptr(),
-               ws.save[l].data_ptr() if stash else None, ws.out_b[l].data_ptr(), ws.gru_ws.data_ptr(), s)
-        layer_in, ld_in, in_bf16 = ws.out_b[l].data_ptr(), 2 * H, True
+               ws.save[l].data_ptr() if stash else None, ws.gru_ws.data_ptr(), s)
+        layer_in, ld_in = ws.out[l].data_ptr(), 2 * H
         if train and l < cfg.gru_layers - 1 and cfg.gru_dropout > 0.0:
-            L.call("ss_dropout_bf16", ws.out[l].data_ptr(), ws.out_drop_b[l].data_ptr(), N * 2 * H, cfg.gru_dropout, seed, (l + 1) << 40, s)
-            layer_in = ws.out_drop_b[l].data_ptr()
+            L.call("ss_dropout", ws.out[l].data_ptr(), ws.out_drop[l].data_ptr(), N * 2 * H, cfg.gru_dropout, seed, (l + 1) << 40,
+                   None, s)
+            layer_in = ws.out_drop[l].data_ptr()
     top = ws.out[cfg.gru_layers - 1]
     p_drop = cfg.head_dropout if train else 0.0
     y_ptr, ls, denom, loss_ptr, correct_ptr = ce if ce is not None else (None, 0.0, 1.0, None, None)
@@ -210,24 +205,22 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         top_layer = l == cfg.gru_layers - 1
         g_in = ws.d_out if top_layer else ws.d_lower[l + 1]
         L.call("ss_gru_bf16_bwd", g_in.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(), ws.whht[l].data_ptr(),
-               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), ws.dG_b[l].data_ptr(),
-               0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed, (l + 1) << 40, ws.gru_ws.data_ptr(), s)
+               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), 0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed,
+               (l + 1) << 40, ws.gru_ws.data_ptr(), s)
         if l == 0:
-            lin, ld_in, lin_bf16 = ((ws.Z.data_ptr(), cfg.in_dim) if cfg.use_roi else (X.data_ptr(), cfg.x_dim)) + (False,)
+            lin, ld_in = (ws.Z.data_ptr(), cfg.in_dim) if cfg.use_roi else (X.data_ptr(), cfg.x_dim)
         else:
-            lin, ld_in, lin_bf16 = (ws.out_drop_b[l - 1] if use_drop else ws.out_b[l - 1]).data_ptr(), 2 * H, True
+            lin, ld_in = (ws.out_drop[l - 1] if use_drop else ws.out[l - 1]).data_ptr(), 2 * H
         dg = ws.dG[l].data_ptr()
-        dgb = ws.dG_b[l].data_ptr()  # the GEMMs below read the bf16 copy (element offsets and strides are the same)
         wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
 
-        def param_grads(l=l, K=K, lin=lin, ld_in=ld_in, lin_bf16=lin_bf16, dg=dg, dgb=dgb, wi=wi, wir=wir):
+        def param_grads(l=l, K=K, lin=lin, ld_in=ld_in, dg=dg, wi=wi, wir=wir):
             # ---- bias gradients: column sums of d_g (r | z | n | hn), both directions in one launch
             L.call("ss_gru_bias_grad", dg, N, H, G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
                    G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.stream())
             # ---- weight gradients: d W_ih = dGi^T . layer_in;  d W_hh = dGh^T . h_prev (rows r|z from columns [0,2H), rows n from [3H,4H))
-            gemm(0, 0, 3 * H, K, N, dgb, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
-                 splits=split_k(3 * H, K, N, 2), batch=2, strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0), tag="gemm_bf16_dW",
-                 a_bf16=True, b_bf16=lin_bf16)
+            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
+                 splits=split_k(3 * H, K, N, 2), batch=2, strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0), tag="gemm_bf16_dW")
             if T > 1:
                 wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
                 Kh = B * (T - 1)
@@ -235,13 +228,11 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
                 # forward direction pairs dG[b][t] with out[b][t-1]; the reverse direction dG[b][t] with out[b][t+1]: the same
                 # pairing seen from one row earlier in dG and one row later in out (two pointer shifts = the batch strides)
                 sa, sb, sc = N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr)
-                hp = ws.out_b[l].data_ptr()
-                gemm(0, 0, 2 * H, H, Kh, dgb, 4 * H, hp, 2 * H, G[wh].data_ptr(), H, accumulate=True, atomic=True,
-                     splits=split_k(2 * H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW",
-                     a_bf16=True, b_bf16=True)
-                gemm(0, 0, H, H, Kh, dgb + 3 * H * 2, 4 * H, hp, 2 * H, _addr(G[wh], 2 * H * H), H, accumulate=True, atomic=True,
-                     splits=split_k(H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW",
-                     a_bf16=True, b_bf16=True)
+                hp = ws.out[l].data_ptr()
+                gemm(0, 0, 2 * H, H, Kh, dg, 4 * H, hp, 2 * H, G[wh].data_ptr(), H, accumulate=True, atomic=True,
+                     splits=split_k(2 * H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
+                gemm(0, 0, H, H, Kh, dg + 3 * H * 4, 4 * H, hp, 2 * H, _addr(G[wh], 2 * H * H), H, accumulate=True, atomic=True,
+                     splits=split_k(H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
 
         # ---- d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r (both directions in one launch, float atomics into a cleared buffer):
         # on the critical path (the layer below / the CNN backward waits for it), so it goes first
@@ -257,8 +248,8 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
             else:
                 d_X.zero_()
                 dst, ld_dst, c0 = d_X.data_ptr(), cfg.x_dim, 0
-            gemm(1, 0, N, K - c0, 3 * H, dgb, 4 * H, _addr(P[wi], c0), K, dst, ld_dst, accumulate=True, atomic=True, batch=2,
-                 strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0), tag="gemm_bf16_dX", a_bf16=True)
+            gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(P[wi], c0), K, dst, ld_dst, accumulate=True, atomic=True, batch=2,
+                 strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0), tag="gemm_bf16_dX")
         if USE_SIDE_STREAM:
             ws.ev_fork.record()
             with torch.cuda.stream(ws.side):

@@ -47,38 +47,6 @@ def test_gemm_bf16_layouts(L, akc, bkc, M, N, K):
     assert err < 2e-4 * max(1.0, float(ref.abs().max())), err
 
 
-@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
-@pytest.mark.parametrize("abf,bbf", [(1, 0), (1, 1)])
-def test_gemm_bf16_sources_already_bf16(L, akc, bkc, abf, bbf):
-    """Operands that are bf16 in HBM (the copies the GRU step kernels write): same products as the f32-source form."""
-    M, N, K = 200, 148, 292
-    g = torch.Generator().manual_seed(akc * 8 + bkc * 4 + abf * 2 + bbf)
-    A = bf(torch.randn(M, K, generator=g))
-    B = bf(torch.randn(K, N, generator=g))
-    ref = (A.double() @ B.double()).float()
-    A_st = (A if akc else A.t()).contiguous()
-    B_st = (B.t() if bkc else B).contiguous()
-    A_d = (A_st.to(torch.bfloat16).view(torch.int16) if abf else A_st).cuda()
-    B_d = (B_st.to(torch.bfloat16).view(torch.int16) if bbf else B_st).cuda()
-    C = torch.zeros(M, N, device="cuda")
-    L.call("ss_gemm_bf16_batched_ex", akc, bkc, abf, bbf, M, N, K, A_d.data_ptr(), A_st.shape[1], INT_MAX, 0, 0, B_d.data_ptr(),
-           B_st.shape[1], INT_MAX, 0, 0, C.data_ptr(), N, None, 0, 1, 1, 0, 0, 0, 0, L.stream())
-    torch.cuda.synchronize()
-    assert float((C.cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max())
-
-
-def test_dropout_bf16_matches_the_f32_dropout_stream(L):
-    g = torch.Generator().manual_seed(2)
-    x = torch.randn(4096 * 5, generator=g).cuda()
-    y = torch.empty_like(x)
-    yb = torch.empty(x.numel(), device="cuda", dtype=torch.int16)
-    for p_ in (0.0, 0.1):
-        L.call("ss_dropout", x.data_ptr(), y.data_ptr(), x.numel(), p_, 77, 3 << 40, None, L.stream())
-        L.call("ss_dropout_bf16", x.data_ptr(), yb.data_ptr(), x.numel(), p_, 77, 3 << 40, L.stream())
-        torch.cuda.synchronize()
-        assert torch.equal(yb.cpu().view(torch.bfloat16).float(), bf(y.cpu()))
-
-
 def test_gemm_bf16_batch_splitk_remap(L):
     """Two problems per launch (both GRU directions), K sliced over workgroups with float atomics into an initialised C,
     and the storage-row remap that pairs dG[b][t] with h[b][t-1] (group T-1 of stride T)."""
@@ -159,11 +127,9 @@ def test_gru_bf16_fwd_bwd(L, B, T, H):
     lens = lengths.to(torch.int32).cuda()
     out = torch.full((N, 2 * H), 9.0, device="cuda")
     save = torch.full((2, N, 4, H), 9.0, device="cuda")
-    out_b = torch.empty(N, 2 * H, device="cuda", dtype=torch.int16)
     L.call("ss_gru_bf16_fwd", gid.data_ptr(), wb.data_ptr(), b_f.data_ptr(), b_r.data_ptr(), lens.data_ptr(), B, T, H,
-           out.data_ptr(), save.data_ptr(), out_b.data_ptr(), ws.data_ptr(), L.stream())
+           out.data_ptr(), save.data_ptr(), ws.data_ptr(), L.stream())
     torch.cuda.synchronize()
-    assert torch.equal(out_b.cpu().view(torch.bfloat16).float(), bf(out.cpu()))
     err = float((out.cpu().view(B, T, 2 * H) - out_ref.detach()).abs().max())
     assert err < 2e-3, err  # bf16 rounding of the state decides differently only through v_exp/v_rcp noise: amplified by 1 bf16 ulp
     mask = (torch.arange(T)[None] < lengths[:, None]).float()[None, :, :, None, None]
@@ -172,11 +138,9 @@ def test_gru_bf16_fwd_bwd(L, B, T, H):
 
     dG = torch.full((2, N, 4, H), 9.0, device="cuda")
     d_out_d = dev(d_out.reshape(N, 2 * H))
-    dG_b = torch.empty(2, N, 4, H, device="cuda", dtype=torch.int16)
     L.call("ss_gru_bf16_bwd", d_out_d.data_ptr(), out.data_ptr(), save.data_ptr(), wtb.data_ptr(),
-           lens.data_ptr(), B, T, H, dG.data_ptr(), dG_b.data_ptr(), 0.0, 0, 0, ws.data_ptr(), L.stream())
+           lens.data_ptr(), B, T, H, dG.data_ptr(), 0.0, 0, 0, ws.data_ptr(), L.stream())
     torch.cuda.synchronize()
-    assert torch.equal(dG_b.cpu().view(torch.bfloat16).float(), bf(dG.cpu()))
     dGc = dG.cpu().view(2, B, T, 4, H)
     for d in range(2):
         ref = gi_l[d].grad.view(B, T, 3, H)   # d gi = (d r_pre, d z_pre, d n_pre)
