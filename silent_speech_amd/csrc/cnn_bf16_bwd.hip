@@ -136,8 +136,9 @@ __device__ __forceinline__ void last_dfeat(const ConvBwdParams& p, int n, float*
 // every WK-th 32-pixel k step
 // RC (layer 2 only): the layer's input a1 = pool(ReLU(conv1(frame))) is not read from HBM but recomputed per band from the 9 KB
 // uint8 frame (conv1 patch GEMM of cnn_bf16.hip: 12 MFMAs per row pair) -- it was the largest tensor of the net.
-template <int CIN, int COUT, int H, int W, bool LAST, int BH, int WCO, int WCI, int WK, bool RC = false>
-__global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(ConvBwdParams p) {
+// MINW: waves per SIMD the register allocation must allow (2 = one workgroup per CU, 4 = two)
+template <int CIN, int COUT, int H, int W, bool LAST, int BH, int WCO, int WCI, int WK, bool RC = false, int MINW = 2>
+__global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   static_assert(WCO * WCI * WK == NW && H % BH == 0, "wave split");
   static_assert(!RC || (CIN == C1 && H == 48 && W == 48 && !LAST), "recompute form: layer 2");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -604,13 +605,15 @@ __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
   }
 }
 
+// wgs_per_cu: workgroups the LDS footprint lets a CU hold; the grid is that many times the 256 CUs (a persistent workgroup walks
+// its share of the frames), so one workgroup's commit / barrier phases run under another's MFMAs
 template <class P, class K>
-int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s) {
-  if (lds_bytes > 160 * 1024) return SS_ERR_UNSUPPORTED;
+int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s, int wgs_per_cu = 1) {
+  if (lds_bytes > 160 * 1024 / wgs_per_cu) return SS_ERR_UNSUPPORTED;
   if (lds_bytes > 0 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
     return SS_ERR_LAUNCH;
-  const int grid = N < 256 ? N : 256;
+  const int grid = N < 256 * wgs_per_cu ? N : 256 * wgs_per_cu;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();
 }
@@ -645,8 +648,8 @@ extern "C" int ss_c5_conv_dgrad(int layer, const uint16_t* da_out, const uint8_t
   ConvBwdParams p{};
   p.N = N; p.da_out = da_out; p.idx = idx; p.w = w; p.da_in = da_in;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (layer == 2) return launch_persistent(conv_dgrad_kernel<C1, C2, 48, 48, false, 16, 12, true>, p, dgrad_lds<C1, C2, 48, 16, true>(), N, s);
-  if (layer == 3) return launch_persistent(conv_dgrad_kernel<C2, C3, 24, 24, false, 12, 9, true>, p, dgrad_lds<C2, C3, 24, 12, true>(), N, s);
+  if (layer == 2) return launch_persistent(conv_dgrad_kernel<C1, C2, 48, 48, false, 8, 6, true>, p, dgrad_lds<C1, C2, 48, 8, true>(), N, s, 2);
+  if (layer == 3) return launch_persistent(conv_dgrad_kernel<C2, C3, 24, 24, false, 4, 3, true>, p, dgrad_lds<C2, C3, 24, 4, true>(), N, s, 2);
   return SS_ERR_UNSUPPORTED;
 }
 

@@ -36,7 +36,15 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=Fal
            batch, *strides, L.stream(), tag=tag)
 
 
-def split_k(M, N, K, batch, target_wgs=768):
+import os
+
+# K slices of the weight-gradient GEMMs aim at this many workgroups (measured 192 / 384 / 768 / 1536: 6.10 / 6.09 / 6.17 / 6.33 ms
+# per step: the GEMMs run beside the BPTT steps on the side stream, fewer float atomics matter more than their own time)
+_SPLITK_TARGET = int(os.environ.get("SS_C5_SPLITK_TARGET", "384"))
+
+
+def split_k(M, N, K, batch, target_wgs=None):
+    target_wgs = target_wgs or _SPLITK_TARGET
     tiles = -(-M // 128) * -(-N // 128) * batch
     return max(1, min(-(-K // 32), target_wgs // tiles))
 
