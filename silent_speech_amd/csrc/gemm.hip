@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
   float asum = 0.f;  // column sums of the [k][row] A tile (bias gradient), thread t < BM owns row m0 + t
   const bool want_asum = (!A_KCONTIG) && p.asum && blockIdx.x == 0;
 
+  STAMP_ENTRY;
   STAMP_DECL;
   Stager<BM, A_KCONTIG> sa[KSUB];
   Stager<BN, B_KCONTIG> sb[KSUB];

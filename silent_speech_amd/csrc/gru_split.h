@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   const long dir_off = (long)dir * p.B * T;
   const rsrc_t hrs = granule_rsrc(hx, 2L * pairs * SLICE * H);
   bool dead = false;
+  STAMP_ENTRY;
   STAMP_DECL;
   for (int s = 0; s < T; ++s) {
     STAMP(15);
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
     }
   };
   load_inputs(0);
+  STAMP_ENTRY;
   STAMP_DECL;
   for (int s = 0; s < T; ++s) {
     STAMP(15);

@@ -73,6 +73,7 @@ struct FwdLds {
 
 template <class G>
 __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
+  STAMP_ENTRY;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = FwdLds<G>;
   constexpr int H = G::H, W = G::W, H2 = G::H2, W2 = G::W2, W4 = G::W4, HW = G::HW, P = G::P;

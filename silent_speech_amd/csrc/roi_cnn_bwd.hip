@@ -6,7 +6,8 @@
 // (pooled maps a1, a2, pool argmaxes, conv3 sign mask, averaged features: 67 KB for 64x64) plus the
 // 4 KB uint8 frame, and runs four MFMA contractions and one VALU gather out of LDS:
 //
-//   S1  dW3[n][c][tap] += sum_p dy3[n][p] * a2[c][p+tap]      M=n(24->32) N=c(16) per tap, K=pixels
+//   S1  dW3[n][c][tap] += sum_q dy3[n][q-tap] * a2[c][q]       M=(tap,n)=216->224 N=c(16) K=pixels: the tap shift sits in
+//                                                              the A operand, so 9 x 24 rows pack into 14 tiles (18 with M=n)
 //   S2  da2[c][p] = sum_{n,tap} dy3[n][p-tap] * W3[n][c][tap]  M=pixels N=c(16) K=(tap,n)=216
 //   T   dy2 (gradient before max-pool 2) expanded ONCE into a dense LDS image from da2 + 2-bit argmax
 //   S3  dW2[n][c][tap] += sum_x dy2[n][x] * a1[c][x+tap]       M=n(16) N=(tap,c)=72->80 K=pixels
@@ -44,7 +45,10 @@ struct BwdLds {
   // k-steps of an S4 tap are then ONE ds_read_b128 at (lane base + immediate): no address arithmetic, no edge selects
   static constexpr int W2H = G::W2 + 2;
   static constexpr int o_xh = o_ph + 16 * G::H2 * W2H;
-  static constexpr int XHN = (G::H + 2) * G::XS;
+  // row stride of the normalised frame == 8 (mod 32): S5's B operand -- 16 shifted views (ry, rx) x 4 k-steps 2g apart --
+  // then reads bank 8 ry + rx + 2g, conflict-free per 32 lanes (W + 2 put three rows on the same banks)
+  static constexpr int XSB = G::XS + (8 - G::XS % 32 + 32) % 32;
+  static constexpr int XHN = (G::H + 2) * XSB;
   static constexpr int o_i1b = (o_xh + XHN + 3) & ~3;
   static constexpr int end2 = (o_i1b + 2 * G::I1S + 3) & ~3;
   // W3 (13.8 KB) stays resident behind the phase area when the CU's 160 KB allow it; otherwise it lives in the
@@ -77,11 +81,62 @@ struct CnnBwdParams {
   float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *g_wfc, *g_bfc;
 };
 
+// S1's A rows are (tap, n) pairs: dW3[n][c][tap] = sum_q dy3[n][q - tap] * a2[c][q] with the B operand a2[c][q] shared by
+// every tap.  Two taps = 48 rows = three full tiles: tile 0 = (tap a, n 0..15), tile 1 = (tap a, n 16..23 | tap b, n 0..7),
+// tile 2 = (tap b, n 8..23); the ninth tap takes a full tile and a half-empty one.  The four k-quarter waves of each half of
+// the workgroup own taps {0..3} + (tap 8, n 0..15) resp. {4..7} + (tap 8, n 16..23): seven tiles either way.
+// dy3 is pixel-major [haloed pixel][24]: byte offset of tap (ky, kx) relative to the lane base at (y, x) of the haloed image
+template <int S2>
+__device__ constexpr int s1_off(int tap) { return ((2 - tap / 3) * S2 + (2 - tap % 3)) * 24; }
+
+template <class G, int HALF, class F>
+__device__ __forceinline__ void s1_rows(const float* dy3h, const float* a2h, int kg, int i, int g, f32x4 (&acc)[7], F&& on_row) {
+  constexpr int S2 = G::S2, W4 = G::W4, P2 = G::P2;
+  constexpr int rows = G::P / 4 / W4;  // whole rows of the pooled-2 grid per wave: row bases + immediates
+  static_assert(rows * W4 * 4 == G::P && (W4 / 4) % 2 == 0, "S1 row split");
+  constexpr int t0 = 4 * HALF;
+  const int dA = i < 8 ? s1_off<S2>(t0) + 16 + i : s1_off<S2>(t0 + 1) + i - 8;
+  const int dB = i < 8 ? s1_off<S2>(t0 + 2) + 16 + i : s1_off<S2>(t0 + 3) + i - 8;
+#pragma unroll 1
+  for (int r = 0; r < rows; ++r) {
+    on_row(r, rows);
+    const int y = kg * rows + r;
+    const float* lb = dy3h + (y * S2 + g) * 24;
+    const float* lbi = lb + i;
+    const float* lbA = lb + dA;
+    const float* lbB = lb + dB;
+    const float* bp = a2h + i * P2 + (y + 1) * S2 + g + 1;
+#pragma unroll
+    for (int xq = 0; xq < W4 / 4; xq += 2) {  // two k-steps per pass: 16 LDS reads in flight, then 14 MFMAs
+      float a[2][7], b[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int o = (xq + u) * 96;
+        b[u] = bp[(xq + u) * 4];
+        a[u][0] = lbi[o + s1_off<S2>(t0)];
+        a[u][1] = lbA[o];
+        a[u][2] = lbi[o + s1_off<S2>(t0 + 1) + 8];
+        a[u][3] = lbi[o + s1_off<S2>(t0 + 2)];
+        a[u][4] = lbB[o];
+        a[u][5] = lbi[o + s1_off<S2>(t0 + 3) + 8];
+        a[u][6] = lbi[o + s1_off<S2>(8) + (HALF ? 16 : 0)];  // half 1: rows 8..15 are padding (dropped at the flush)
+      }
+      SS_SCHED_FENCE();
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 7; ++t) acc[t] = mfma16(a[u][t], b[u], acc[t]);
+      SS_SCHED_FENCE();
+    }
+  }
+}
+
 template <class G>
 __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
+  STAMP_ENTRY;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = BwdLds<G>;
-  constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H, XS = G::XS;
+  constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H, XS = LL::XSB;
   constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, W2H = LL::W2H;
   constexpr int NCH = (HW / 16 + NT - 1) / NT;    // 16-byte pixel chunks per thread
   constexpr int I1S = G::I1S;
@@ -146,13 +201,11 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   }
 
   // persistent per-thread accumulators
-  // S1 splits K (pixels) four ways and the nine taps into {0..4} / {5..8} over the 8 waves
-  f32x4 acc3[2][5], acc2[5];
+  // S1 splits K (pixels) four ways and the 14 (tap, n) tiles in two halves over the 8 waves (s1_rows)
+  f32x4 acc3[7], acc2[5];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 5; ++b) acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int s1_kg = wvu & 3, s1_tbase = (wvu >> 2) * 5, s1_ntap = (wvu >> 2) ? 4 : 5;
+  for (int a = 0; a < 7; ++a) acc3[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int s1_kg = wvu & 3, s1_half = wvu >> 2;
 #pragma unroll
   for (int a = 0; a < 5; ++a) acc2[a] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 accG[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // S5: rows (c, window slot), cols (ry, rx)
@@ -171,7 +224,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   __syncthreads();
   STAMP_DECL;
 
-  // Every per-frame input is fetched ONE FRAME AHEAD by LDS-DMA, issued right before S5 of the previous frame and
+  // Every per-frame input is fetched ONE FRAME AHEAD by LDS-DMA, issued during S5 of the previous frame and
   // waited for at the top of the next one: the pooled-2 map straight into its place (phase 1's a2h lies under the dense
   // dy2 image, dead by then), the uint8 frame / conv3 sign mask / pool-2 argmaxes into a staging area inside the (equally
   // dead) dy3 planes, the d_out row and the averaged features into their misc slots.  No registers are involved, so
@@ -183,14 +236,16 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float wfc_r[3];  // fc weight: the same for every frame
 #pragma unroll
   for (int k = 0; k < 3; ++k) wfc_r[k] = (tid + k * NT < E * 24) ? p.wfc[tid + k * NT] : 0.f;
-  auto prefetch_frame = [&](int nf) {
+  // part / nparts: the issue is spread over the row iterations of S5 (a 1 KB DMA instruction occupies the CU's vector-memory
+  // path for ~30 cycles; 39 of them back to back stalled every wave for 1.2 k cycles per frame, under MFMAs they are free)
+  auto prefetch_frame = [&](int nf, int part, int nparts) {
     constexpr int A2_PIECES = (16 * P2 * 4 + 1023) / 1024, PX_PIECES = (HW + 1023) / 1024,
                   M3_PIECES = (32 * P + 1023) / 1024, I2_PIECES = (16 * P + 1023) / 1024;
     const char* a2src = reinterpret_cast<const char*>(p.st_a2 + (long)nf * 16 * P2);
     const char* pxsrc = reinterpret_cast<const char*>(p.R + (long)nf * HW);
     const char* m3src = reinterpret_cast<const char*>(p.st_m3 + (long)nf * 32 * P);
     const char* i2src = reinterpret_cast<const char*>(p.st_i2 + (long)nf * 16 * P);
-    for (int piece = wvu; piece < A2_PIECES + PX_PIECES + M3_PIECES + I2_PIECES; piece += NWV) {
+    for (int piece = wvu + NWV * part; piece < A2_PIECES + PX_PIECES + M3_PIECES + I2_PIECES; piece += NWV * nparts) {
       int q = piece;
       if (q < A2_PIECES) {
         const int off = q * 1024 + lane * 16;
@@ -213,14 +268,14 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       const int off = q * 1024 + lane * 16;
       if (off < 16 * P) ss_dma16(i2src + off, (unsigned)(STG_I2 * 4 + q * 1024));
     }
-    if (wvu == NWV - 1) {
+    if (wvu == NWV - 1 && part == 0) {
       if (lane < E) ss_dma4(p.d_out + (long)nf * p.ld_dout + lane, (unsigned)((LL::o_misc) * 4));
       if (lane < 24) ss_dma4(p.st_feat + (long)nf * ST_FEAT + lane, (unsigned)((LL::o_misc + 64) * 4));
       if (lane < 24) ss_dma4(p.st_feat + (long)nf * ST_FEAT + 24 + lane, (unsigned)((LL::o_misc + 448) * 4));
       if (lane < 2) ss_dma4(p.st_feat + (long)nf * ST_FEAT + 48 + lane, (unsigned)((LL::o_misc + 128) * 4));  // mean, std
     }
   };
-  if ((int)blockIdx.x < p.N) prefetch_frame(blockIdx.x);
+  if ((int)blockIdx.x < p.N) prefetch_frame(blockIdx.x, 0, 1);
 
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     STAMP(15);
@@ -240,15 +295,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     for (int k = 0; k < 3; ++k)
       if (tid + k * NT < E * 24) s_wfc[tid + k * NT] = wfc_r[k];
     if (!LL::W3_RESIDENT) stage_w3();
-    {  // pooled-1 map: LDS-DMA, 1 KB per wave instruction, issued after every compiler-tracked load of this phase
-       // has been consumed and waited for only before S3 (it flies under S1/S2)
-      constexpr int BYTES = 8 * P1 * 4;
-      const char* src = reinterpret_cast<const char*>(p.st_a1 + (long)n * 8 * P1);
-      for (int piece = wvu; piece * 1024 < BYTES; piece += NWV) {
-        const int off = piece * 1024 + lane * 16;
-        if (off < BYTES) ss_dma16(src + off, (unsigned)(LL::o_a1h * 4 + piece * 1024));
-      }
-    }
     __syncthreads();  // A
     STAMP(0);
 
@@ -305,34 +351,18 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     STAMP(2);
 
     // ---------------- S1: dW3
-    {
-      constexpr int kpw = P / 4;
-      const int pbase = s1_kg * kpw;
-#pragma unroll 1
-      for (int kk = 0; kk < kpw / 4; ++kk) {
-        const int p0 = pbase + 4 * kk;
-        const int y = p0 / W4, x = p0 % W4 + g;
-        const int hal = (y + 1) * S2 + x + 1;
-        const float a0 = dy3h[hal * 24 + i];
-        const float a1v = (i < 8) ? dy3h[hal * 24 + 16 + i] : 0.f;
-        const float* bp = a2h + i * P2 + y * S2 + x;
-        float b[5];
-#pragma unroll
-        for (int tl = 0; tl < 5; ++tl) {
-          const int tap = s1_tbase + (tl < s1_ntap ? tl : 0);
-          b[tl] = bp[(tap / 3) * S2 + (tap % 3)];
-        }
-        SS_SCHED_FENCE();
-#pragma unroll
-        for (int tl = 0; tl < 5; ++tl) {
-          if (tl < s1_ntap) {  // wave-uniform
-            acc3[0][tl] = mfma16(a0, b[tl], acc3[0][tl]);
-            acc3[1][tl] = mfma16(a1v, b[tl], acc3[1][tl]);
-          }
-        }
-        SS_SCHED_FENCE();
+    // the pooled-1 map arrives by LDS-DMA (1 KB per wave instruction) under S1 / S2, one share per row iteration; it is
+    // waited for before S3.  a1h held da1 of the previous frame, dead since barrier E
+    auto a1_dma = [&](int part, int nparts) {
+      constexpr int BYTES = 8 * P1 * 4;
+      const char* src = reinterpret_cast<const char*>(p.st_a1 + (long)n * 8 * P1);
+      for (int piece = wvu + NWV * part; piece * 1024 < BYTES; piece += NWV * nparts) {
+        const int off = piece * 1024 + lane * 16;
+        if (off < BYTES) ss_dma16(src + off, (unsigned)(LL::o_a1h * 4 + piece * 1024));
       }
-    }
+    };
+    if (s1_half == 0) s1_rows<G, 0>(dy3h, a2h, s1_kg, i, g, acc3, a1_dma);
+    else s1_rows<G, 1>(dy3h, a2h, s1_kg, i, g, acc3, a1_dma);
     STAMP_SYNC(3);
     // pool-1 argmaxes for the phase switch: fetched here so that HBM answers under S2
     uint4 ix1[NI1];
@@ -453,7 +483,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         if (q < XS) cell = q;                                   // top row
         else if (q < 2 * XS) cell = (H + 1) * XS + (q - XS);    // bottom row
         else if (q < 2 * XS + H) cell = (q - 2 * XS + 1) * XS;  // left column
-        else cell = (q - 2 * XS - H + 1) * XS + XS - 1;         // right column
+        else cell = (q - 2 * XS - H + 1) * XS + W + 1;          // right column (cells beyond it are never read)
         xh[cell] = 0.f;
       }
 #pragma unroll
@@ -560,7 +590,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     }
     __syncthreads();  // da1 complete
     STAMP(9);
-    if (n + (int)gridDim.x < p.N) prefetch_frame(n + gridDim.x);
     STAMP(10);
     // ---------------- S5: conv1 weight gradient on the pooled grid (K = pooled pixels, whole rows per wave: row
     // bases + immediates)
@@ -572,6 +601,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       const int boff5 = (i >> 2) * XS + (i & 3);  // B column (ry, rx)
 #pragma unroll 1
       for (int r = 0; r < rows; ++r) {
+        if (n + (int)gridDim.x < p.N) prefetch_frame(n + gridDim.x, r, rows);  // dy2 / dy3 areas are dead: S4 is through
         const float* dp = a1h + c * P1 + (y0 + r + 1) * S1 + g + 1;
         // i1b and xh lie beyond the 64 KB reach of a ds_read immediate: keep the whole byte offset in a register the
         // compiler cannot split, so that the per-read constants stay immediates instead of one v_add each
@@ -626,14 +656,17 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   for (int q = tid; q < rtot; q += NT) lds[q] = 0.f;
   __syncthreads();
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int t = 0; t < 7; ++t)
 #pragma unroll
-    for (int tl = 0; tl < 5; ++tl)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nn = 16 * mt + 4 * g + r;
-        if (nn < 24 && tl < s1_ntap) atomicAdd(&r_w3[nn * 144 + i * 9 + s1_tbase + tl], acc3[mt][tl][r]);
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * g + r, t0 = 4 * s1_half + 2 * (t / 3);
+      int nn, tap;
+      if (t == 6) { nn = s1_half ? 16 + row : row; tap = 8; }
+      else if (t % 3 == 0) { nn = row; tap = t0; }
+      else if (t % 3 == 1) { nn = row < 8 ? 16 + row : row - 8; tap = row < 8 ? t0 : t0 + 1; }
+      else { nn = 8 + row; tap = t0 + 1; }
+      if (nn < 24) atomicAdd(&r_w3[nn * 144 + i * 9 + tap], acc3[t][r]);
+    }
 #pragma unroll
   for (int nt = 0; nt < 5; ++nt) {
     const int idx = 16 * nt + i;

@@ -136,16 +136,20 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // Thread 0 of every workgroup accumulates s_memtime deltas between barriers; the real build has no stamps.
 #ifdef SS_STAMP
 #define SS_STAMP_SLOTS 16
+#define SS_STAMP_WGS 512
 // one table per translation unit (no relocatable device code): STAMP_TABLE(fn) defines it and its host reader
 #define STAMP_TABLE(reader)                                                                           \
-  __device__ unsigned long long ss_stamp_buf[256 * SS_STAMP_SLOTS];                                   \
+  __device__ unsigned long long ss_stamp_buf[SS_STAMP_WGS * SS_STAMP_SLOTS];                                   \
   extern "C" int reader(unsigned long long* host_out) {                                               \
     if (hipDeviceSynchronize() != hipSuccess) return SS_ERR_LAUNCH;                                   \
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ss_stamp_buf), sizeof(unsigned long long) * 256 * SS_STAMP_SLOTS) == hipSuccess \
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ss_stamp_buf), sizeof(unsigned long long) * SS_STAMP_WGS * SS_STAMP_SLOTS) == hipSuccess \
                ? SS_OK                                                                                \
                : SS_ERR_LAUNCH;                                                                       \
   }
-#define STAMP_DECL unsigned long long st_last = clock64(), st_acc[SS_STAMP_SLOTS] = {0}
+// STAMP_ENTRY at the top of the kernel: slot 14 = cycles before the frame loop, slots 12 / 13 = wall clock (100 MHz, the same
+// counter on every CU) at entry / exit -- dispatch stagger and tail imbalance across workgroups
+#define STAMP_ENTRY unsigned long long st_entry = clock64(), st_wall0 = wall_clock64()
+#define STAMP_DECL unsigned long long st_last = clock64(), st_acc[SS_STAMP_SLOTS] = {0}; st_acc[14] = st_last - st_entry; st_acc[12] = st_wall0
 #define STAMP(k)                               \
   do {                                         \
     if (threadIdx.x == 0) {                    \
@@ -167,10 +171,12 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
   } while (0)
 #define STAMP_FLUSH()                                                                       \
   do {                                                                                      \
-    if (threadIdx.x == 0 && blockIdx.x < 256)                                               \
+    st_acc[13] = wall_clock64();                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < SS_STAMP_WGS)                                      \
       for (int k_ = 0; k_ < SS_STAMP_SLOTS; ++k_) ss_stamp_buf[blockIdx.x * SS_STAMP_SLOTS + k_] = st_acc[k_]; \
   } while (0)
 #else
+#define STAMP_ENTRY
 #define STAMP_DECL
 #define STAMP(k)
 #define STAMP_SYNC(k)

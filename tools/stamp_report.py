@@ -36,16 +36,25 @@ def main():
         tr.step(X, lengths, R, y)
     lib = L.load()
     for which, names in ((0, FWD), (1, BWD)):
-        buf = np.zeros(256 * 16, np.uint64)
+        nwg = 512
+        buf = np.zeros(nwg * 16, np.uint64)
         fn = getattr(lib, "ss_debug_stamps_fwd" if which == 0 else "ss_debug_stamps_bwd")
         fn.argtypes, fn.restype = [C.c_void_p], C.c_int
         assert fn(buf.ctypes.data) == 0
-        t = buf.reshape(256, 16).astype(np.float64)
-        tot = t.sum(1).mean()
-        fpw = 15 if which == 0 else 30  # forward: 512 workgroups of 256 threads (two per CU), backward: 256 of 512
-        print(f"kernel {'roi_cnn_fwd' if which == 0 else 'roi_cnn_bwd'}: {tot / fpw:.0f} cycles per frame (mean over the first 256 workgroups, {fpw} frames each)")
+        t = buf.reshape(nwg, 16).astype(np.float64)
+        used = 512 if which == 0 else 256   # forward: 512 workgroups of 256 threads (two per CU), backward: 256 of 512
+        t = t[:used]
+        stage = t[:, list(names)]
+        tot = stage.sum(1).mean()
+        fpw = B * T // used
+        print(f"kernel {'roi_cnn_fwd' if which == 0 else 'roi_cnn_bwd'}: {tot / fpw:.0f} cycles per frame (mean over {used} workgroups, {fpw} frames each)")
         for k, name in names.items():
             print(f"   {name:28s} {t[:, k].mean() / fpw:9.0f} cyc/frame  {100 * t[:, k].mean() / tot:5.1f} %")
+        loop = stage.sum(1)
+        print(f"   frame loop per workgroup: min {loop.min():.0f}  mean {loop.mean():.0f}  max {loop.max():.0f} cycles; before the loop: mean {t[:, 14].mean():.0f} max {t[:, 14].max():.0f}")
+        w0, w1 = t[:, 12], t[:, 13]
+        print(f"   wall clock (100 MHz ticks): first entry -> last entry {w0.max() - w0.min():.0f}, first entry -> first exit {w1.min() - w0.min():.0f}, "
+              f"-> last exit {w1.max() - w0.min():.0f}; lifetime mean {np.mean(w1 - w0):.0f}")
 
 
 if __name__ == "__main__":
