@@ -32,9 +32,10 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True, stamp: bool = False) -> str:
     """``stamp=True`` builds the diagnostic library (in-kernel stage timers) next to the real one."""
     if stamp:
-        out = os.path.join(HERE, "libss_hotpath_stamp.so")
+        # A/B experiments: SS_STAMP_DEFS="-DSS_VAR=1" SS_STAMP_OUT=libss_hotpath_stampB.so builds a second variant
+        out = os.path.join(HERE, os.environ.get("SS_STAMP_OUT", "libss_hotpath_stamp.so"))
         srcs = [os.path.join(CSRC, s) for s in SOURCES]
-        cmd = [_hipcc(), *FLAGS, "-DSS_STAMP", "-shared", "-o", out, *srcs]
+        cmd = [_hipcc(), *FLAGS, "-DSS_STAMP", *os.environ.get("SS_STAMP_DEFS", "").split(), "-shared", "-o", out, *srcs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -97,37 +97,36 @@ __device__ __forceinline__ void s1_rows(const float* dy3h, const float* a2h, int
   constexpr int t0 = 4 * HALF;
   const int dA = i < 8 ? s1_off<S2>(t0) + 16 + i : s1_off<S2>(t0 + 1) + i - 8;
   const int dB = i < 8 ? s1_off<S2>(t0 + 2) + 16 + i : s1_off<S2>(t0 + 3) + i - 8;
-#pragma unroll 1
-  for (int r = 0; r < rows; ++r) {
-    on_row(r, rows);
-    const int y = kg * rows + r;
-    const float* lb = dy3h + (y * S2 + g) * 24;
-    const float* lbi = lb + i;
-    const float* lbA = lb + dA;
-    const float* lbB = lb + dB;
-    const float* bp = a2h + i * P2 + (y + 1) * S2 + g + 1;
+  // one k-step (8 LDS reads, 7 MFMAs) per pass, the next pass's reads issued before this pass's MFMAs (see S3); fully
+  // unrolled: every address is one of four lane bases + an immediate
+  constexpr int KPR = W4 / 4, NP = rows * KPR;
+  const float* lb = dy3h + (kg * rows * S2 + g) * 24;
+  const float* lbi = lb + i;
+  const float* lbA = lb + dA;
+  const float* lbB = lb + dB;
+  const float* bp = a2h + i * P2 + (kg * rows + 1) * S2 + g + 1;
+  float a[2][7], b[2];
 #pragma unroll
-    for (int xq = 0; xq < W4 / 4; xq += 2) {  // two k-steps per pass: 16 LDS reads in flight, then 14 MFMAs
-      float a[2][7], b[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int o = (xq + u) * 96;
-        b[u] = bp[(xq + u) * 4];
-        a[u][0] = lbi[o + s1_off<S2>(t0)];
-        a[u][1] = lbA[o];
-        a[u][2] = lbi[o + s1_off<S2>(t0 + 1) + 8];
-        a[u][3] = lbi[o + s1_off<S2>(t0 + 2)];
-        a[u][4] = lbB[o];
-        a[u][5] = lbi[o + s1_off<S2>(t0 + 3) + 8];
-        a[u][6] = lbi[o + s1_off<S2>(8) + (HALF ? 16 : 0)];  // half 1: rows 8..15 are padding (dropped at the flush)
-      }
-      SS_SCHED_FENCE();
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int t = 0; t < 7; ++t) acc[t] = mfma16(a[u][t], b[u], acc[t]);
-      SS_SCHED_FENCE();
+  for (int ps = -1; ps < NP; ++ps) {
+    if (ps + 1 < NP) {
+      const int nx = ps + 1, r = nx / KPR, xq = nx % KPR, buf = nx & 1;
+      if (xq == 0) on_row(r, rows);
+      const int o = (r * S2 + 4 * xq) * 24;
+      b[buf] = bp[r * S2 + 4 * xq];
+      a[buf][0] = lbi[o + s1_off<S2>(t0)];
+      a[buf][1] = lbA[o];
+      a[buf][2] = lbi[o + s1_off<S2>(t0 + 1) + 8];
+      a[buf][3] = lbi[o + s1_off<S2>(t0 + 2)];
+      a[buf][4] = lbB[o];
+      a[buf][5] = lbi[o + s1_off<S2>(t0 + 3) + 8];
+      a[buf][6] = lbi[o + s1_off<S2>(8) + (HALF ? 16 : 0)];  // half 1: rows 8..15 are padding (dropped at the flush)
     }
+    SS_SCHED_FENCE();
+    if (ps >= 0) {
+#pragma unroll
+      for (int t = 0; t < 7; ++t) acc[t] = mfma16(a[ps & 1][t], b[ps & 1], acc[t]);
+    }
+    SS_SCHED_FENCE();
   }
 }
 
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   using LL = BwdLds<G>;
   constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H, XS = LL::XSB;
   constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, W2H = LL::W2H;
-  constexpr int NCH = (HW / 16 + NT - 1) / NT;    // 16-byte pixel chunks per thread
+  constexpr int NCH = (HW / 8 + NT - 1) / NT;     // 8-byte pixel chunks per thread (every thread of a 64x64 frame has one)
   constexpr int I1S = G::I1S;
   constexpr int NI1 = (I1S / 2 + NT - 1) / NT;    // 16-byte pool-1 argmax chunks per thread
   float* a1h = lds + LL::o_a1h;
@@ -159,7 +158,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float* s_gb3 = misc + 160;     // [32]  accumulated over the frame walk
   float* s_cnt = misc + 448;     // [24] positive conv3 outputs per channel of this frame (from the forward's stash)
   float* s_xn = misc + 192;      // [256] normalised value of every uint8 level for this frame
-  float* s_wfc = da2m;           // [E*24] staged per frame; da2m itself is first written in S2
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wvu = __builtin_amdgcn_readfirstlane(wv);
@@ -232,10 +230,11 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   // round trips per frame: spilled pointers and split destination registers each forced an s_waitcnt vmcnt(0)).
   constexpr int STG_PX = LL::o_dy3h, STG_M3 = STG_PX + HW / 4, STG_I2 = STG_M3 + 8 * P;   // float offsets
   static_assert(HW / 4 + 12 * P <= 24 * P2 && HW % 16 == 0 && P % 16 == 0, "staging");
-  uint4 px[NCH];
-  float wfc_r[3];  // fc weight: the same for every frame
+  uint2 px[NCH];
+  // fc weight column of this thread's channel (c = tid / 16; e = tid % 16 + 16 k): d feat needs nothing staged per frame
+  float wq[4];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) wfc_r[k] = (tid + k * NT < E * 24) ? p.wfc[tid + k * NT] : 0.f;
+  for (int k = 0; k < 4; ++k) wq[k] = (tid < 24 * 16 && (tid & 15) + 16 * k < E) ? p.wfc[((tid & 15) + 16 * k) * 24 + (tid >> 4)] : 0.f;
   // part / nparts: the issue is spread over the row iterations of S5 (a 1 KB DMA instruction occupies the CU's vector-memory
   // path for ~30 cycles; 39 of them back to back stalled every wave for 1.2 k cycles per frame, under MFMAs they are free)
   auto prefetch_frame = [&](int nf, int part, int nparts) {
@@ -282,32 +281,39 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // ---------------- L0: the prefetched inputs have landed (the frame's mean / std come with them, from the forward's stash)
     ss_dma_wait();    // this wave's pieces (issued a frame ago)
     __syncthreads();  // A0: everybody's
+    STAMP(16);
     constexpr int NM3 = (2 * P + NT - 1) / NT;  // 16-byte mask items (pixel, channel half) per thread
     uint4 m3w[NM3];
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
-      if ((tid + k * NT) * 16 < HW) px[k] = reinterpret_cast<const uint4*>(lds + STG_PX)[tid + k * NT];
+      if ((tid + k * NT) * 8 < HW) px[k] = reinterpret_cast<const uint2*>(lds + STG_PX)[tid + k * NT];
 #pragma unroll
     for (int k = 0; k < NM3; ++k)
       m3w[k] = (tid + k * NT < 2 * P) ? reinterpret_cast<const uint4*>(lds + STG_M3)[tid + k * NT] : uint4{0, 0, 0, 0};
     if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = reinterpret_cast<const uint4*>(lds + STG_I2)[tid];
+    STAMP(17);
+    if (tid < 24 * 16) {  // d feat[c] = sum_e d_out[e] * Wfc[e][c]: 16 lanes per channel (one DPP row), then a shuffle tree
+      float sacc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (tid + k * NT < E * 24) s_wfc[tid + k * NT] = wfc_r[k];
+      for (int k = 0; k < 4; ++k) sacc += s_dout[(tid & 15) + 16 * k] * wq[k];  // slots beyond E stay zero
+      sacc = row_sum(sacc);
+      if ((tid & 15) == 0) s_dfeat[tid >> 4] = sacc / (float)P;
+    }
+    STAMP(18);
     if (!LL::W3_RESIDENT) stage_w3();
     __syncthreads();  // A
     STAMP(0);
 
-    // the dy3 planes held the staged inputs (all consumed before barrier A): back to zero, the fill below writes the
-    // interiors and the halo must be zero
-    for (int q = tid; q < (LL::o_da2m - LL::o_dy3h) / 4; q += NT)
-      reinterpret_cast<f32x4*>(dy3h)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < 24 * 16) {  // d feat[c] = sum_e d_out[e] * Wfc[e][c]: 16 lanes per channel, then a shuffle tree
-      const int c = tid >> 4, sub = tid & 15;
-      float s = 0.f;
-      for (int e = sub; e < E; e += 16) s += s_dout[e] * s_wfc[e * 24 + c];
-      s = row_sum(s);  // the 16 lanes of a channel are one DPP row
-      if (sub == 0) s_dfeat[c] = s / (float)P;
+    // the dy3 planes held the staged inputs (all consumed before barrier A): the fill below writes every interior pixel,
+    // the halo pixels go back to zero here
+    for (int q = tid; q < (2 * S2 + 2 * G::H4) * 6; q += NT) {
+      const int hp = q / 6, part = q - 6 * hp;
+      int pixh;
+      if (hp < S2) pixh = hp;                                           // top row
+      else if (hp < 2 * S2) pixh = (G::H4 + 1) * S2 + (hp - S2);        // bottom row
+      else if (hp < 2 * S2 + G::H4) pixh = (hp - 2 * S2 + 1) * S2;      // left column
+      else pixh = (hp - 2 * S2 - G::H4 + 1) * S2 + W4 + 1;              // right column
+      reinterpret_cast<f32x4*>(dy3h + pixh * 24)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -318,7 +324,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
     }
     if (tid < E) accbfc += s_dout[tid];
-    __syncthreads();  // B
     STAMP(1);
 
     // dy3 = mask3 * dfeat / P, pixel-major [haloed pixel][24 channels] (the region was cleared above, so the halo is zero):
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     {
       constexpr int tiles = P / 16;
 #pragma unroll 1
-      for (int tile = wv; tile < tiles; tile += 2 * NWV) {
+      for (int tile = wvu; tile < tiles; tile += 2 * NWV) {  // wvu: scalar loop control and tile arithmetic
         const int tile2 = tile + NWV;
         const bool two = tile2 < tiles;
         const int pp0 = 16 * tile + i, pp1 = 16 * (two ? tile2 : tile) + i;
@@ -387,21 +392,34 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         asm volatile("" : "+v"(w3off), "+v"(w3off8));  // W3 may lie beyond the 64 KB reach of a ds_read immediate (see S5)
         const float* bt16 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + w3off);
         const float* bt8 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + w3off8);
+        // a tap is two steps -- channels 0..15 (3 x ds_read_b128, 8 MFMAs) and 16..23 (3 x ds_read_b64, 4 MFMAs) -- and
+        // every step's reads are issued before the MFMAs of the step in front of it (see S3)
+        f32x4 b16, a016, a116;
+        float2 b8, a08, a18;
+        auto back_of = [](int tap) { return ((tap / 3) * S2 + (tap % 3)) * 24; };
+        b16 = *reinterpret_cast<const f32x4*>(bt16);
+        a016 = *reinterpret_cast<const f32x4*>(ap0 + 4 * g);
+        a116 = *reinterpret_cast<const f32x4*>(ap1 + 4 * g);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int back = ((tap / 3) * S2 + (tap % 3)) * 24;
-          const f32x4 b16 = *reinterpret_cast<const f32x4*>(bt16 + tap * 256);
-          const float2 b8 = *reinterpret_cast<const float2*>(bt8 + tap * 128);
-          const f32x4 a016 = *reinterpret_cast<const f32x4*>(ap0 - back + 4 * g);
-          const float2 a08 = *reinterpret_cast<const float2*>(ap0 - back + 16 + 2 * g);
-          const f32x4 a116 = *reinterpret_cast<const f32x4*>(ap1 - back + 4 * g);
-          const float2 a18 = *reinterpret_cast<const float2*>(ap1 - back + 16 + 2 * g);
+          const int back = back_of(tap);
+          b8 = *reinterpret_cast<const float2*>(bt8 + tap * 128);
+          a08 = *reinterpret_cast<const float2*>(ap0 - back + 16 + 2 * g);
+          a18 = *reinterpret_cast<const float2*>(ap1 - back + 16 + 2 * g);
           SS_SCHED_FENCE();
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             acc0 = mfma16(a016[e], b16[e], acc0);
             acc1x = mfma16(a116[e], b16[e], acc1x);
           }
+          SS_SCHED_FENCE();
+          if (tap + 1 < 9) {
+            const int nb = back_of(tap + 1);
+            b16 = *reinterpret_cast<const f32x4*>(bt16 + (tap + 1) * 256);
+            a016 = *reinterpret_cast<const f32x4*>(ap0 - nb + 4 * g);
+            a116 = *reinterpret_cast<const f32x4*>(ap1 - nb + 4 * g);
+          }
+          SS_SCHED_FENCE();
           acc0 = mfma16(a08.x, b8.x, acc0);
           acc1x = mfma16(a18.x, b8.x, acc1x);
           acc0 = mfma16(a08.y, b8.y, acc0);
@@ -444,19 +462,24 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         iv[e] = (q < 16 * P) ? (int)i2b[q] : 0;
       }
       __syncthreads();  // every read of the phase-1 images is done before the first overwrite
+      STAMP(11);
 #pragma unroll
       for (int e = 0; e < TV; ++e) {
         const int q = tid + e * NT;  // da2m and the argmaxes are pixel-major: q = pooled-2 pixel * 16 + channel
         if (q < 16 * P) {
           const int c = q & 15, r = q >> 4;
           const int qy = r / W4, qx = r % W4;
-          float* dst = dy2 + ((2 * qy) * W2H + 2 * qx + 1) * 16 + c;
+          // a wave's store covers 4 pixels x 16 channels and a dy2 pixel is 16 banks wide: pixels of odd qx write the
+          // right-hand window column first, so that every store spreads over all 32 banks (2-way instead of 4-way)
+          const int par = qx & 1;
+          float* d0 = dy2 + ((2 * qy) * W2H + 2 * qx + 1 + par) * 16 + c;
+          float* d1 = dy2 + ((2 * qy) * W2H + 2 * qx + 2 - par) * 16 + c;
           const float v = dv[e];
           const int o = iv[e];
-          dst[0] = o == 0 ? v : 0.f;
-          dst[16] = o == 1 ? v : 0.f;
-          dst[16 * W2H] = o == 2 ? v : 0.f;
-          dst[16 * W2H + 16] = o == 3 ? v : 0.f;
+          d0[0] = o == par ? v : 0.f;
+          d1[0] = o == 1 - par ? v : 0.f;
+          d0[16 * W2H] = o == 2 + par ? v : 0.f;
+          d1[16 * W2H] = o == 3 - par ? v : 0.f;
         }
       }
       // the zero columns of dy2 (the area held phase-1 data)
@@ -464,16 +487,17 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         const int y = q >> 3, side = (q >> 2) & 1, part = q & 3;
         reinterpret_cast<f32x4*>(dy2)[(y * W2H + (side ? W2 + 1 : 0)) * 4 + part] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      STAMP(10);
       // normalised frame: interior by table lookup, halo cells zeroed (the area held phase-1 data)
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
         const int q = tid + k * NT;
-        if (q * 16 < HW) {
-          const int lin = q * 16;
+        if (q * 8 < HW) {
+          const int lin = q * 8;
           float* dst = xh + (lin / W + 1) * XS + (lin % W + 1);
-          const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+          const unsigned wds[2] = {px[k].x, px[k].y};
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int b = 0; b < 4; ++b) dst[4 * e + b] = s_xn[(wds[e] >> (8 * b)) & 255u];
         }
@@ -486,6 +510,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         else cell = (q - 2 * XS - H + 1) * XS + W + 1;          // right column (cells beyond it are never read)
         xh[cell] = 0.f;
       }
+      STAMP(8);
 #pragma unroll
       for (int k = 0; k < NI1; ++k)
         if ((tid + k * NT) * 16 < 8 * I1S) reinterpret_cast<uint4*>(i1b)[tid + k * NT] = ix1[k];
@@ -494,35 +519,41 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     __syncthreads();  // T done
     STAMP(5);
 
-    // ---------------- S3: dW2.  A wave owns whole rows of the pooled-1 grid: per row one A base and five B bases,
-    // everything else is an immediate offset (VALU work between MFMAs is not hidden by them)
+    // ---------------- S3: dW2.  A wave owns whole rows of the pooled-1 grid: one A base and five B bases per wave,
+    // everything else is an immediate offset (VALU work between MFMAs is not hidden by them).  The two waves of a SIMD
+    // leave the barrier together and then run in lockstep -- both read, both multiply -- so a wave's operand reads are
+    // NOT covered by its partner's MFMAs: each pass issues the reads of the next one before its own MFMAs (two register
+    // sets), fully unrolled so that every address is base + immediate.
     {
       constexpr int kpw = HW2 / NWV, rows = kpw / W2;
       static_assert(rows * W2 == kpw && (W2 / 4) % 2 == 0, "S3 row split");
+      constexpr int PPR = W2 / 8, NP = rows * PPR;  // passes of two k-steps (12 LDS reads, 10 MFMAs)
       const int y0 = wvu * rows;
-#pragma unroll 1
-      for (int r = 0; r < rows; ++r) {
-        const float* ap = dy2 + ((y0 + r) * W2H + 1 + g) * 16 + i;
-        const float* bp = a1h + (y0 + r) * S1 + g;
-        const float* bpn[5];
+      const float* ap = dy2 + (y0 * W2H + 1 + g) * 16 + i;
+      const float* bpn[5];
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) bpn[nt] = bp + boff[nt];
+      for (int nt = 0; nt < 5; ++nt) bpn[nt] = a1h + y0 * S1 + g + boff[nt];
+      float a[2][2], b[2][2][5];
 #pragma unroll
-        for (int xq = 0; xq < W2 / 4; xq += 2) {  // two k-steps per pass: 12 LDS reads in flight, then 10 MFMAs
-          float a[2], b[2][5];
+      for (int ps = -1; ps < NP; ++ps) {
+        if (ps + 1 < NP) {
+          const int nx = ps + 1, r = nx / PPR, xq = 2 * (nx % PPR), buf = nx & 1;
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            a[u] = ap[(xq + u) * 64];
+            a[buf][u] = ap[r * W2H * 16 + (xq + u) * 64];
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) b[u][nt] = bpn[nt][(xq + u) * 4];
+            for (int nt = 0; nt < 5; ++nt) b[buf][u][nt] = bpn[nt][r * S1 + (xq + u) * 4];
           }
-          SS_SCHED_FENCE();
+        }
+        SS_SCHED_FENCE();
+        if (ps >= 0) {
+          const int buf = ps & 1;
 #pragma unroll
           for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) acc2[nt] = mfma16(a[u], b[u][nt], acc2[nt]);
-          SS_SCHED_FENCE();
+            for (int nt = 0; nt < 5; ++nt) acc2[nt] = mfma16(a[buf][u], b[buf][u][nt], acc2[nt]);
         }
+        SS_SCHED_FENCE();
       }
     }
     STAMP_SYNC(6);
@@ -532,8 +563,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       constexpr int xt_n = W2 / 16;
       constexpr int chains = (H2 / 2) * xt_n;
       const int c = i & 7, s = i >> 3;
+      // (a wave needs its two chains: one chain of dependent MFMAs alone runs at half rate -- measured with single-chain
+      // passes for waves 4..7, meant to stagger the epilogues of a SIMD's two waves: S4 15.5 k -> 20.3 k cycles)
 #pragma unroll 1
-      for (int ch = wv; ch < chains; ch += 2 * NWV) {
+      for (int ch = wvu; ch < chains; ch += 2 * NWV) {  // wvu: the edge-row tests below are scalar branches, not exec masks
         const int ch2 = ch + NWV;
         const bool two = ch2 < chains;
         const int chb = two ? ch2 : ch;
@@ -546,29 +579,39 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         const float* ab0 = dy2 + ((y0_ - 1) * W2H + x0_) * 16 + 4 * g;
         const float* ab1 = dy2 + ((y1_ - 1) * W2H + x1_) * 16 + 4 * g;
         const float* bb = w2t + (g * 16 + i) * 4;
+        // one tap (3 x ds_read_b128, 8 MFMAs) per step, the next tap's reads issued before this tap's MFMAs (see S3)
+        f32x4 a0[2], a1[2], b[2];
+        float* cell0 = a1h + c * P1 + (y0_ + s + 1) * S1 + x0_ - i + 4 * g + 1;
+        float* cell1 = a1h + c * P1 + (y1_ + s + 1) * S1 + x1_ - i + 4 * g + 1;
+        float mk0[4], mk1[4];
 #pragma unroll
-        for (int tp = 0; tp < 12; tp += 2) {
-          f32x4 a0[2], a1[2], b[2];
-          bool ok0[2], ok1[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int tk = tp + u, t = tk / 3, kx = tk % 3;
+        for (int tk = -1; tk < 12; ++tk) {
+          if (tk + 1 < 12) {
+            const int nx = tk + 1, t = nx / 3, kx = nx % 3, buf = nx & 1;
             const int off = (t * W2H + 2 - kx) * 16;
-            ok0[u] = !(t == 0 && y0_ == 0) && !(t == 3 && y0_ == H2 - 2);
-            ok1[u] = !(t == 0 && y1_ == 0) && !(t == 3 && y1_ == H2 - 2);
-            a0[u] = a1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok0[u]) a0[u] = *reinterpret_cast<const f32x4*>(ab0 + off);
-            if (ok1[u]) a1[u] = *reinterpret_cast<const f32x4*>(ab1 + off);
-            b[u] = *reinterpret_cast<const f32x4*>(bb + tk * 256);
+            const bool ok0 = !(t == 0 && y0_ == 0) && !(t == 3 && y0_ == H2 - 2);
+            const bool ok1 = !(t == 0 && y1_ == 0) && !(t == 3 && y1_ == H2 - 2);
+            a0[buf] = a1[buf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok0) a0[buf] = *reinterpret_cast<const f32x4*>(ab0 + off);
+            if (ok1) a1[buf] = *reinterpret_cast<const f32x4*>(ab1 + off);
+            b[buf] = *reinterpret_cast<const f32x4*>(bb + nx * 256);
+          }
+          if (tk == 9) {  // the a1 cells whose sign masks the result: read under the last taps, not in the epilogue
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              mk0[r] = cell0[r];
+              mk1[r] = cell1[r];
+            }
           }
           SS_SCHED_FENCE();
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
+          if (tk >= 0) {
+            const int buf = tk & 1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              acc0 = mfma16(a0[u][e], b[u][e], acc0);
-              acc1x = mfma16(a1[u][e], b[u][e], acc1x);
+              acc0 = mfma16(a0[buf][e], b[buf][e], acc0);
+              acc1x = mfma16(a1[buf][e], b[buf][e], acc1x);
             }
+          }
           SS_SCHED_FENCE();
         }
         // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0 and leave da1 IN PLACE of
@@ -576,12 +619,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           if (half == 1 && !two) break;
-          const int yy = (half ? y1_ : y0_) + s;
-          const int xb0 = (half ? x1_ : x0_) - i + 4 * g;
-          float* cell = a1h + c * P1 + (yy + 1) * S1 + xb0 + 1;
+          float* cell = half ? cell1 : cell0;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float d = cell[r] > 0.f ? (half ? acc1x[r] : acc0[r]) : 0.f;
+            const float d = (half ? mk1[r] : mk0[r]) > 0.f ? (half ? acc1x[r] : acc0[r]) : 0.f;
             cell[r] = d;
             accb1 += d;
           }
@@ -590,7 +631,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     }
     __syncthreads();  // da1 complete
     STAMP(9);
-    STAMP(10);
     // ---------------- S5: conv1 weight gradient on the pooled grid (K = pooled pixels, whole rows per wave: row
     // bases + immediates)
     {
@@ -599,49 +639,55 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       const int y0 = wvu * rows;
       const int c = i & 7, os = i >> 3;         // A rows: tile 0 -> window slot os, tile 1 -> slot 2 + os
       const int boff5 = (i >> 2) * XS + (i & 3);  // B column (ry, rx)
-#pragma unroll 1
-      for (int r = 0; r < rows; ++r) {
-        if (n + (int)gridDim.x < p.N) prefetch_frame(n + gridDim.x, r, rows);  // dy2 / dy3 areas are dead: S4 is through
-        const float* dp = a1h + c * P1 + (y0 + r + 1) * S1 + g + 1;
-        // i1b and xh lie beyond the 64 KB reach of a ds_read immediate: keep the whole byte offset in a register the
-        // compiler cannot split, so that the per-read constants stay immediates instead of one v_add each
-        int ioff = LL::o_i1b * 4 + c * I1S + (y0 + r) * W2 + g;
-        int xoff = (LL::o_xh + 2 * (y0 + r) * XS + 2 * g + boff5) * 4;
-        asm volatile("" : "+v"(ioff), "+v"(xoff));
-        const uint8_t* ip = reinterpret_cast<const uint8_t*>(lds) + ioff;
-        const float* xp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + xoff);
-        constexpr int KP = 4;  // k-steps per pass: 3 KP LDS reads in flight, then 2 KP MFMAs
+      // i1b and xh lie beyond the 64 KB reach of a ds_read immediate: keep the whole byte offset in a register the
+      // compiler cannot split, so that the per-read constants stay immediates instead of one v_add each
+      const float* dp = a1h + c * P1 + (y0 + 1) * S1 + g + 1;
+      int ioff = LL::o_i1b * 4 + c * I1S + y0 * W2 + g;
+      int xoff = (LL::o_xh + 2 * y0 * XS + 2 * g + boff5) * 4;
+      asm volatile("" : "+v"(ioff), "+v"(xoff));
+      const uint8_t* ip = reinterpret_cast<const uint8_t*>(lds) + ioff;
+      const float* xp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + xoff);
+      constexpr int KP = 4;                  // k-steps per pass: 3 KP LDS reads, 2 KP selects, 2 KP MFMAs
+      constexpr int PPR = W2 / 4 / KP, NP = rows * PPR;
+      constexpr int pf_parts = rows >= 2 ? rows / 2 : 1;
+      // fully unrolled, the next pass's reads issued before this pass's selects and MFMAs (see S3)
+      float d[2][KP], xv[2][KP];
+      int ix[2][KP];
 #pragma unroll
-        for (int xq = 0; xq < W2 / 4; xq += KP) {
-          float d[KP], xv[KP];
-          int ix[KP];
+      for (int ps = -1; ps < NP; ++ps) {
+        if (ps + 1 < NP) {
+          const int nx = ps + 1, r = nx / PPR, xq = KP * (nx % PPR), buf = nx & 1;
+          // dy2 / dy3 areas are dead (S4 is through); everything is on its way by the middle of S5 so that it has landed at L0
+          if (nx % PPR == 0 && r < pf_parts && n + (int)gridDim.x < p.N) prefetch_frame(n + gridDim.x, r, pf_parts);
 #pragma unroll
           for (int u = 0; u < KP; ++u) {
-            d[u] = dp[(xq + u) * 4];
-            ix[u] = ip[(xq + u) * 4];
-            xv[u] = xp[(xq + u) * 8];
+            d[buf][u] = dp[r * S1 + (xq + u) * 4];
+            ix[buf][u] = ip[r * W2 + (xq + u) * 4];
+            xv[buf][u] = xp[2 * r * XS + (xq + u) * 8];
           }
+        }
+        if (ps >= 0) {
+          const int buf = ps & 1;
           // every operand is selected into a register of its own BEFORE the MFMA block: a select that rewrites the
           // source register of the MFMA in front of it waits for that MFMA (measured: 2.7x the MFMA time)
           float s0[KP], s1[KP];
 #pragma unroll
           for (int u = 0; u < KP; ++u) {
-            s0[u] = ix[u] == os ? d[u] : 0.f;
-            s1[u] = ix[u] == 2 + os ? d[u] : 0.f;
+            s0[u] = ix[buf][u] == os ? d[buf][u] : 0.f;
+            s1[u] = ix[buf][u] == 2 + os ? d[buf][u] : 0.f;
           }
           SS_SCHED_FENCE();
 #pragma unroll
           for (int u = 0; u < KP; ++u) {
-            accG[0] = mfma16(s0[u], xv[u], accG[0]);
-            accG[1] = mfma16(s1[u], xv[u], accG[1]);
+            accG[0] = mfma16(s0[u], xv[buf][u], accG[0]);
+            accG[1] = mfma16(s1[u], xv[buf][u], accG[1]);
           }
-          SS_SCHED_FENCE();
         }
+        SS_SCHED_FENCE();
       }
     }
     __syncthreads();  // E
     STAMP(7);
-    STAMP(8);
   }
 
   // ---------------- flush: reduce the per-wave partials through LDS, then one atomic per element

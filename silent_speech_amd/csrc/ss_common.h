@@ -135,7 +135,7 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // ---- diagnostic build only (-DSS_STAMP): per-stage cycle shares of the persistent kernels.
 // Thread 0 of every workgroup accumulates s_memtime deltas between barriers; the real build has no stamps.
 #ifdef SS_STAMP
-#define SS_STAMP_SLOTS 16
+#define SS_STAMP_SLOTS 24
 #define SS_STAMP_WGS 512
 // one table per translation unit (no relocatable device code): STAMP_TABLE(fn) defines it and its host reader
 #define STAMP_TABLE(reader)                                                                           \

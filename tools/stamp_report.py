@@ -19,8 +19,8 @@ from silent_speech_amd import _lib as L  # noqa: E402
 
 FWD = {15: "loop top", 0: "stats+normalise", 1: "conv1 (MFMA)", 2: "a1 stash copy + conv2 (MFMA)", 3: "a2 stash copy",
        4: "conv3 (MFMA)", 5: "feat + fc"}
-BWD = {15: "loop top", 0: "L0 loads a2/i2/a1", 1: "dfeat + fc grads", 2: "dy3 fill", 3: "S1 dW3", 4: "S2 da2",
-       5: "T phase switch (dy2, x, i1)", 6: "S3 dW2", 9: "S4 da1", 10: "prefetch of the next frame (issue)", 7: "S5 dW1 (MFMA)", 8: "halo re-zero"}
+BWD = {15: "loop top", 16: "L0: DMA wait + barrier", 17: "L0: staging -> regs", 18: "L0: dfeat", 0: "L0: barrier A", 1: "dfeat + fc grads", 2: "dy3 fill", 3: "S1 dW3", 4: "S2 da2",
+       11: "T: da2m/argmax -> regs, barrier", 10: "T: dy2 scatter", 8: "T: normalised frame", 5: "T: i1, a1 DMA wait, barrier", 6: "S3 dW2", 9: "S4 da1", 7: "S5 dW1 (MFMA)"}
 
 
 def main():
@@ -37,11 +37,11 @@ def main():
     lib = L.load()
     for which, names in ((0, FWD), (1, BWD)):
         nwg = 512
-        buf = np.zeros(nwg * 16, np.uint64)
+        buf = np.zeros(nwg * 24, np.uint64)
         fn = getattr(lib, "ss_debug_stamps_fwd" if which == 0 else "ss_debug_stamps_bwd")
         fn.argtypes, fn.restype = [C.c_void_p], C.c_int
         assert fn(buf.ctypes.data) == 0
-        t = buf.reshape(nwg, 16).astype(np.float64)
+        t = buf.reshape(nwg, 24).astype(np.float64)
         used = 512 if which == 0 else 256   # forward: 512 workgroups of 256 threads (two per CU), backward: 256 of 512
         t = t[:used]
         stage = t[:, list(names)]
