@@ -16,6 +16,8 @@
 // buffer and a reduce pass; several split-K problems can share one launch (gemm_dma_group_kernel).
 #include <stdlib.h>
 
+// diagnostic build: rows of the stamp table in dispatch order over the 3-D grid
+#define SS_STAMP_ROW ((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)))
 #include "ss_common.h"
 
 STAMP_TABLE(ss_debug_stamps_gemm)
@@ -331,13 +333,7 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
   gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g, nullptr,
                 TileId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y});
   STAMP_WAIT(4);
-#ifdef SS_STAMP
-  {  // the first 256 workgroups in dispatch order report
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (threadIdx.x == 0 && lin < 256)
-      for (int k_ = 0; k_ < SS_STAMP_SLOTS; ++k_) ss_stamp_buf[lin * SS_STAMP_SLOTS + k_] = st_acc[k_];
-  }
-#endif
+  STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@
 //
 // Weight-gradient partial sums stay in registers for the whole frame walk (K = pixels split over the
 // 8 waves) and are reduced through LDS, then one float atomic per element per workgroup, at the end.
+#include <type_traits>
 #include "ss_common.h"
 #include "roi_cnn_geom.h"
 
@@ -50,7 +51,10 @@ struct BwdLds {
   static constexpr int XSB = G::XS + (8 - G::XS % 32 + 32) % 32;
   static constexpr int XHN = (G::H + 2) * XSB;
   static constexpr int o_i1b = (o_xh + XHN + 3) & ~3;
-  static constexpr int end2 = (o_i1b + 2 * G::I1S + 3) & ~3;
+  // pool-1 argmax planes in LDS, one bank apart: S5 reads one byte per channel plane and the stash's plane stride (H2*W2
+  // bytes, a multiple of 128) would put all eight on the same bank
+  static constexpr int I1SB = G::I1S + 4;
+  static constexpr int end2 = (o_i1b + 2 * I1SB + 3) & ~3;
   // W3 (13.8 KB) stays resident behind the phase area when the CU's 160 KB allow it; otherwise it lives in the
   // phase-1 part and is re-staged from L2 every frame
   static constexpr int fixed = 192 * 16 + 512;             // w2t + misc
@@ -513,7 +517,11 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       STAMP(8);
 #pragma unroll
       for (int k = 0; k < NI1; ++k)
-        if ((tid + k * NT) * 16 < 8 * I1S) reinterpret_cast<uint4*>(i1b)[tid + k * NT] = ix1[k];
+        if ((tid + k * NT) * 16 < 8 * I1S) {  // 16 stash bytes -> their plane's place in the padded LDS layout
+          const int q = (tid + k * NT) * 16;
+          uint32_t* dst = reinterpret_cast<uint32_t*>(i1b + q + 4 * (q / I1S));
+          dst[0] = ix1[k].x; dst[1] = ix1[k].y; dst[2] = ix1[k].z; dst[3] = ix1[k].w;
+        }
     }
     ss_dma_wait();    // this wave's share of the pooled-1 map has landed in LDS
     __syncthreads();  // T done
@@ -565,9 +573,12 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       const int c = i & 7, s = i >> 3;
       // (a wave needs its two chains: one chain of dependent MFMAs alone runs at half rate -- measured with single-chain
       // passes for waves 4..7, meant to stagger the epilogues of a SIMD's two waves: S4 15.5 k -> 20.3 k cycles)
+      // A pass takes two NEIGHBOURING chains: with two column blocks per row pair both lie on the same rows, so both
+      // are interior, both on the first row pair or both on the last one (see the tap loop below)
+      constexpr int npairs = (chains + 1) / 2;
 #pragma unroll 1
-      for (int ch = wvu; ch < chains; ch += 2 * NWV) {  // wvu: the edge-row tests below are scalar branches, not exec masks
-        const int ch2 = ch + NWV;
+      for (int pj = wvu; pj < npairs; pj += NWV) {  // wvu: pass control and the edge tests are scalar
+        const int ch = 2 * pj, ch2 = ch + 1;
         const bool two = ch2 < chains;
         const int chb = two ? ch2 : ch;
         const int y0_ = 2 * (ch / xt_n), x0_ = 16 * (ch % xt_n) + i;
@@ -579,40 +590,55 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         const float* ab0 = dy2 + ((y0_ - 1) * W2H + x0_) * 16 + 4 * g;
         const float* ab1 = dy2 + ((y1_ - 1) * W2H + x1_) * 16 + 4 * g;
         const float* bb = w2t + (g * 16 + i) * 4;
-        // one tap (3 x ds_read_b128, 8 MFMAs) per step, the next tap's reads issued before this tap's MFMAs (see S3)
-        f32x4 a0[2], a1[2], b[2];
+        // one tap (3 x ds_read_b128, 8 MFMAs) per step, the next tap's reads issued before this tap's MFMAs (see S3).
+        // Source rows above / below the map (t = 0 of the first row pair, t = 3 of the last) contribute nothing.  Four
+        // copies of the tap loop: KIND 0 both chains interior (12 taps, no test), 1 both on the first row pair (taps 3..11),
+        // 2 both on the last (taps 0..8), 3 anything else: every tap's row tested, scalar branches around the reads
+        // (all passes through KIND 3 cost 15 us per launch: the stage ends when its slowest wave does)
         float* cell0 = a1h + c * P1 + (y0_ + s + 1) * S1 + x0_ - i + 4 * g + 1;
         float* cell1 = a1h + c * P1 + (y1_ + s + 1) * S1 + x1_ - i + 4 * g + 1;
         float mk0[4], mk1[4];
+        auto taps = [&](auto kind_tag) {
+          constexpr int KIND = decltype(kind_tag)::value;
+          constexpr int T0 = KIND == 1 ? 3 : 0, T1 = KIND == 2 ? 9 : 12;
+          f32x4 a0[2], a1[2], b[2];
 #pragma unroll
-        for (int tk = -1; tk < 12; ++tk) {
-          if (tk + 1 < 12) {
-            const int nx = tk + 1, t = nx / 3, kx = nx % 3, buf = nx & 1;
-            const int off = (t * W2H + 2 - kx) * 16;
-            const bool ok0 = !(t == 0 && y0_ == 0) && !(t == 3 && y0_ == H2 - 2);
-            const bool ok1 = !(t == 0 && y1_ == 0) && !(t == 3 && y1_ == H2 - 2);
-            a0[buf] = a1[buf] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok0) a0[buf] = *reinterpret_cast<const f32x4*>(ab0 + off);
-            if (ok1) a1[buf] = *reinterpret_cast<const f32x4*>(ab1 + off);
-            b[buf] = *reinterpret_cast<const f32x4*>(bb + nx * 256);
-          }
-          if (tk == 9) {  // the a1 cells whose sign masks the result: read under the last taps, not in the epilogue
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              mk0[r] = cell0[r];
-              mk1[r] = cell1[r];
+          for (int tk = T0 - 1; tk < T1; ++tk) {
+            if (tk + 1 < T1) {
+              const int nx = tk + 1, t = nx / 3, kx = nx % 3, buf = nx & 1;
+              const int off = (t * W2H + 2 - kx) * 16;
+              const bool ok0 = KIND != 3 || (!(t == 0 && y0_ == 0) && !(t == 3 && y0_ == H2 - 2));
+              const bool ok1 = KIND != 3 || (!(t == 0 && y1_ == 0) && !(t == 3 && y1_ == H2 - 2));
+              a0[buf] = a1[buf] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (ok0) a0[buf] = *reinterpret_cast<const f32x4*>(ab0 + off);
+              if (ok1) a1[buf] = *reinterpret_cast<const f32x4*>(ab1 + off);
+              b[buf] = *reinterpret_cast<const f32x4*>(bb + nx * 256);
             }
-          }
-          SS_SCHED_FENCE();
-          if (tk >= 0) {
-            const int buf = tk & 1;
+            if (tk == T1 - 3) {  // the a1 cells whose sign masks the result: read under the last taps, not in the epilogue
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              acc0 = mfma16(a0[buf][e], b[buf][e], acc0);
-              acc1x = mfma16(a1[buf][e], b[buf][e], acc1x);
+              for (int r = 0; r < 4; ++r) {
+                mk0[r] = cell0[r];
+                mk1[r] = cell1[r];
+              }
             }
+            SS_SCHED_FENCE();
+            if (tk >= T0) {
+              const int buf = tk & 1;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                acc0 = mfma16(a0[buf][e], b[buf][e], acc0);
+                acc1x = mfma16(a1[buf][e], b[buf][e], acc1x);
+              }
+            }
+            SS_SCHED_FENCE();
           }
-          SS_SCHED_FENCE();
+        };
+        {
+          const bool top0 = y0_ == 0, top1 = y1_ == 0, bot0 = y0_ == H2 - 2, bot1 = y1_ == H2 - 2;
+          if (!(top0 || top1 || bot0 || bot1)) taps(std::integral_constant<int, 0>{});
+          else if (top0 && top1 && !bot0 && !bot1) taps(std::integral_constant<int, 1>{});
+          else if (bot0 && bot1 && !top0 && !top1) taps(std::integral_constant<int, 2>{});
+          else taps(std::integral_constant<int, 3>{});
         }
         // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0 and leave da1 IN PLACE of
         // a1 (each cell is read and rewritten by exactly one lane; S3 finished with a1 before the barrier above).
@@ -642,7 +668,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       // i1b and xh lie beyond the 64 KB reach of a ds_read immediate: keep the whole byte offset in a register the
       // compiler cannot split, so that the per-read constants stay immediates instead of one v_add each
       const float* dp = a1h + c * P1 + (y0 + 1) * S1 + g + 1;
-      int ioff = LL::o_i1b * 4 + c * I1S + y0 * W2 + g;
+      int ioff = LL::o_i1b * 4 + c * LL::I1SB + y0 * W2 + g;
       int xoff = (LL::o_xh + 2 * y0 * XS + 2 * g + boff5) * 4;
       asm volatile("" : "+v"(ioff), "+v"(xoff));
       const uint8_t* ip = reinterpret_cast<const uint8_t*>(lds) + ioff;

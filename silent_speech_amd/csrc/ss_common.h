@@ -139,22 +139,39 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #define SS_STAMP_WGS 512
 // one table per translation unit (no relocatable device code): STAMP_TABLE(fn) defines it and its host reader
 #define STAMP_TABLE(reader)                                                                           \
-  __device__ unsigned long long ss_stamp_buf[SS_STAMP_WGS * SS_STAMP_SLOTS];                                   \
+  __device__ unsigned long long ss_stamp_buf[SS_STAMP_WGS * SS_STAMP_SLOTS];                          \
   extern "C" int reader(unsigned long long* host_out) {                                               \
     if (hipDeviceSynchronize() != hipSuccess) return SS_ERR_LAUNCH;                                   \
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ss_stamp_buf), sizeof(unsigned long long) * SS_STAMP_WGS * SS_STAMP_SLOTS) == hipSuccess \
-               ? SS_OK                                                                                \
-               : SS_ERR_LAUNCH;                                                                       \
+    const size_t bytes_ = sizeof(unsigned long long) * SS_STAMP_WGS * SS_STAMP_SLOTS;                 \
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ss_stamp_buf), bytes_) != hipSuccess) return SS_ERR_LAUNCH; \
+    void* dev_ = nullptr;  /* the table accumulates over launches: reading it clears it */            \
+    if (hipGetSymbolAddress(&dev_, HIP_SYMBOL(ss_stamp_buf)) != hipSuccess) return SS_ERR_LAUNCH;     \
+    return hipMemset(dev_, 0, bytes_) == hipSuccess ? SS_OK : SS_ERR_LAUNCH;                          \
   }
+// Thread 0 adds every delta straight into the table with a no-return atomic: the timers cost three registers, not a
+// 24-entry array (which pushed the 250-register kernels into scratch and distorted what it measured).
 // STAMP_ENTRY at the top of the kernel: slot 14 = cycles before the frame loop, slots 12 / 13 = wall clock (100 MHz, the same
 // counter on every CU) at entry / exit -- dispatch stagger and tail imbalance across workgroups
+// (row of the table: SS_STAMP_ROW, the workgroup's x index unless the file defines its own before its first stamp)
+#ifndef SS_STAMP_ROW
+#define SS_STAMP_ROW ((int)blockIdx.x)
+#endif
+#define STAMP_ADD_(k, v)                                                                              \
+  do {                                                                                                \
+    if (SS_STAMP_ROW < SS_STAMP_WGS) atomicAdd(&ss_stamp_buf[SS_STAMP_ROW * SS_STAMP_SLOTS + (k)], (unsigned long long)(v)); \
+  } while (0)
 #define STAMP_ENTRY unsigned long long st_entry = clock64(), st_wall0 = wall_clock64()
-#define STAMP_DECL unsigned long long st_last = clock64(), st_acc[SS_STAMP_SLOTS] = {0}; st_acc[14] = st_last - st_entry; st_acc[12] = st_wall0
+#define STAMP_DECL                                   \
+  unsigned long long st_last = clock64();            \
+  if (threadIdx.x == 0) {                            \
+    STAMP_ADD_(14, st_last - st_entry);              \
+    STAMP_ADD_(12, st_wall0);                        \
+  }
 #define STAMP(k)                               \
   do {                                         \
     if (threadIdx.x == 0) {                    \
       unsigned long long t_ = clock64();       \
-      st_acc[k] += t_ - st_last;               \
+      STAMP_ADD_(k, t_ - st_last);             \
       st_last = t_;                            \
     }                                          \
   } while (0)
@@ -169,11 +186,9 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
     __builtin_amdgcn_s_waitcnt(0);   \
     STAMP(k);                        \
   } while (0)
-#define STAMP_FLUSH()                                                                       \
-  do {                                                                                      \
-    st_acc[13] = wall_clock64();                                                            \
-    if (threadIdx.x == 0 && blockIdx.x < SS_STAMP_WGS)                                      \
-      for (int k_ = 0; k_ < SS_STAMP_SLOTS; ++k_) ss_stamp_buf[blockIdx.x * SS_STAMP_SLOTS + k_] = st_acc[k_]; \
+#define STAMP_FLUSH()                                        \
+  do {                                                       \
+    if (threadIdx.x == 0) STAMP_ADD_(13, wall_clock64());    \
   } while (0)
 #else
 #define STAMP_ENTRY
