@@ -213,29 +213,36 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
     __syncthreads();
     STAMP(0);
 
-    // ---------------- stage 1: conv1 (MFMA) + ReLU + pool -> a1 (haloed), argmax bytes
+    // ---------------- stage 1: conv1 (MFMA) + ReLU + pool -> a1 (haloed), argmax bytes.
+    // The pooling epilogue is the stage's cost (the forward kernel issues 3.3 other vector instructions per MFMA, most of
+    // them here, and they do not hide behind the MFMAs of the CU's other workgroup): it is written for instruction count.
+    //  * a pass = UC neighbouring 16-pixel blocks of one row pair: one address per pass, immediates per chain;
+    //  * max first, bias and ReLU once on the winner (max(relu(x_i + b)) = relu(max(x_i + b)));
+    //  * the argmax bits are lane MASKS (v_cmp writes an SGPR pair): the row / column bookkeeping and the exchange with
+    //    the partner lane (i ^ 8: a byte swap of the mask) run on the scalar unit, two vector instructions turn the
+    //    final masks into the index byte;
+    //  * the MFMAs of the next pass are issued before the epilogue of this one (two accumulator sets).
     {
       constexpr int XT = W / 16;
-      constexpr int chains = (H / 2) * XT;
+      constexpr int UC = (XT % 4 == 0) ? 4 : (XT % 3 == 0) ? 3 : 2;
+      static_assert(XT % UC == 0, "conv1 pass split");
+      constexpr int XP = XT / UC, passes = (H / 2) * XP, ppw = passes / NWV;
+      static_assert(ppw * NWV == passes && ppw % 2 == 0, "conv1 pass split");
       const int c = i & 7, s = i >> 3;
+      const int wvu = __builtin_amdgcn_readfirstlane(wv);
       const float bias = s_b1[c];
-      // UC independent chains per pass: their reads, 3-deep MFMA chains and pooling epilogues overlap (one chain alone
-      // is a serial read -> MFMA -> MFMA -> MFMA -> exchange -> write dependency, ~550 cycles with nothing beside it)
-      constexpr int cpw = chains / NWV;
-      static_assert(cpw * NWV == chains && cpw % 2 == 0, "conv1 chain split");
-      constexpr int UC = (cpw % 4 == 0) ? 4 : 2;
-#pragma unroll 1
-      for (int ch0 = wv; ch0 < chains; ch0 += UC * NWV) {
+      constexpr unsigned long long S = 0xFF00FF00FF00FF00ull, LO = 0x00FF00FF00FF00FFull;  // lanes of row s = 1; low bytes
+      const float* xa = xh + i;
+      float* a1w = a1 + c * P1 + S1 + 2 * g + s + 1;
+      uint8_t* i1w = i1s + c * G::I1S + 2 * g + s;
+      auto mm = [&](int ps, f32x4 (&acc)[UC]) {
+        const float* ap = xa + (2 * (ps / XP)) * XS + 16 * UC * (ps % XP);
         float av[UC][3];
 #pragma unroll
-        for (int q = 0; q < UC; ++q) {
-          const int ch = ch0 + q * NWV;
-          const float* ap = xh + (2 * (ch / XT)) * XS + 16 * (ch % XT) + i;
+        for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
-          for (int kk = 0; kk < 3; ++kk) av[q][kk] = ap[aoff1[kk]];
-        }
+          for (int q = 0; q < UC; ++q) av[q][kk] = (ap + aoff1[kk])[16 * q];
         SS_SCHED_FENCE();
-        f32x4 acc[UC];
 #pragma unroll
         for (int q = 0; q < UC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -243,35 +250,45 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
 #pragma unroll
           for (int q = 0; q < UC; ++q) acc[q] = mfma16(av[q][kk], bw1[kk], acc[q]);
         SS_SCHED_FENCE();
+      };
+      auto epi = [&](int ps, const f32x4 (&acc)[UC]) {
+        const int yp = ps / XP, xt0 = UC * (ps % XP);
+        float* aw = a1w + yp * S1 + 8 * xt0;
+        uint8_t* iw = i1w + yp * W2 + 8 * xt0;
 #pragma unroll
         for (int q = 0; q < UC; ++q) {
-          const int ch = ch0 + q * NWV;
-          const int yp = ch / XT, xt = ch % XT;
-          // lane holds 4 pixels x0+4g+r of row 2yp+s for channel c
-          float m[2];
-          int cb[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float v0 = fmaxf(acc[q][2 * e] + bias, 0.f), v1 = fmaxf(acc[q][2 * e + 1] + bias, 0.f);
-            m[e] = v1 > v0 ? v1 : v0;
-            cb[e] = v1 > v0 ? 1 : 0;
-          }
+          // lane holds 4 pixels x0+4g+r of row 2yp+s for channel c: column pairs (0,1) and (2,3)
+          const float x0 = acc[q][0] + bias, x1 = acc[q][1] + bias, x2 = acc[q][2] + bias, x3 = acc[q][3] + bias;
+          const unsigned long long m0 = __ballot(x1 > x0), m1 = __ballot(x3 > x2);
+          const float p0 = fmaxf(x0, x1), p1 = fmaxf(x2, x3);
           // row s = 0 lanes finish column pair 0, row s = 1 lanes finish column pair 1; the partner (other row, same
           // channel) is lane ^ 8: a rotate by 8 inside the 16-lane DPP row, no LDS round trip
-          const float send_v = s ? m[0] : m[1];
-          const int send_c = s ? cb[0] : cb[1];
-          const float recv_v = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send_v), 0x128, 0xf, 0xf, false));
-          const int recv_c = __builtin_amdgcn_update_dpp(0, send_c, 0x128, 0xf, 0xf, false);
-          const float own_v = s ? m[1] : m[0];
-          const int own_c = s ? cb[1] : cb[0];
-          const float r0v = s ? recv_v : own_v, r1v = s ? own_v : recv_v;
-          const int r0c = s ? recv_c : own_c, r1c = s ? own_c : recv_c;
-          const float best = r1v > r0v ? r1v : r0v;
-          const int bi = r1v > r0v ? 2 + r1c : r0c;
-          const int pxx = 8 * xt + 2 * g + s;
-          a1[c * P1 + (yp + 1) * S1 + pxx + 1] = best;
-          i1s[c * G::I1S + yp * W2 + pxx] = (uint8_t)bi;
+          const float own = s ? p1 : p0, send = s ? p0 : p1;
+          const float recv = SS_DPP_F(send, 0x128);
+          const unsigned long long oc = (m1 & S) | (m0 & ~S);   // column bit of the own pair
+          const unsigned long long sc = (m0 & S) | (m1 & ~S);   // column bit of the pair the partner finishes
+          const unsigned long long rc = ((sc & LO) << 8) | ((sc >> 8) & LO);  // the partner's bit for the own pair
+          const unsigned long long rg = __ballot(recv > own), og = __ballot(own > recv);
+          const unsigned long long t1 = (rg & ~S) | (og & S);   // row 1 wins (strictly: ties go to the first in row-major order)
+          const unsigned long long r1c = (oc & S) | (rc & ~S), r0c = (rc & S) | (oc & ~S);
+          const unsigned long long b0 = (t1 & r1c) | (~t1 & r0c);
+          const float best = fmaxf(fmaxf(own, recv), 0.f);
+          int hi, bi;
+          unsigned long long carry_out;
+          asm("v_cndmask_b32_e64 %0, 0, 2, %1" : "=v"(hi) : "s"(t1));
+          asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(bi), "=s"(carry_out) : "v"(hi), "s"(b0));
+          aw[8 * q] = best;
+          iw[8 * q] = (uint8_t)bi;
         }
+      };
+      f32x4 accA[UC], accB[UC];
+      mm(wvu, accA);
+#pragma unroll 1
+      for (int it = 0; it < ppw; it += 2) {
+        mm(wvu + NWV * (it + 1), accB);
+        epi(wvu + NWV * it, accA);
+        if (it + 2 < ppw) mm(wvu + NWV * (it + 2), accA);
+        epi(wvu + NWV * (it + 1), accB);
       }
     }
     __syncthreads();
