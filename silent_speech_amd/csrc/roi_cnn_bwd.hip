@@ -64,7 +64,13 @@ struct BwdLds {
   static constexpr int o_w3s = W3_RESIDENT ? ph_end : end1a;
   static constexpr int o_w2t = W3_RESIDENT ? ph_end + 3456 : ph_end;
   static constexpr int o_misc = o_w2t + 192 * 16;
-  static constexpr int total = o_misc + 512;
+  // staging of the NEXT frame's uint8 pixels and pool-2 argmaxes (they are consumed at the top of that frame, after the
+  // dy3 image -- where the mask bytes are staged -- has been filled): the part of the da2m planes that the normalised
+  // frame does not cover is free while S5 runs; shapes where that is too small get an area of their own
+  static constexpr int stg2_need = G::HW / 4 + 4 * G::P;
+  static constexpr bool STG2_IN_DA2M = o_xh - o_da2m >= stg2_need;
+  static constexpr int o_stg2 = STG2_IN_DA2M ? o_da2m : o_misc + 512;
+  static constexpr int total = o_misc + 512 + (STG2_IN_DA2M ? 0 : stg2_need);
   static_assert(total * 4 <= 160 * 1024, "LDS image exceeds a CU");
   static constexpr int TV = (16 * G::P + NT - 1) / NT;    // (da2m, argmax) pairs per thread at the phase switch
 };
@@ -226,14 +232,16 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   __syncthreads();
   STAMP_DECL;
 
-  // Every per-frame input is fetched ONE FRAME AHEAD by LDS-DMA, issued during S5 of the previous frame and
-  // waited for at the top of the next one: the pooled-2 map straight into its place (phase 1's a2h lies under the dense
-  // dy2 image, dead by then), the uint8 frame / conv3 sign mask / pool-2 argmaxes into a staging area inside the (equally
-  // dead) dy3 planes, the d_out row and the averaged features into their misc slots.  No registers are involved, so
+  // Every per-frame input is fetched ONE FRAME AHEAD by LDS-DMA, issued at the start of S5 of the previous frame: the
+  // pooled-2 map straight into its place (phase 1's a2h lies under the dense dy2 image, dead by then), the conv3 sign mask
+  // into the (equally dead) dy3 planes, the uint8 frame / pool-2 argmaxes into the second staging area, the d_out row and
+  // the averaged features into their misc slots.  The front of the next frame -- d feat, the dy3 image, the grey-level
+  // table: barriers and LDS round trips with no MFMA beside them -- then runs INSIDE the last quarter of S5 (top1 / top2
+  // below): a frame starts at S1.  No registers are involved, so
   // nothing the compiler does with its own loads can wait on these (a register prefetch cost 2.8 us of serialised HBM
   // round trips per frame: spilled pointers and split destination registers each forced an s_waitcnt vmcnt(0)).
-  constexpr int STG_PX = LL::o_dy3h, STG_M3 = STG_PX + HW / 4, STG_I2 = STG_M3 + 8 * P;   // float offsets
-  static_assert(HW / 4 + 12 * P <= 24 * P2 && HW % 16 == 0 && P % 16 == 0, "staging");
+  constexpr int STG_M3 = LL::o_dy3h, STG_PX = LL::o_stg2, STG_I2 = STG_PX + HW / 4;   // float offsets
+  static_assert(8 * P <= 24 * P2 && HW % 16 == 0 && P % 16 == 0, "staging");
   uint2 px[NCH];
   // fc weight column of this thread's channel (c = tid / 16; e = tid % 16 + 16 k): d feat needs nothing staged per frame
   float wq[4];
@@ -278,46 +286,19 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       if (lane < 2) ss_dma4(p.st_feat + (long)nf * ST_FEAT + 48 + lane, (unsigned)((LL::o_misc + 128) * 4));  // mean, std
     }
   };
-  if ((int)blockIdx.x < p.N) prefetch_frame(blockIdx.x, 0, 1);
-
-  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
-    STAMP(15);
-    // ---------------- L0: the prefetched inputs have landed (the frame's mean / std come with them, from the forward's stash)
-    ss_dma_wait();    // this wave's pieces (issued a frame ago)
-    __syncthreads();  // A0: everybody's
-    STAMP(16);
-    constexpr int NM3 = (2 * P + NT - 1) / NT;  // 16-byte mask items (pixel, channel half) per thread
-    uint4 m3w[NM3];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k)
-      if ((tid + k * NT) * 8 < HW) px[k] = reinterpret_cast<const uint2*>(lds + STG_PX)[tid + k * NT];
+  constexpr int NM3 = (2 * P + NT - 1) / NT;  // 16-byte mask items (pixel, channel half) per thread
+  // top1: after the barrier behind which every wave's DMA pieces have landed.  Mask bytes into registers (the dy3 image is
+  // about to be written over their staging area), d feat, the fc gradients' share of this frame, the grey-level table.
+  auto top1 = [&](uint4 (&m3w)[NM3]) {
 #pragma unroll
     for (int k = 0; k < NM3; ++k)
       m3w[k] = (tid + k * NT < 2 * P) ? reinterpret_cast<const uint4*>(lds + STG_M3)[tid + k * NT] : uint4{0, 0, 0, 0};
-    if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = reinterpret_cast<const uint4*>(lds + STG_I2)[tid];
-    STAMP(17);
     if (tid < 24 * 16) {  // d feat[c] = sum_e d_out[e] * Wfc[e][c]: 16 lanes per channel (one DPP row), then a shuffle tree
       float sacc = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) sacc += s_dout[(tid & 15) + 16 * k] * wq[k];  // slots beyond E stay zero
       sacc = row_sum(sacc);
       if ((tid & 15) == 0) s_dfeat[tid >> 4] = sacc / (float)P;
-    }
-    STAMP(18);
-    if (!LL::W3_RESIDENT) stage_w3();
-    __syncthreads();  // A
-    STAMP(0);
-
-    // the dy3 planes held the staged inputs (all consumed before barrier A): the fill below writes every interior pixel,
-    // the halo pixels go back to zero here
-    for (int q = tid; q < (2 * S2 + 2 * G::H4) * 6; q += NT) {
-      const int hp = q / 6, part = q - 6 * hp;
-      int pixh;
-      if (hp < S2) pixh = hp;                                           // top row
-      else if (hp < 2 * S2) pixh = (G::H4 + 1) * S2 + (hp - S2);        // bottom row
-      else if (hp < 2 * S2 + G::H4) pixh = (hp - 2 * S2 + 1) * S2;      // left column
-      else pixh = (hp - 2 * S2 - G::H4 + 1) * S2 + W4 + 1;              // right column
-      reinterpret_cast<f32x4*>(dy3h + pixh * 24)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -328,10 +309,25 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
     }
     if (tid < E) accbfc += s_dout[tid];
-    STAMP(1);
-
-    // dy3 = mask3 * dfeat / P, pixel-major [haloed pixel][24 channels] (the region was cleared above, so the halo is zero):
-    // an item is 16 mask bytes = 16 channels of one pixel -> four (two for channels 16..23) 16-byte stores
+    if (tid < 256) {  // the forward's xn = (u/255 - mu)/sd, once per grey level instead of once per pixel
+      const float rr = (float)tid / 255.0f;
+      s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
+    }
+  };
+  // top2: after the barrier behind which every mask byte is in a register and d feat is published.
+  // dy3 = mask3 * dfeat / P, pixel-major [haloed pixel][24 channels]: the halo pixels back to zero (the planes held the
+  // staged mask), every interior pixel written: an item is 16 mask bytes = 16 channels of one pixel -> four (two for
+  // channels 16..23) 16-byte stores
+  auto top2 = [&](const uint4 (&m3w)[NM3]) {
+    for (int q = tid; q < (2 * S2 + 2 * G::H4) * 6; q += NT) {
+      const int hp = q / 6, part = q - 6 * hp;
+      int pixh;
+      if (hp < S2) pixh = hp;                                           // top row
+      else if (hp < 2 * S2) pixh = (G::H4 + 1) * S2 + (hp - S2);        // bottom row
+      else if (hp < 2 * S2 + G::H4) pixh = (hp - 2 * S2 + 1) * S2;      // left column
+      else pixh = (hp - 2 * S2 - G::H4 + 1) * S2 + W4 + 1;              // right column
+      reinterpret_cast<f32x4*>(dy3h + pixh * 24)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int k = 0; k < NM3; ++k) {
       const int item = tid + k * NT;
@@ -351,13 +347,29 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         }
       }
     }
-    if (tid < 256) {  // the forward's xn = (u/255 - mu)/sd, once per grey level instead of once per pixel
-      const float rr = (float)tid / 255.0f;
-      s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
-    }
-    __syncthreads();  // C
     if (tid < 24) s_gb3[tid] += s_dfeat[tid] * s_cnt[tid];  // d b3 = d feat x (number of positive conv3 outputs)
-    STAMP(2);
+  };
+  if ((int)blockIdx.x < p.N) {  // the first frame's inputs and front, outside the pipeline
+    prefetch_frame(blockIdx.x, 0, 1);
+    ss_dma_wait();
+    __syncthreads();
+    uint4 m3w[NM3];
+    top1(m3w);
+    __syncthreads();
+    top2(m3w);
+    __syncthreads();
+  }
+
+  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    STAMP(15);
+    // ---------------- frame top: d feat, the dy3 image and the grey-level table of this frame were made during S5 of the
+    // previous one (top1 / top2); what is left are two copies out of the second staging area, needed at the phase switch
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+      if ((tid + k * NT) * 8 < HW) px[k] = reinterpret_cast<const uint2*>(lds + STG_PX)[tid + k * NT];
+    if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = reinterpret_cast<const uint4*>(lds + STG_I2)[tid];
+    if (!LL::W3_RESIDENT) stage_w3();  // (read in S2, behind the barrier that ends S1)
+    STAMP(0);
 
     // ---------------- S1: dW3
     // the pooled-1 map arrives by LDS-DMA (1 KB per wave instruction) under S1 / S2, one share per row iteration; it is
@@ -675,7 +687,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       const float* xp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + xoff);
       constexpr int KP = 4;                  // k-steps per pass: 3 KP LDS reads, 2 KP selects, 2 KP MFMAs
       constexpr int PPR = W2 / 4 / KP, NP = rows * PPR;
-      constexpr int pf_parts = rows >= 2 ? rows / 2 : 1;
+      constexpr int FRONT = NP - (NP + 3) / 4;  // pass after which the next frame's front runs (the DMA has ~3/4 of S5 to land)
+      const bool has_next = n + (int)gridDim.x < p.N;
       // fully unrolled, the next pass's reads issued before this pass's selects and MFMAs (see S3)
       float d[2][KP], xv[2][KP];
       int ix[2][KP];
@@ -683,8 +696,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       for (int ps = -1; ps < NP; ++ps) {
         if (ps + 1 < NP) {
           const int nx = ps + 1, r = nx / PPR, xq = KP * (nx % PPR), buf = nx & 1;
-          // dy2 / dy3 areas are dead (S4 is through); everything is on its way by the middle of S5 so that it has landed at L0
-          if (nx % PPR == 0 && r < pf_parts && n + (int)gridDim.x < p.N) prefetch_frame(n + gridDim.x, r, pf_parts);
+          // dy2 / dy3 areas are dead (S4 is through): the next frame's inputs are requested with the first pass
+          if (nx == 0 && has_next) prefetch_frame(n + gridDim.x, 0, 1);
 #pragma unroll
           for (int u = 0; u < KP; ++u) {
             d[buf][u] = dp[r * S1 + (xq + u) * 4];
@@ -710,6 +723,14 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           }
         }
         SS_SCHED_FENCE();
+        if (ps == FRONT - 1 && has_next) {  // (wave-uniform; the reads of pass FRONT are already in flight)
+          ss_dma_wait();
+          __syncthreads();  // F1: every wave's pieces of the next frame have landed
+          uint4 m3w[NM3];
+          top1(m3w);
+          __syncthreads();  // F2: mask bytes are in registers, d feat is published
+          top2(m3w);
+        }
       }
     }
     __syncthreads();  // E
