@@ -247,16 +247,37 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float wq[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) wq[k] = (tid < 24 * 16 && (tid & 15) + 16 * k < E) ? p.wfc[((tid & 15) + 16 * k) * 24 + (tid >> 4)] : 0.f;
-  // part / nparts: the issue is spread over the row iterations of S5 (a 1 KB DMA instruction occupies the CU's vector-memory
-  // path for ~30 cycles; 39 of them back to back stalled every wave for 1.2 k cycles per frame, under MFMAs they are free)
-  auto prefetch_frame = [&](int nf, int part, int nparts) {
+  // FAST (one 16-byte mask item per thread, whole rows of the pooled-2 grid per wave -- the 64x64 frames of BASELINE.json):
+  // the front of the next frame needs no workgroup barrier.  Every wave fetches the 1 KB of mask bytes of ITS pixels into
+  // the dy3 cells of those same pixels, reads them back after its own s_waitcnt and fills its rows; d feat is made a stage
+  // earlier (its inputs are requested in S1).  The two waves of a SIMD then run their fronts at DIFFERENT passes of S5, one
+  // wave's vector / LDS work under the other's MFMAs (tools/microbench/mfma_valu: a wave's v_fma stream does not slow the
+  // partner's MFMAs at all); with barriers in it the front costs its full length wherever it is put.
+  constexpr bool FAST = (2 * P == NT) && ((P / NWV) % W4 == 0);
+  auto m3_own_dst = [&]() {  // float offset of this wave's first interior pixel in the dy3 image
+    const int pix0 = (P / NWV) * wvu;
+    return LL::o_dy3h + ((pix0 / W4 + 1) * S2 + pix0 % W4 + 1) * 24;
+  };
+  static_assert(!FAST || W4 * 24 >= 256, "a wave's mask piece stays inside its first row");
+  auto misc_dma = [&](int nf) {  // d_out row, averaged features, counts, mean / std: one wave, four tiny DMAs
+    if (wvu == NWV - 1) {
+      if (lane < E) ss_dma4(p.d_out + (long)nf * p.ld_dout + lane, (unsigned)((LL::o_misc) * 4));
+      if (lane < 24) ss_dma4(p.st_feat + (long)nf * ST_FEAT + lane, (unsigned)((LL::o_misc + 64) * 4));
+      if (lane < 24) ss_dma4(p.st_feat + (long)nf * ST_FEAT + 24 + lane, (unsigned)((LL::o_misc + 448) * 4));
+      if (lane < 2) ss_dma4(p.st_feat + (long)nf * ST_FEAT + 48 + lane, (unsigned)((LL::o_misc + 128) * 4));  // mean, std
+    }
+  };
+  // (a 1 KB DMA instruction occupies the CU's vector-memory path for ~30 cycles; 39 of them back to back at a barrier
+  // stalled every wave for 1.2 k cycles per frame, under MFMAs they are free)
+  auto prefetch_frame = [&](int nf) {
     constexpr int A2_PIECES = (16 * P2 * 4 + 1023) / 1024, PX_PIECES = (HW + 1023) / 1024,
-                  M3_PIECES = (32 * P + 1023) / 1024, I2_PIECES = (16 * P + 1023) / 1024;
+                  M3_PIECES = FAST ? 0 : (32 * P + 1023) / 1024, I2_PIECES = (16 * P + 1023) / 1024;
     const char* a2src = reinterpret_cast<const char*>(p.st_a2 + (long)nf * 16 * P2);
     const char* pxsrc = reinterpret_cast<const char*>(p.R + (long)nf * HW);
     const char* m3src = reinterpret_cast<const char*>(p.st_m3 + (long)nf * 32 * P);
     const char* i2src = reinterpret_cast<const char*>(p.st_i2 + (long)nf * 16 * P);
-    for (int piece = wvu + NWV * part; piece < A2_PIECES + PX_PIECES + M3_PIECES + I2_PIECES; piece += NWV * nparts) {
+    if (FAST) ss_dma16(m3src + (wvu * 64 + lane) * 16, (unsigned)(m3_own_dst() * 4));
+    for (int piece = wvu; piece < A2_PIECES + PX_PIECES + M3_PIECES + I2_PIECES; piece += NWV) {
       int q = piece;
       if (q < A2_PIECES) {
         const int off = q * 1024 + lane * 16;
@@ -279,20 +300,11 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       const int off = q * 1024 + lane * 16;
       if (off < 16 * P) ss_dma16(i2src + off, (unsigned)(STG_I2 * 4 + q * 1024));
     }
-    if (wvu == NWV - 1 && part == 0) {
-      if (lane < E) ss_dma4(p.d_out + (long)nf * p.ld_dout + lane, (unsigned)((LL::o_misc) * 4));
-      if (lane < 24) ss_dma4(p.st_feat + (long)nf * ST_FEAT + lane, (unsigned)((LL::o_misc + 64) * 4));
-      if (lane < 24) ss_dma4(p.st_feat + (long)nf * ST_FEAT + 24 + lane, (unsigned)((LL::o_misc + 448) * 4));
-      if (lane < 2) ss_dma4(p.st_feat + (long)nf * ST_FEAT + 48 + lane, (unsigned)((LL::o_misc + 128) * 4));  // mean, std
-    }
+    if (!FAST) misc_dma(nf);
   };
   constexpr int NM3 = (2 * P + NT - 1) / NT;  // 16-byte mask items (pixel, channel half) per thread
-  // top1: after the barrier behind which every wave's DMA pieces have landed.  Mask bytes into registers (the dy3 image is
-  // about to be written over their staging area), d feat, the fc gradients' share of this frame, the grey-level table.
-  auto top1 = [&](uint4 (&m3w)[NM3]) {
-#pragma unroll
-    for (int k = 0; k < NM3; ++k)
-      m3w[k] = (tid + k * NT < 2 * P) ? reinterpret_cast<const uint4*>(lds + STG_M3)[tid + k * NT] : uint4{0, 0, 0, 0};
+  // ---- the pieces of a frame's front
+  auto front_dfeat = [&]() {  // needs the d_out row and the averaged features (landed and published)
     if (tid < 24 * 16) {  // d feat[c] = sum_e d_out[e] * Wfc[e][c]: 16 lanes per channel (one DPP row), then a shuffle tree
       float sacc = 0.f;
 #pragma unroll
@@ -309,25 +321,16 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
     }
     if (tid < E) accbfc += s_dout[tid];
+  };
+  auto front_table = [&]() {
     if (tid < 256) {  // the forward's xn = (u/255 - mu)/sd, once per grey level instead of once per pixel
       const float rr = (float)tid / 255.0f;
       s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
     }
   };
-  // top2: after the barrier behind which every mask byte is in a register and d feat is published.
-  // dy3 = mask3 * dfeat / P, pixel-major [haloed pixel][24 channels]: the halo pixels back to zero (the planes held the
-  // staged mask), every interior pixel written: an item is 16 mask bytes = 16 channels of one pixel -> four (two for
-  // channels 16..23) 16-byte stores
-  auto top2 = [&](const uint4 (&m3w)[NM3]) {
-    for (int q = tid; q < (2 * S2 + 2 * G::H4) * 6; q += NT) {
-      const int hp = q / 6, part = q - 6 * hp;
-      int pixh;
-      if (hp < S2) pixh = hp;                                           // top row
-      else if (hp < 2 * S2) pixh = (G::H4 + 1) * S2 + (hp - S2);        // bottom row
-      else if (hp < 2 * S2 + G::H4) pixh = (hp - 2 * S2 + 1) * S2;      // left column
-      else pixh = (hp - 2 * S2 - G::H4 + 1) * S2 + W4 + 1;              // right column
-      reinterpret_cast<f32x4*>(dy3h + pixh * 24)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  // dy3 = mask3 * dfeat / P, pixel-major [haloed pixel][24 channels]: an item is 16 mask bytes = 16 channels of one
+  // pixel -> four (two for channels 16..23) 16-byte stores
+  auto front_fill = [&](const uint4 (&m3w)[NM3]) {
 #pragma unroll
     for (int k = 0; k < NM3; ++k) {
       const int item = tid + k * NT;
@@ -347,16 +350,70 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         }
       }
     }
+  };
+  auto front_gb3 = [&]() {
     if (tid < 24) s_gb3[tid] += s_dfeat[tid] * s_cnt[tid];  // d b3 = d feat x (number of positive conv3 outputs)
   };
+  // generic path, top1: after the barrier behind which every wave's DMA pieces have landed.  Mask bytes into registers
+  // (the dy3 image is about to be written over their staging area), d feat, the grey-level table.
+  auto top1 = [&](uint4 (&m3w)[NM3]) {
+#pragma unroll
+    for (int k = 0; k < NM3; ++k)
+      m3w[k] = (tid + k * NT < 2 * P) ? reinterpret_cast<const uint4*>(lds + STG_M3)[tid + k * NT] : uint4{0, 0, 0, 0};
+    front_dfeat();
+    front_table();
+  };
+  // generic path, top2: after the barrier behind which every mask byte is in a register and d feat is published: the halo
+  // pixels of the dy3 image back to zero (the planes held the staged mask), every interior pixel written
+  auto top2 = [&](const uint4 (&m3w)[NM3]) {
+    for (int q = tid; q < (2 * S2 + 2 * G::H4) * 6; q += NT) {
+      const int hp = q / 6, part = q - 6 * hp;
+      int pixh;
+      if (hp < S2) pixh = hp;                                           // top row
+      else if (hp < 2 * S2) pixh = (G::H4 + 1) * S2 + (hp - S2);        // bottom row
+      else if (hp < 2 * S2 + G::H4) pixh = (hp - 2 * S2 + 1) * S2;      // left column
+      else pixh = (hp - 2 * S2 - G::H4 + 1) * S2 + W4 + 1;              // right column
+      reinterpret_cast<f32x4*>(dy3h + pixh * 24)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    front_fill(m3w);
+    front_gb3();
+  };
+  // FAST path: one wave's share of the front, no barrier.  Its own DMA pieces have landed (s_waitcnt), its mask bytes come
+  // back out of the cells of its own pixels, which it then fills; it zeroes the halo cells of its own rows (waves 0 and
+  // NWV - 1 the top / bottom row as well); d feat was published a stage ago
+  auto front_own = [&]() {
+    ss_dma_wait();
+    uint4 m3w[NM3];
+    m3w[0] = *reinterpret_cast<const uint4*>(lds + m3_own_dst() + lane * 4);
+    constexpr int RPW = P / NWV / W4;  // rows of the pooled-2 grid per wave
+    for (int q = lane; q < 2 * RPW * 6; q += 64) {  // left / right halo pixel of each own row, six 16-byte pieces each
+      const int hp = q / 6, part = q - 6 * hp;
+      const int pixh = (RPW * wvu + (hp >> 1) + 1) * S2 + ((hp & 1) ? W4 + 1 : 0);
+      reinterpret_cast<f32x4*>(dy3h + pixh * 24)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (wvu == 0 || wvu == NWV - 1) {
+      const int row = wvu == 0 ? 0 : G::H4 + 1;
+      for (int q = lane; q < S2 * 6; q += 64) reinterpret_cast<f32x4*>(dy3h + row * S2 * 24)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    front_fill(m3w);
+    front_table();
+    front_gb3();
+  };
   if ((int)blockIdx.x < p.N) {  // the first frame's inputs and front, outside the pipeline
-    prefetch_frame(blockIdx.x, 0, 1);
+    prefetch_frame(blockIdx.x);
+    if (FAST) misc_dma(blockIdx.x);
     ss_dma_wait();
     __syncthreads();
-    uint4 m3w[NM3];
-    top1(m3w);
-    __syncthreads();
-    top2(m3w);
+    if (FAST) {
+      front_dfeat();
+      __syncthreads();
+      front_own();
+    } else {
+      uint4 m3w[NM3];
+      top1(m3w);
+      __syncthreads();
+      top2(m3w);
+    }
     __syncthreads();
   }
 
@@ -375,6 +432,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // the pooled-1 map arrives by LDS-DMA (1 KB per wave instruction) under S1 / S2, one share per row iteration; it is
     // waited for before S3.  a1h held da1 of the previous frame, dead since barrier E
     auto a1_dma = [&](int part, int nparts) {
+      // FAST: the next frame's d_out row / features / statistics are requested here (d feat is made at the phase switch)
+      if (FAST && part == 0 && n + (int)gridDim.x < p.N) misc_dma(n + gridDim.x);
       constexpr int BYTES = 8 * P1 * 4;
       const char* src = reinterpret_cast<const char*>(p.st_a1 + (long)n * 8 * P1);
       for (int piece = wvu + NWV * part; piece * 1024 < BYTES; piece += NWV * nparts) {
@@ -384,7 +443,13 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     };
     if (s1_half == 0) s1_rows<G, 0>(dy3h, a2h, s1_kg, i, g, acc3, a1_dma);
     else s1_rows<G, 1>(dy3h, a2h, s1_kg, i, g, acc3, a1_dma);
-    STAMP_SYNC(3);
+    // S2 writes da2m, whose planes hold the staged pixels / argmaxes that the frame top copies out, and (shapes whose W3
+    // is re-staged per frame) reads what stage_w3 wrote there: no wave starts S2 before every wave has made its copies.
+    // (Found the hard way: this used to be a barrier of the diagnostic build only.  hipcc sinks the frame top's LDS read of
+    // the pixels to the end of S1 -- legal for one wave -- where a faster wave's da2m stores overtook it: d W1, the only
+    // consumer, moved by up to 4e-2 relative between identical launches; tools/bwd_determinism.py now checks that.)
+    __syncthreads();
+    STAMP(3);
     // pool-1 argmaxes for the phase switch: fetched here so that HBM answers under S2
     uint4 ix1[NI1];
 #pragma unroll
@@ -462,8 +527,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         }
       }
     }
+    if (FAST && wvu == NWV - 1) ss_dma_wait();  // the next frame's d_out row has landed: published by barrier D
     __syncthreads();  // D: dy3h / a2h / w3 are dead, da2m is complete
     STAMP(4);
+    if (FAST && n + (int)gridDim.x < p.N) front_dfeat();  // (s_dfeat of THIS frame was last read in S5 of the previous one)
 
     // ---------------- T: phase switch.  Every thread takes its share of (da2m, argmax) into registers, then the
     // phase-2 images are written over the phase-1 area: dense dy2, the normalised frame (haloed), pool-1 argmaxes.
@@ -576,7 +643,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         SS_SCHED_FENCE();
       }
     }
-    STAMP_SYNC(6);
+    __syncthreads();  // S4 overwrites a1 with da1 in place; S3 reads a1 rows of the neighbouring waves' bands as well
+    STAMP(6);
     // ---------------- S4 + S5: da1 for rows y, y+1 of a 16-pixel column block (two blocks per pass share the W2
     // table reads); dW1 / db1 in the epilogue
     {
@@ -688,6 +756,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       constexpr int KP = 4;                  // k-steps per pass: 3 KP LDS reads, 2 KP selects, 2 KP MFMAs
       constexpr int PPR = W2 / 4 / KP, NP = rows * PPR;
       constexpr int FRONT = NP - (NP + 3) / 4;  // pass after which the next frame's front runs (the DMA has ~3/4 of S5 to land)
+      constexpr int FRONT_A = NP / 2;           // FAST: waves 0 .. NWV/2 - 1 run theirs here
       const bool has_next = n + (int)gridDim.x < p.N;
       // fully unrolled, the next pass's reads issued before this pass's selects and MFMAs (see S3)
       float d[2][KP], xv[2][KP];
@@ -697,7 +766,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         if (ps + 1 < NP) {
           const int nx = ps + 1, r = nx / PPR, xq = KP * (nx % PPR), buf = nx & 1;
           // dy2 / dy3 areas are dead (S4 is through): the next frame's inputs are requested with the first pass
-          if (nx == 0 && has_next) prefetch_frame(n + gridDim.x, 0, 1);
+          if (nx == 0 && has_next) prefetch_frame(n + gridDim.x);
 #pragma unroll
           for (int u = 0; u < KP; ++u) {
             d[buf][u] = dp[r * S1 + (xq + u) * 4];
@@ -723,7 +792,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           }
         }
         SS_SCHED_FENCE();
-        if (ps == FRONT - 1 && has_next) {  // (wave-uniform; the reads of pass FRONT are already in flight)
+        if (FAST) {  // the two waves of a SIMD (w, w + NWV / 2) take different passes
+          if (ps == FRONT_A - 1 && has_next && wvu < NWV / 2) front_own();
+          if (ps == FRONT - 1 && has_next && wvu >= NWV / 2) front_own();
+        } else if (ps == FRONT - 1 && has_next) {  // (wave-uniform; the reads of pass FRONT are already in flight)
           ss_dma_wait();
           __syncthreads();  // F1: every wave's pieces of the next frame have landed
           uint4 m3w[NM3];

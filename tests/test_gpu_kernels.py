@@ -661,6 +661,35 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     assert_close("accumulate", G[4], 2 * leaves[CNN_KEYS[4]].grad, atol=6e-4 * float(leaves[CNN_KEYS[4]].grad.abs().max()),
                  rtol=1e-3)
 
+    # The frame PIPELINE (prefetch one frame ahead, the next frame's front inside the current frame's last stage) only
+    # runs when a workgroup walks several frames: cap the grid so that every workgroup takes 4+ frames, check the same
+    # references, then repeat the launch: identical launches may differ by the order of the float atomics only
+    # (a missing barrier once made d W1 move by 4e-2 between launches while every single-frame test passed).
+    cap = 16 if N > 100 else 3
+    L.call("ss_roi_cnn_set_max_workgroups", cap)
+    try:
+        out2 = torch.empty_like(out)
+        L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out2.data_ptr(), 32,
+               *[s.data_ptr() for s in st], n_a1, n_a2, n_i1, L.stream())
+        sync()
+        assert torch.equal(out2, out), "the forward output of a frame must not depend on which workgroup computes it"
+        runs = []
+        for _ in range(8):
+            G2 = [torch.zeros_like(p) for p in P]
+            L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
+                   n_a1, n_a2, n_i1, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G2], L.stream())
+            sync()
+            runs.append(G2)
+        for k, gg in zip(CNN_KEYS, runs[0]):
+            ref = leaves[k].grad
+            assert_close("walked grad " + k, gg, ref, atol=3e-4 * max(float(ref.abs().max()), 1e-3), rtol=1e-3)
+        for r in runs[1:]:
+            for k, g0, g1 in zip(CNN_KEYS, runs[0], r):
+                spread = float((g1 - g0).abs().max()) / max(float(g0.abs().max()), 1e-30)
+                assert spread < 2e-5, f"{k}: identical launches differ by {spread:.1e} of the largest entry"
+    finally:
+        L.call("ss_roi_cnn_set_max_workgroups", 0)
+
 
 # ------------------------------------------------------------------------------------- features / crop
 def _anchors(idxs):
