@@ -96,8 +96,8 @@ def step_gflop_per_clip(T, D, E, H, C, roi, mid=128, fwd_only=False):
     return 2.0 * (3 * fwd - T * conv1) / 1e9
 
 
-PMC_TRAFFIC = os.path.join("profiles", "round2_b_pmc_traffic.json")
-PMC_MFMA = os.path.join("profiles", "round2_b_pmc_mfma.json")
+PMC_TRAFFIC = os.path.join("profiles", "round2_c_pmc_traffic.json")
+PMC_MFMA = os.path.join("profiles", "round2_c_pmc_mfma.json")
 
 
 def pmc_mfma_busy(kernel_tag):
