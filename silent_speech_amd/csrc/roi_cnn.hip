@@ -341,18 +341,25 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
           }
           SS_SCHED_FENCE();
         }
+        // pooling epilogue, written for instruction count like conv1's: the window's four values sit in one lane
+        // (acc0 = row 2yp, acc1 = row 2yp + 1; column pairs 2e, 2e + 1), max first, ReLU once, argmax bits as lane masks
+        float* aw = a2 + i * P2 + (yp + 1) * S2 + 8 * xt + 2 * g + 1;
+        uint8_t* iw = i2s + (yp * W4 + 8 * xt + 2 * g) * 16 + i;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const float v00 = fmaxf(acc0[2 * e] + bias, 0.f), v01 = fmaxf(acc0[2 * e + 1] + bias, 0.f);
-          const float v10 = fmaxf(acc1[2 * e] + bias, 0.f), v11 = fmaxf(acc1[2 * e + 1] + bias, 0.f);
-          float best = v00;
-          int bi = 0;
-          if (v01 > best) { best = v01; bi = 1; }
-          if (v10 > best) { best = v10; bi = 2; }
-          if (v11 > best) { best = v11; bi = 3; }
-          const int pxx = 8 * xt + 2 * g + e;
-          a2[i * P2 + (yp + 1) * S2 + pxx + 1] = best;
-          i2s[(yp * W4 + pxx) * 16 + i] = (uint8_t)bi;
+          const float x00 = acc0[2 * e] + bias, x01 = acc0[2 * e + 1] + bias;
+          const float x10 = acc1[2 * e] + bias, x11 = acc1[2 * e + 1] + bias;
+          const unsigned long long c0 = __ballot(x01 > x00), c1 = __ballot(x11 > x10);
+          const float m0 = fmaxf(x00, x01), m1 = fmaxf(x10, x11);
+          const unsigned long long t1 = __ballot(m1 > m0);  // strictly: ties go to the first in row-major order
+          const unsigned long long b0 = (t1 & c1) | (~t1 & c0);
+          const float best = fmaxf(fmaxf(m0, m1), 0.f);
+          int hi, bi;
+          unsigned long long carry_out;
+          asm("v_cndmask_b32_e64 %0, 0, 2, %1" : "=v"(hi) : "s"(t1));
+          asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(bi), "=s"(carry_out) : "v"(hi), "s"(b0));
+          aw[e] = best;
+          iw[16 * e] = (uint8_t)bi;
         }
       }
     }
@@ -395,13 +402,16 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float va = acca[r] + bias_a, vb = accb[r] + bias_b;
-          if (va > 0.f) { fa += va; ca += 1.f; }
-          if (vb > 0.f) { fb += vb; cb += 1.f; }
+          const bool pa = va > 0.f, pb = vb > 0.f;
+          fa += fmaxf(va, 0.f);  // (one v_max + v_add instead of compare, select, add)
+          fb += fmaxf(vb, 0.f);
+          ca += pa ? 1.f : 0.f;
+          cb += pb ? 1.f : 0.f;
           if (stash) {  // D row 4g+r = pixel, column i = channel: pixel-major bytes
             uint8_t* mp = m3s + (16 * u + 4 * g + r) * 32;
-            mp[i] = va > 0.f;
+            mp[i] = pa;
             if (i < 8) {
-              mp[16 + i] = vb > 0.f;
+              mp[16 + i] = pb;
               mp[24 + i] = 0;
             }
           }
