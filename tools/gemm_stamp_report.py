@@ -2,7 +2,10 @@
 """Diagnostic: where a weight-gradient GEMM workgroup spends its life (needs the -DSS_STAMP build).
 
 Thread 0 of workgroups 0..255 accumulates clock64() deltas: prologue (first fetch -> LDS -> barrier), per k tile:
-fetch issue + LDS reads + MFMAs, LDS store of the next tile, barrier; epilogue (atomics, drained)."""
+fetch issue + LDS reads + MFMAs, LDS store of the next tile, barrier; epilogue (atomics, drained).
+
+The timers sit in the REGISTER-STAGED kernel (gemm_f32_kernel); the LDS-DMA ring kernel that the step uses carries none, so
+this tool forces the register-staged one (SS_GEMM_NO_DMA=1): it explains that kernel, not the production GEMM times."""
 import ctypes as C
 import os
 import sys
@@ -12,6 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["SS_GEMM_NO_DMA"] = "1"
 os.environ.setdefault("SS_HOTPATH_LIB", os.path.join(ROOT, "silent_speech_amd", "libss_hotpath_stamp.so"))
 from silent_speech_amd import _lib as L  # noqa: E402
 from silent_speech_amd import engine as E  # noqa: E402
