@@ -243,12 +243,14 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
 #pragma unroll
           for (int q = 0; q < UC; ++q) av[q][kk] = (ap + aoff1[kk])[16 * q];
         SS_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);  // conv1's twelve MFMAs ahead of the partner's vector work, its own epilogue not
 #pragma unroll
         for (int q = 0; q < UC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
           for (int q = 0; q < UC; ++q) acc[q] = mfma16(av[q][kk], bw1[kk], acc[q]);
+        __builtin_amdgcn_s_setprio(0);
         SS_SCHED_FENCE();
       };
       auto epi = [&](int ps, const f32x4 (&acc)[UC]) {
@@ -319,6 +321,11 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       constexpr int XT = W2 / 16;
       constexpr int units = (H2 / 2) * XT;
       const float bias = s_b2[i];
+      // The CU's other workgroup is usually in a different stage: while this wave streams MFMAs its issue slots must not
+      // go to the partner's vector instructions (each holds the SIMD's issue port for 4+ cycles and the in-order wave
+      // then misses its MFMA slot).  Raised priority through the MFMA-dense stages, the default for epilogue-heavy conv1,
+      // the statistics and the copies: 472 -> 462 us per launch, the largest single gain of the round for two lines.
+      __builtin_amdgcn_s_setprio(2);
       for (int u = wv; u < units; u += NWV) {
         const int yp = u / XT, xt = u % XT;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -363,6 +370,7 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     STAMP(2);
     if (stash) {
@@ -379,6 +387,7 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       float fa = 0.f, fb = 0.f;  // per-lane partial channel sums (tile 0: n=i, tile 1: n=16+i)
       float ca = 0.f, cb = 0.f;  // and counts of positive outputs
       const float bias_a = s_b3[i], bias_b = (i < 8) ? s_b3[16 + i] : 0.f;
+      __builtin_amdgcn_s_setprio(2);
       for (int u = wv; u < tiles; u += NWV) {
         const int pa = 16 * u + i;
         const float* base = a2 + g * P2 + (pa / W4) * S2 + (pa % W4);
@@ -417,6 +426,7 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
           }
         }
       }
+      __builtin_amdgcn_s_setprio(0);
       // reduce over the 4 lane groups (rows of the tiles), then over waves through LDS
       fa += __shfl_xor(fa, 16, 64); fa += __shfl_xor(fa, 32, 64);
       fb += __shfl_xor(fb, 16, 64); fb += __shfl_xor(fb, 32, 64);
