@@ -20,6 +20,14 @@
 //
 // Weight-gradient partial sums stay in registers for the whole frame walk (K = pixels split over the
 // 8 waves) and are reduced through LDS, then one float atomic per element per workgroup, at the end.
+//
+// Frame schedule (a frame starts at S1; seven workgroup barriers):
+//   [E] pixels / pool-2 argmaxes out of staging | S1 (+ the pooled-1 map's DMA, + the NEXT frame's d_out row) | barrier |
+//   S2 | [D] d feat of the next frame, phase switch T (two barriers) | S3 | barrier | S4 | barrier |
+//   S5 (+ the next frame's inputs by DMA with its first pass, + the next frame's front -- dy3 image, grey-level table --
+//   per wave, without a barrier, the two waves of a SIMD at different passes) | [E]
+// Every MFMA stage issues its operand reads one pass ahead of the MFMAs: the two waves of a SIMD leave each barrier
+// together and run in lockstep, so a wave's LDS latency is not covered by its partner.
 #include <type_traits>
 #include "ss_common.h"
 #include "roi_cnn_geom.h"
@@ -714,10 +722,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           }
         };
         {
-          const bool top0 = y0_ == 0, top1 = y1_ == 0, bot0 = y0_ == H2 - 2, bot1 = y1_ == H2 - 2;
-          if (!(top0 || top1 || bot0 || bot1)) taps(std::integral_constant<int, 0>{});
-          else if (top0 && top1 && !bot0 && !bot1) taps(std::integral_constant<int, 1>{});
-          else if (bot0 && bot1 && !top0 && !top1) taps(std::integral_constant<int, 2>{});
+          const bool first0 = y0_ == 0, first1 = y1_ == 0, last0 = y0_ == H2 - 2, last1 = y1_ == H2 - 2;
+          if (!(first0 || first1 || last0 || last1)) taps(std::integral_constant<int, 0>{});
+          else if (first0 && first1 && !last0 && !last1) taps(std::integral_constant<int, 1>{});
+          else if (last0 && last1 && !first0 && !first1) taps(std::integral_constant<int, 2>{});
           else taps(std::integral_constant<int, 3>{});
         }
         // D: row 4g+r -> pixel x0+4g+r of row y+s ; column i -> channel c.  Mask by a1 > 0 and leave da1 IN PLACE of
