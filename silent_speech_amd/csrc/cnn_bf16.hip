@@ -14,6 +14,8 @@
 // Replaces /root/reference/train_model_official.py:286-291 (normalise) and :212-229 (CNN) for the wider model.
 #include "cnn_bf16.h"
 
+extern int ss_cnn_max_wgs;  // roi_cnn.hip: test hook, workgroups per launch (0 = one per CU)
+
 namespace {
 using namespace c5;
 
@@ -350,7 +352,8 @@ int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s)
   if (lds_bytes > 160 * 1024) return SS_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
     return SS_ERR_LAUNCH;
-  const int grid = N < 256 ? N : 256;
+  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256;  // (the cap makes a test walk many frames per workgroup)
+  const int grid = N < cap ? N : cap;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();
 }

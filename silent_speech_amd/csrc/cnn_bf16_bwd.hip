@@ -17,6 +17,8 @@
 //   conv1 wgrad: 1 input channel -- a GEMM on the pooled grid against the 4 x 4 input patch under every pool window.
 #include "cnn_bf16.h"
 
+extern int ss_cnn_max_wgs;  // roi_cnn.hip: test hook, workgroups per launch (0 = one per CU)
+
 namespace {
 using namespace c5;
 
@@ -613,7 +615,8 @@ int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s,
   if (lds_bytes > 0 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
     return SS_ERR_LAUNCH;
-  const int grid = N < 256 * wgs_per_cu ? N : 256 * wgs_per_cu;
+  const int cap = (ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256) * wgs_per_cu;  // (the cap makes a test walk many frames per workgroup)
+  const int grid = N < cap ? N : cap;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();
 }

@@ -228,8 +228,18 @@ def normalise_like_kernel(R, standardize=True):
     return torch.from_numpy(xn), torch.from_numpy(mus), torch.from_numpy(sds)
 
 
+@pytest.fixture(params=[0, 7], ids=["grid=CUs", "grid=7"])
+def wg_cap(L, request):
+    """The CNN kernels are persistent: a workgroup walks its share of the frames and fetches the next frame / band while it
+    computes the current one.  With the default grid (one or two workgroups per CU) a test of 300 frames walks two frames on
+    a few workgroups; capped at 7 workgroups every one of them walks 40+ (the frame pipeline is what the bench runs)."""
+    L.call("ss_roi_cnn_set_max_workgroups", request.param)
+    yield request.param
+    L.call("ss_roi_cnn_set_max_workgroups", 0)
+
+
 @pytest.mark.parametrize("N,standardize", [(3, 1), (300, 1), (4, 0)])
-def test_c5_conv1_fwd(L, N, standardize):
+def test_c5_conv1_fwd(L, N, standardize, wg_cap):
     g = torch.Generator().manual_seed(N)
     R = torch.randint(0, 256, (N, 96, 96), generator=g, dtype=torch.uint8)
     R[0] = 7                     # constant frame: std clamp, every normalised pixel is exactly 0
@@ -262,7 +272,7 @@ def test_c5_conv1_fwd(L, N, standardize):
 
 
 @pytest.mark.parametrize("layer,N", [(2, 2), (2, 270), (3, 3), (3, 300)])
-def test_c5_conv_fwd(L, layer, N):
+def test_c5_conv_fwd(L, layer, N, wg_cap):
     cin, cout = C5[layer - 1], C5[layer]
     hw = 96 >> (layer - 1)
     g = torch.Generator().manual_seed(layer * 100 + N)
@@ -282,7 +292,7 @@ def test_c5_conv_fwd(L, layer, N):
 
 
 @pytest.mark.parametrize("N", [3, 300])
-def test_c5_conv_last_fwd(L, N):
+def test_c5_conv_last_fwd(L, N, wg_cap):
     g = torch.Generator().manual_seed(N)
     E, ld = 64, 148
     a3 = bf(torch.relu(torch.randn(N, 64, 12, 12, generator=g)))
@@ -314,7 +324,7 @@ def test_c5_conv_last_fwd(L, N):
 
 
 @pytest.mark.parametrize("layer,N", [(2, 2), (2, 270), (3, 3), (3, 300)])
-def test_c5_conv_bwd(L, layer, N):
+def test_c5_conv_bwd(L, layer, N, wg_cap):
     cin, cout = C5[layer - 1], C5[layer]
     hw = 96 >> (layer - 1)
     g = torch.Generator().manual_seed(layer * 10 + N)
@@ -341,7 +351,7 @@ def test_c5_conv_bwd(L, layer, N):
 
 
 @pytest.mark.parametrize("N", [3, 300])
-def test_c5_conv_last_bwd(L, N):
+def test_c5_conv_last_bwd(L, N, wg_cap):
     g = torch.Generator().manual_seed(N + 5)
     E, ld = 64, 148
     a3 = bf(torch.relu(torch.randn(N, 64, 12, 12, generator=g)))
@@ -379,7 +389,7 @@ def test_c5_conv_last_bwd(L, N):
 
 
 @pytest.mark.parametrize("N", [2, 300])
-def test_c5_conv1_wgrad(L, N):
+def test_c5_conv1_wgrad(L, N, wg_cap):
     g = torch.Generator().manual_seed(N + 11)
     R = torch.randint(0, 256, (N, 96, 96), generator=g, dtype=torch.uint8)
     xn, mu, sd = normalise_like_kernel(R)
@@ -401,7 +411,7 @@ def test_c5_conv1_wgrad(L, N):
 
 
 @pytest.mark.parametrize("N", [3, 300])
-def test_c5_conv12_fused_forward_and_recomputing_backward(L, N):
+def test_c5_conv12_fused_forward_and_recomputing_backward(L, N, wg_cap):
     """The fused forms the engine runs: conv1 + conv2 in one kernel (the pooled conv1 map stays in LDS), layer 2's weight gradient
     with that map recomputed from the frame, conv1's weight gradient with its pool winners recomputed -- against the same
     references as the per-layer kernels."""
