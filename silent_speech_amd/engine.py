@@ -83,6 +83,9 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=Fal
 _SPLITK_TARGET = int(os.environ.get("SS_SPLITK_TARGET", "768"))
 
 
+_DX_SPLIT_CAP = int(os.environ.get("SS_DX_SPLITS", "2"))  # K slices of a d layer_in GEMM with few output tiles (1 = off)
+
+
 def split_k(M, N, K, batch=1, target_wgs=_SPLITK_TARGET):
     """K slices for a weight-gradient GEMM (tiny M x N, huge K): enough workgroups to fill the chip ~3x over."""
     tiles = -(-M // 128) * -(-N // 64) * batch
@@ -381,8 +384,12 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
             # nobody asked for d X: only the ROI-embedding columns of d Z feed the CNN backward
             c0 = cfg.x_dim if (l == 0 and cfg.use_roi and d_X is None) else 0
+            # few output tiles (layer 0 with only the ROI columns wanted: 120 workgroups for 256 CUs): slice K as well --
+            # the destination is summed atomically anyway
+            tiles = -(-N // 128) * -(-(K - c0) // 64) * 2
+            dx_splits = max(1, min(_DX_SPLIT_CAP, 768 // tiles, (3 * H) // 96))
             gemm(1, 0, N, K - c0, 3 * H, ws.dG[l].data_ptr(), 4 * H, _addr(P[wi], c0), K, dst + 4 * c0, ld_dst,
-                 accumulate=True, atomic=True, tag="gemm_gru_dX", batch=2,
+                 accumulate=True, atomic=True, tag="gemm_gru_dX", batch=2, splits=dx_splits,
                  strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0, 0))
         if SIDE_AFTER_DX and l > 0:
             side_work()
