@@ -579,6 +579,18 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         reinterpret_cast<f32x4*>(dy2)[(y * W2H + (side ? W2 + 1 : 0)) * 4 + part] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       STAMP(10);
+      STAMP(8);
+    }
+    ss_dma_wait();    // this wave's share of the pooled-1 map has landed in LDS
+    __syncthreads();  // T done
+    STAMP(5);
+
+    // The normalised frame (interior by table lookup, halo cells zeroed: the area held phase-1 data) and the pool-1 argmax
+    // bytes are needed by S5 only, and every thread makes them from its OWN registers (px, ix1) and the grey-level table:
+    // like the next frame's front they run per wave, without a barrier, inside S3 -- the two waves of a SIMD at
+    // different passes, one wave's table lookups and LDS stores under its partner's MFMAs (they were 2.4 k cycles of
+    // the phase switch, with every wave storing and nobody multiplying).
+    auto xh_own = [&]() {
       // normalised frame: interior by table lookup, halo cells zeroed (the area held phase-1 data)
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
@@ -601,7 +613,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         else cell = (q - 2 * XS - H + 1) * XS + W + 1;          // right column (cells beyond it are never read)
         xh[cell] = 0.f;
       }
-      STAMP(8);
 #pragma unroll
       for (int k = 0; k < NI1; ++k)
         if ((tid + k * NT) * 16 < 8 * I1S) {  // 16 stash bytes -> their plane's place in the padded LDS layout
@@ -609,11 +620,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           uint32_t* dst = reinterpret_cast<uint32_t*>(i1b + q + 4 * (q / I1S));
           dst[0] = ix1[k].x; dst[1] = ix1[k].y; dst[2] = ix1[k].z; dst[3] = ix1[k].w;
         }
-    }
-    ss_dma_wait();    // this wave's share of the pooled-1 map has landed in LDS
-    __syncthreads();  // T done
-    STAMP(5);
-
+    };
     // ---------------- S3: dW2.  A wave owns whole rows of the pooled-1 grid: one A base and five B bases per wave,
     // everything else is an immediate offset (VALU work between MFMAs is not hidden by them).  The two waves of a SIMD
     // leave the barrier together and then run in lockstep -- both read, both multiply -- so a wave's operand reads are
@@ -649,6 +656,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
             for (int nt = 0; nt < 5; ++nt) acc2[nt] = mfma16(a[buf][u], b[buf][u][nt], acc2[nt]);
         }
         SS_SCHED_FENCE();
+        if (ps == NP / 4 && wvu < NWV / 2) xh_own();          // (wave-uniform; the next pass's reads are in flight)
+        if (ps == (3 * NP) / 4 && wvu >= NWV / 2) xh_own();
       }
     }
     __syncthreads();  // S4 overwrites a1 with da1 in place; S3 reads a1 rows of the neighbouring waves' bands as well
