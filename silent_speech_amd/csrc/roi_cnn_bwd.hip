@@ -538,7 +538,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     if (FAST && wvu == NWV - 1) ss_dma_wait();  // the next frame's d_out row has landed: published by barrier D
     __syncthreads();  // D: dy3h / a2h / w3 are dead, da2m is complete
     STAMP(4);
-    if (FAST && n + (int)gridDim.x < p.N) front_dfeat();  // (s_dfeat of THIS frame was last read in S5 of the previous one)
 
     // ---------------- T: phase switch.  Every thread takes its share of (da2m, argmax) into registers, then the
     // phase-2 images are written over the phase-1 area: dense dy2, the normalised frame (haloed), pool-1 argmaxes.
@@ -573,11 +572,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           d1[16 * W2H] = o == 3 - par ? v : 0.f;
         }
       }
-      // the zero columns of dy2 (the area held phase-1 data)
-      for (int q = tid; q < 2 * H2 * 4; q += NT) {
-        const int y = q >> 3, side = (q >> 2) & 1, part = q & 3;
-        reinterpret_cast<f32x4*>(dy2)[(y * W2H + (side ? W2 + 1 : 0)) * 4 + part] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
       STAMP(10);
       STAMP(8);
     }
@@ -589,7 +583,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // bytes are needed by S5 only, and every thread makes them from its OWN registers (px, ix1) and the grey-level table:
     // like the next frame's front they run per wave, without a barrier, inside S3 -- the two waves of a SIMD at
     // different passes, one wave's table lookups and LDS stores under its partner's MFMAs (they were 2.4 k cycles of
-    // the phase switch, with every wave storing and nobody multiplying).
+    // the phase switch, with every wave storing and nobody multiplying).  The zero columns of dy2 and the next frame's
+    // d feat ride along.
     auto xh_own = [&]() {
       // normalised frame: interior by table lookup, halo cells zeroed (the area held phase-1 data)
 #pragma unroll
@@ -620,6 +615,14 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           uint32_t* dst = reinterpret_cast<uint32_t*>(i1b + q + 4 * (q / I1S));
           dst[0] = ix1[k].x; dst[1] = ix1[k].y; dst[2] = ix1[k].z; dst[3] = ix1[k].w;
         }
+      // the zero columns of dy2 (the area held phase-1 data): S3 reads interior columns only, S4 is behind a barrier
+      for (int q = tid; q < 2 * H2 * 4; q += NT) {
+        const int y = q >> 3, side = (q >> 2) & 1, part = q & 3;
+        reinterpret_cast<f32x4*>(dy2)[(y * W2H + (side ? W2 + 1 : 0)) * 4 + part] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      // FAST: d feat of the NEXT frame (its d_out row landed before barrier D; s_dfeat of THIS frame was last read in S5 of
+      // the previous one, the new value is read in S5 of this one, two barriers on)
+      if (FAST && n + (int)gridDim.x < p.N) front_dfeat();
     };
     // ---------------- S3: dW2.  A wave owns whole rows of the pooled-1 grid: one A base and five B bases per wave,
     // everything else is an immediate offset (VALU work between MFMAs is not hidden by them).  The two waves of a SIMD
