@@ -23,9 +23,10 @@
 //
 // Frame schedule (a frame starts at S1; seven workgroup barriers):
 //   [E] pixels / pool-2 argmaxes out of staging | S1 (+ the pooled-1 map's DMA, + the NEXT frame's d_out row) | barrier |
-//   S2 | [D] d feat of the next frame, phase switch T (two barriers) | S3 | barrier | S4 | barrier |
-//   S5 (+ the next frame's inputs by DMA with its first pass, + the next frame's front -- dy3 image, grey-level table --
-//   per wave, without a barrier, the two waves of a SIMD at different passes) | [E]
+//   S2 | [D] phase switch T: the dy2 scatter (two barriers) | S3 (+ per wave, without a barrier, the two waves of a SIMD
+//   at different passes: the normalised frame, the pool-1 argmax bytes, dy2's zero columns, d feat of the next frame) |
+//   barrier | S4 | barrier | S5 (+ the next frame's inputs by DMA with its first pass, + the next frame's front -- dy3
+//   image, grey-level table -- per wave in the same way) | [E]
 // Every MFMA stage issues its operand reads one pass ahead of the MFMAs: the two waves of a SIMD leave each barrier
 // together and run in lockstep, so a wave's LDS latency is not covered by its partner.
 #include <type_traits>
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // the pooled-1 map arrives by LDS-DMA (1 KB per wave instruction) under S1 / S2, one share per row iteration; it is
     // waited for before S3.  a1h held da1 of the previous frame, dead since barrier E
     auto a1_dma = [&](int part, int nparts) {
-      // FAST: the next frame's d_out row / features / statistics are requested here (d feat is made at the phase switch)
+      // FAST: the next frame's d_out row / features / statistics are requested here (d feat is made inside S3)
       if (FAST && part == 0 && n + (int)gridDim.x < p.N) misc_dma(n + gridDim.x);
       constexpr int BYTES = 8 * P1 * 4;
       const char* src = reinterpret_cast<const char*>(p.st_a1 + (long)n * 8 * P1);
