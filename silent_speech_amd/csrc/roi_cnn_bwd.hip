@@ -258,8 +258,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   for (int k = 0; k < 4; ++k) wq[k] = (tid < 24 * 16 && (tid & 15) + 16 * k < E) ? p.wfc[((tid & 15) + 16 * k) * 24 + (tid >> 4)] : 0.f;
   // FAST (one 16-byte mask item per thread, whole rows of the pooled-2 grid per wave -- the 64x64 frames of BASELINE.json):
   // the front of the next frame needs no workgroup barrier.  Every wave fetches the 1 KB of mask bytes of ITS pixels into
-  // the dy3 cells of those same pixels, reads them back after its own s_waitcnt and fills its rows; d feat is made a stage
-  // earlier (its inputs are requested in S1).  The two waves of a SIMD then run their fronts at DIFFERENT passes of S5, one
+  // the dy3 cells of those same pixels, reads them back after its own s_waitcnt and fills its rows; d feat is made two stages
+  // earlier, inside S3 (its inputs are requested in S1).  The two waves of a SIMD then run their fronts at DIFFERENT passes of S5, one
   // wave's vector / LDS work under the other's MFMAs (tools/microbench/mfma_valu: a wave's v_fma stream does not slow the
   // partner's MFMAs at all); with barriers in it the front costs its full length wherever it is put.
   constexpr bool FAST = (2 * P == NT) && ((P / NWV) % W4 == 0);
