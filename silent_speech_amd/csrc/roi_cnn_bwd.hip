@@ -45,7 +45,8 @@ constexpr int NWV = NT / 64;
 template <class G>
 struct BwdLds {
   static constexpr int o_a1h = 0;                         // [8][P1]   haloed pooled-1 map; S4 overwrites it with da1
-  // phase area.  phase 1: a2h | dy3 (pixel-major [haloed pixel][24 ch]) | da2m | i2 (| w3) ;  phase 2: dy2 | xh | i1
+  // phase area.  phase 1: a2h | dy3 (pixel-major [haloed pixel][24 ch]) | (free: second staging area) | i2 (| w3) ;
+  // phase 2: dy2 | xh | i1
   static constexpr int o_ph = 8 * G::P1;
   static constexpr int o_dy3h = o_ph + 16 * G::P2;
   static constexpr int o_da2m = o_dy3h + 24 * G::P2;
@@ -81,7 +82,6 @@ struct BwdLds {
   static constexpr int o_stg2 = STG2_IN_DA2M ? o_da2m : o_misc + 512;
   static constexpr int total = o_misc + 512 + (STG2_IN_DA2M ? 0 : stg2_need);
   static_assert(total * 4 <= 160 * 1024, "LDS image exceeds a CU");
-  static constexpr int TV = (16 * G::P + NT - 1) / NT;    // (da2m, argmax) pairs per thread at the phase switch
 };
 
 struct CnnBwdParams {
@@ -162,7 +162,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float* a1h = lds + LL::o_a1h;
   float* a2h = lds + LL::o_ph;
   float* dy3h = lds + LL::o_dy3h;
-  float* da2m = lds + LL::o_da2m;
   uint8_t* i2b = reinterpret_cast<uint8_t*>(lds + LL::o_i2b);
   float* w3s = lds + LL::o_w3s;
   float* dy2 = lds + LL::o_ph;
@@ -452,11 +451,12 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     };
     if (s1_half == 0) s1_rows<G, 0>(dy3h, a2h, s1_kg, i, g, acc3, a1_dma);
     else s1_rows<G, 1>(dy3h, a2h, s1_kg, i, g, acc3, a1_dma);
-    // S2 writes da2m, whose planes hold the staged pixels / argmaxes that the frame top copies out, and (shapes whose W3
-    // is re-staged per frame) reads what stage_w3 wrote there: no wave starts S2 before every wave has made its copies.
-    // (Found the hard way: this used to be a barrier of the diagnostic build only.  hipcc sinks the frame top's LDS read of
-    // the pixels to the end of S1 -- legal for one wave -- where a faster wave's da2m stores overtook it: d W1, the only
-    // consumer, moved by up to 4e-2 relative between identical launches; tools/bwd_determinism.py now checks that.)
+    // S2's epilogue reads the pool-2 argmaxes that the frame top copied out of staging (and, for shapes whose W3 is
+    // re-staged per frame, S2 reads what stage_w3 wrote): no wave starts S2 before every wave has made its copies.
+    // (Found the hard way: this used to be a barrier of the diagnostic build only.  While S2 still wrote a da2m image over
+    // the staged pixels, hipcc sank the frame top's LDS read of them to the end of S1 -- legal for one wave -- where a
+    // faster wave's stores overtook it: d W1 moved by up to 4e-2 relative between identical launches;
+    // tools/bwd_determinism.py and the kernel test now check that.)
     __syncthreads();
     STAMP(3);
     // pool-1 argmaxes for the phase switch: fetched here so that HBM answers under S2
@@ -465,11 +465,16 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     for (int k = 0; k < NI1; ++k)
       if ((tid + k * NT) * 16 < 8 * I1S)
         ix1[k] = reinterpret_cast<const uint4*>(p.st_i1 + (long)n * 8 * I1S)[tid + k * NT];
-    // ---------------- S2: da2 (masked by a2 > 0) -> da2m ; db2.  Two pixel tiles per pass share the W3 reads.
+    // ---------------- S2: da2 (masked by a2 > 0), kept in registers ; db2.  Two pixel tiles per pass share the W3 reads.
+    constexpr int S2_IT = (P / 16 + 2 * NWV - 1) / (2 * NWV);  // passes of two pixel tiles per wave
+    float s2v[S2_IT][2][4];
+    int s2o[S2_IT][2][4];
     {
       constexpr int tiles = P / 16;
-#pragma unroll 1
-      for (int tile = wvu; tile < tiles; tile += 2 * NWV) {  // wvu: scalar loop control and tile arithmetic
+#pragma unroll
+      for (int it = 0; it < S2_IT; ++it) {
+        const int tile = wvu + 2 * NWV * it;  // wvu: scalar loop control and tile arithmetic
+        if (tile >= tiles) break;
         const int tile2 = tile + NWV;
         const bool two = tile2 < tiles;
         const int pp0 = 16 * tile + i, pp1 = 16 * (two ? tile2 : tile) + i;
@@ -516,12 +521,15 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           acc1x = mfma16(a18.y, b8.y, acc1x);
           SS_SCHED_FENCE();
         }
+        // the masked gradient and the pool-2 argmax of its four pixels stay in registers: this wave scatters them into the
+        // dense dy2 image itself, right behind barrier D (no da2m image, no second barrier)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pq = 16 * tile + 4 * g + r;
           const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
           const float v = av > 0.f ? acc0[r] : 0.f;
-          da2m[pq * 16 + i] = v;
+          s2v[it][0][r] = v;
+          s2o[it][0][r] = i2b[pq * 16 + i];
           accb2 += v;
         }
         if (two) {
@@ -530,51 +538,46 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
             const int pq = 16 * tile2 + 4 * g + r;
             const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
             const float v = av > 0.f ? acc1x[r] : 0.f;
-            da2m[pq * 16 + i] = v;
+            s2v[it][1][r] = v;
+            s2o[it][1][r] = i2b[pq * 16 + i];
             accb2 += v;
           }
         }
       }
     }
     if (FAST && wvu == NWV - 1) ss_dma_wait();  // the next frame's d_out row has landed: published by barrier D
-    __syncthreads();  // D: dy3h / a2h / w3 are dead, da2m is complete
+    __syncthreads();  // D: dy3h / a2h / w3 / the pool-2 argmaxes are dead
     STAMP(4);
 
-    // ---------------- T: phase switch.  Every thread takes its share of (da2m, argmax) into registers, then the
-    // phase-2 images are written over the phase-1 area: dense dy2, the normalised frame (haloed), pool-1 argmaxes.
+    // ---------------- T: phase switch.  The dense dy2 image is written over the phase-1 area (every read of it ended before
+    // barrier D): each wave expands the pixels it computed in S2 -- the value goes to its pool winner's cell, zeros to the
+    // other three.
     {
-      constexpr int TV = LL::TV;
-      float dv[TV];
-      int iv[TV];
+      constexpr int tiles = P / 16;
 #pragma unroll
-      for (int e = 0; e < TV; ++e) {
-        const int q = tid + e * NT;
-        dv[e] = (q < 16 * P) ? da2m[q] : 0.f;
-        iv[e] = (q < 16 * P) ? (int)i2b[q] : 0;
-      }
-      __syncthreads();  // every read of the phase-1 images is done before the first overwrite
-      STAMP(11);
+      for (int it = 0; it < S2_IT; ++it)
 #pragma unroll
-      for (int e = 0; e < TV; ++e) {
-        const int q = tid + e * NT;  // da2m and the argmaxes are pixel-major: q = pooled-2 pixel * 16 + channel
-        if (q < 16 * P) {
-          const int c = q & 15, r = q >> 4;
-          const int qy = r / W4, qx = r % W4;
-          // a wave's store covers 4 pixels x 16 channels and a dy2 pixel is 16 banks wide: pixels of odd qx write the
-          // right-hand window column first, so that every store spreads over all 32 banks (2-way instead of 4-way)
-          const int par = qx & 1;
-          float* d0 = dy2 + ((2 * qy) * W2H + 2 * qx + 1 + par) * 16 + c;
-          float* d1 = dy2 + ((2 * qy) * W2H + 2 * qx + 2 - par) * 16 + c;
-          const float v = dv[e];
-          const int o = iv[e];
-          d0[0] = o == par ? v : 0.f;
-          d1[0] = o == 1 - par ? v : 0.f;
-          d0[16 * W2H] = o == 2 + par ? v : 0.f;
-          d1[16 * W2H] = o == 3 - par ? v : 0.f;
+        for (int h = 0; h < 2; ++h) {
+          const int tile = wvu + 2 * NWV * it + NWV * h;
+          if (tile < tiles) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int pq = 16 * tile + 4 * g + r, qy = pq / W4, qx = pq % W4;
+              // a wave's store covers 4 pixels (one per lane group g) x 16 channels and a dy2 pixel is 16 banks wide: odd
+              // lane groups write the right-hand window column first, so that the 32 lanes of a half spread over all banks
+              const int par = g & 1;
+              float* d0 = dy2 + ((2 * qy) * W2H + 2 * qx + 1 + par) * 16 + i;
+              float* d1 = dy2 + ((2 * qy) * W2H + 2 * qx + 2 - par) * 16 + i;
+              const float v = s2v[it][h][r];
+              const int o = s2o[it][h][r];
+              d0[0] = o == par ? v : 0.f;
+              d1[0] = o == 1 - par ? v : 0.f;
+              d0[16 * W2H] = o == 2 + par ? v : 0.f;
+              d1[16 * W2H] = o == 3 - par ? v : 0.f;
+            }
+          }
         }
-      }
       STAMP(10);
-      STAMP(8);
     }
     ss_dma_wait();    // this wave's share of the pooled-1 map has landed in LDS
     __syncthreads();  // T done
