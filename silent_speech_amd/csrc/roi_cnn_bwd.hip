@@ -49,7 +49,12 @@ struct BwdLds {
   // phase 2: dy2 | xh | i1
   static constexpr int o_ph = 8 * G::P1;
   static constexpr int o_dy3h = o_ph + 16 * G::P2;
-  static constexpr int o_da2m = o_dy3h + 24 * G::P2;
+  // dy3 is pixel-major with a pixel stride of DS = 28 floats (24 channels + 4 of padding): S2 reads 16 consecutive pixels per
+  // ds_read_b128 pass, and 96-byte pixels would put them on 4 of the 8 bank groups (4-way conflicts: S2 was LDS-bound, 8.2 k
+  // cycles for 6.9 k of MFMAs); 112 bytes spread them over all 8 (the 2-way minimum of a 16-lane b128 pass).  Phase 1 is the
+  // smaller of the two phases, so the padding costs no LDS
+  static constexpr int DS = 28;
+  static constexpr int o_da2m = o_dy3h + DS * G::P2;
   static constexpr int o_i2b = o_da2m + 16 * G::P;
   static constexpr int end1a = (o_i2b + 4 * G::P + 3) & ~3;
   // dy2 is pixel-major with a zero column left and right of every row: [H2][W2 + 2][16 channels].  A lane's four
@@ -105,8 +110,9 @@ struct CnnBwdParams {
 // tile 2 = (tap b, n 8..23); the ninth tap takes a full tile and a half-empty one.  The four k-quarter waves of each half of
 // the workgroup own taps {0..3} + (tap 8, n 0..15) resp. {4..7} + (tap 8, n 16..23): seven tiles either way.
 // dy3 is pixel-major [haloed pixel][24]: byte offset of tap (ky, kx) relative to the lane base at (y, x) of the haloed image
+constexpr int DY3_STRIDE = 28;  // == BwdLds::DS (asserted in the kernel)
 template <int S2>
-__device__ constexpr int s1_off(int tap) { return ((2 - tap / 3) * S2 + (2 - tap % 3)) * 24; }
+__device__ constexpr int s1_off(int tap) { return ((2 - tap / 3) * S2 + (2 - tap % 3)) * DY3_STRIDE; }
 
 template <class G, int HALF, class F>
 __device__ __forceinline__ void s1_rows(const float* dy3h, const float* a2h, int kg, int i, int g, f32x4 (&acc)[7], F&& on_row) {
@@ -119,7 +125,7 @@ __device__ __forceinline__ void s1_rows(const float* dy3h, const float* a2h, int
   // one k-step (8 LDS reads, 7 MFMAs) per pass, the next pass's reads issued before this pass's MFMAs (see S3); fully
   // unrolled: every address is one of four lane bases + an immediate
   constexpr int KPR = W4 / 4, NP = rows * KPR;
-  const float* lb = dy3h + (kg * rows * S2 + g) * 24;
+  const float* lb = dy3h + (kg * rows * S2 + g) * DY3_STRIDE;
   const float* lbi = lb + i;
   const float* lbA = lb + dA;
   const float* lbB = lb + dB;
@@ -130,7 +136,7 @@ __device__ __forceinline__ void s1_rows(const float* dy3h, const float* a2h, int
     if (ps + 1 < NP) {
       const int nx = ps + 1, r = nx / KPR, xq = nx % KPR, buf = nx & 1;
       if (xq == 0) on_row(r, rows);
-      const int o = (r * S2 + 4 * xq) * 24;
+      const int o = (r * S2 + 4 * xq) * DY3_STRIDE;
       b[buf] = bp[r * S2 + 4 * xq];
       a[buf][0] = lbi[o + s1_off<S2>(t0)];
       a[buf][1] = lbA[o];
@@ -158,6 +164,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, W2H = LL::W2H;
   constexpr int NCH = (HW / 8 + NT - 1) / NT;     // 8-byte pixel chunks per thread (every thread of a 64x64 frame has one)
   constexpr int I1S = G::I1S;
+  constexpr int DS = LL::DS;
+  static_assert(DS == DY3_STRIDE && DS % 4 == 0 && DS >= 24, "dy3 pixel stride");
   constexpr int NI1 = (I1S / 2 + NT - 1) / NT;    // 16-byte pool-1 argmax chunks per thread
   float* a1h = lds + LL::o_a1h;
   float* a2h = lds + LL::o_ph;
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   // nothing the compiler does with its own loads can wait on these (a register prefetch cost 2.8 us of serialised HBM
   // round trips per frame: spilled pointers and split destination registers each forced an s_waitcnt vmcnt(0)).
   constexpr int STG_M3 = LL::o_dy3h, STG_PX = LL::o_stg2, STG_I2 = STG_PX + HW / 4;   // float offsets
-  static_assert(8 * P <= 24 * P2 && HW % 16 == 0 && P % 16 == 0, "staging");
+  static_assert(8 * P <= DS * P2 && HW % 16 == 0 && P % 16 == 0, "staging");
   uint2 px[NCH];
   // fc weight column of this thread's channel (c = tid / 16; e = tid % 16 + 16 k): d feat needs nothing staged per frame
   float wq[4];
@@ -264,9 +272,9 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   constexpr bool FAST = (2 * P == NT) && ((P / NWV) % W4 == 0);
   auto m3_own_dst = [&]() {  // float offset of this wave's first interior pixel in the dy3 image
     const int pix0 = (P / NWV) * wvu;
-    return LL::o_dy3h + ((pix0 / W4 + 1) * S2 + pix0 % W4 + 1) * 24;
+    return LL::o_dy3h + ((pix0 / W4 + 1) * S2 + pix0 % W4 + 1) * DS;
   };
-  static_assert(!FAST || W4 * 24 >= 256, "a wave's mask piece stays inside its first row");
+  static_assert(!FAST || W4 * DS >= 256, "a wave's mask piece stays inside its first row");
   auto misc_dma = [&](int nf) {  // d_out row, averaged features, counts, mean / std: one wave, four tiny DMAs
     if (wvu == NWV - 1) {
       if (lane < E) ss_dma4(p.d_out + (long)nf * p.ld_dout + lane, (unsigned)((LL::o_misc) * 4));
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       if (item < 2 * P) {
         const int pix = item >> 1, half = item & 1;
         const unsigned wds[4] = {m3w[k].x, m3w[k].y, m3w[k].z, m3w[k].w};
-        float* dst = dy3h + ((pix / W4 + 1) * S2 + (pix % W4) + 1) * 24 + 16 * half;
+        float* dst = dy3h + ((pix / W4 + 1) * S2 + (pix % W4) + 1) * DS + 16 * half;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (half == 0 || e < 2) {
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       else if (hp < 2 * S2) pixh = (G::H4 + 1) * S2 + (hp - S2);        // bottom row
       else if (hp < 2 * S2 + G::H4) pixh = (hp - 2 * S2 + 1) * S2;      // left column
       else pixh = (hp - 2 * S2 - G::H4 + 1) * S2 + W4 + 1;              // right column
-      reinterpret_cast<f32x4*>(dy3h + pixh * 24)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f32x4*>(dy3h + pixh * DS)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     front_fill(m3w);
     front_gb3();
@@ -397,11 +405,11 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     for (int q = lane; q < 2 * RPW * 6; q += 64) {  // left / right halo pixel of each own row, six 16-byte pieces each
       const int hp = q / 6, part = q - 6 * hp;
       const int pixh = (RPW * wvu + (hp >> 1) + 1) * S2 + ((hp & 1) ? W4 + 1 : 0);
-      reinterpret_cast<f32x4*>(dy3h + pixh * 24)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f32x4*>(dy3h + pixh * DS)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (wvu == 0 || wvu == NWV - 1) {
       const int row = wvu == 0 ? 0 : G::H4 + 1;
-      for (int q = lane; q < S2 * 6; q += 64) reinterpret_cast<f32x4*>(dy3h + row * S2 * 24)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = lane; q < S2 * DS / 4; q += 64) reinterpret_cast<f32x4*>(dy3h + row * S2 * DS)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     front_fill(m3w);
     front_table();
@@ -481,8 +489,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0;
         // per tap and pixel tile: channels 4g..4g+3 in one ds_read_b128 (k-steps 0..3), channels 16+2g, 17+2g in one
         // ds_read_b64 (k-steps 4, 5); the tap shift is an immediate
-        const float* ap0 = dy3h + ((pp0 / W4 + 2) * S2 + (pp0 % W4 + 2)) * 24;
-        const float* ap1 = dy3h + ((pp1 / W4 + 2) * S2 + (pp1 % W4 + 2)) * 24;
+        const float* ap0 = dy3h + ((pp0 / W4 + 2) * S2 + (pp0 % W4 + 2)) * DS;
+        const float* ap1 = dy3h + ((pp1 / W4 + 2) * S2 + (pp1 % W4 + 2)) * DS;
         int w3off = (LL::o_w3s + (g * 16 + i) * 4) * 4, w3off8 = (LL::o_w3s + 2304 + (g * 16 + i) * 2) * 4;
         asm volatile("" : "+v"(w3off), "+v"(w3off8));  // W3 may lie beyond the 64 KB reach of a ds_read immediate (see S5)
         const float* bt16 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + w3off);
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         // every step's reads are issued before the MFMAs of the step in front of it (see S3)
         f32x4 b16, a016, a116;
         float2 b8, a08, a18;
-        auto back_of = [](int tap) { return ((tap / 3) * S2 + (tap % 3)) * 24; };
+        auto back_of = [](int tap) { return ((tap / 3) * S2 + (tap % 3)) * DS; };
         b16 = *reinterpret_cast<const f32x4*>(bt16);
         a016 = *reinterpret_cast<const f32x4*>(ap0 + 4 * g);
         a116 = *reinterpret_cast<const f32x4*>(ap1 + 4 * g);
