@@ -476,7 +476,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // ---------------- S2: da2 (masked by a2 > 0), kept in registers ; db2.  Two pixel tiles per pass share the W3 reads.
     constexpr int S2_IT = (P / 16 + 2 * NWV - 1) / (2 * NWV);  // passes of two pixel tiles per wave
     float s2v[S2_IT][2][4];
-    int s2o[S2_IT][2][4];
+    unsigned s2o[S2_IT][2];  // four argmax bytes each
     {
       constexpr int tiles = P / 16;
 #pragma unroll
@@ -531,15 +531,17 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         }
         // the masked gradient and the pool-2 argmax of its four pixels stay in registers: this wave scatters them into the
         // dense dy2 image itself, right behind barrier D (no da2m image, no second barrier)
+        unsigned o0 = 0, o1 = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pq = 16 * tile + 4 * g + r;
           const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
           const float v = av > 0.f ? acc0[r] : 0.f;
           s2v[it][0][r] = v;
-          s2o[it][0][r] = i2b[pq * 16 + i];
+          o0 |= (unsigned)i2b[pq * 16 + i] << (8 * r);
           accb2 += v;
         }
+        s2o[it][0] = o0;
         if (two) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -547,10 +549,11 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
             const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
             const float v = av > 0.f ? acc1x[r] : 0.f;
             s2v[it][1][r] = v;
-            s2o[it][1][r] = i2b[pq * 16 + i];
+            o1 |= (unsigned)i2b[pq * 16 + i] << (8 * r);
             accb2 += v;
           }
         }
+        s2o[it][1] = o1;
       }
     }
     if (FAST && wvu == NWV - 1) ss_dma_wait();  // the next frame's d_out row has landed: published by barrier D
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
               float* d0 = dy2 + ((2 * qy) * W2H + 2 * qx + 1 + par) * 16 + i;
               float* d1 = dy2 + ((2 * qy) * W2H + 2 * qx + 2 - par) * 16 + i;
               const float v = s2v[it][h][r];
-              const int o = s2o[it][h][r];
+              const int o = (s2o[it][h] >> (8 * r)) & 255u;
               d0[0] = o == par ? v : 0.f;
               d1[0] = o == 1 - par ? v : 0.f;
               d0[16 * W2H] = o == 2 + par ? v : 0.f;

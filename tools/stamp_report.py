@@ -20,8 +20,8 @@ from silent_speech_amd import _lib as L  # noqa: E402
 FWD = {15: "loop top", 0: "stats+normalise", 1: "conv1 (MFMA)", 2: "a1 stash copy + conv2 (MFMA)", 3: "a2 stash copy",
        4: "conv3 (MFMA)", 5: "feat + fc"}
 BWD = {15: "loop top (barrier E skew)", 0: "frame top: pixels / argmaxes out of staging", 3: "S1 dW3 (+ pooled-1 DMA issue)", 4: "S2 da2",
-       11: "T: d feat of the next frame, da2m/argmax -> regs, barrier", 10: "T: dy2 scatter", 8: "T: normalised frame",
-       5: "T: i1, a1 DMA wait, barrier", 6: "S3 dW2", 9: "S4 da1", 7: "S5 dW1 + prefetch + the next frame's front"}
+       10: "T: dy2 scatter from registers", 5: "T: a1 DMA wait, barrier", 6: "S3 dW2 (+ normalised frame, i1, d feat per wave)", 9: "S4 da1",
+       7: "S5 dW1 + prefetch + the next frame's front"}
 
 
 def main():
