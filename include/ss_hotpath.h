@@ -82,9 +82,11 @@ int ss_roi_cnn_fwd(const uint8_t* R, int N, int H, int W, int standardize, const
  * A caller that runs a second stream beside them (micro-batch pipelining) leaves CUs free this way. */
 int ss_roi_cnn_set_max_workgroups(int n);
 
-/* per-frame sizes of the stashed pooled maps (floats) and of the pool-1 argmax map (bytes, padded planes) for an
- * (H, W) the kernels are built for */
-int ss_roi_cnn_stash_size(int H, int W, int* a1_floats, int* a2_floats, int* i1_bytes);
+/* per-frame sizes of the six stash arrays for an (H, W) the kernels are built for, sizes[6] (host memory) =
+ * { floats of the pooled-1 map, floats of the pooled-2 map, bytes of the pool-1 argmax map (padded planes), bytes of the
+ *   pool-2 argmax map, bytes of the conv3 sign mask, floats of an st_feat row } */
+#define SS_ROI_CNN_STASH_SIZES 6
+int ss_roi_cnn_stash_size(int H, int W, int* sizes);
 
 /* Same forward, additionally writing what the backward needs (the six st_* pointers are either
  * all NULL -- then this is ss_roi_cnn_fwd -- or all valid):
@@ -95,15 +97,15 @@ int ss_roi_cnn_stash_size(int H, int W, int* a1_floats, int* a2_floats, int* i1_
  * st_a2 (N, a2_floats) f32 and st_i2 (N,H/4,W/4,16) u8 (pixel-major): the same for conv2;
  * st_m3 (N,H/4*W/4,32) u8, pixel-major, channels 24..31 zero: conv3 output > 0; st_feat (N,52): globally averaged conv3 features, then the
  * per-channel counts of positive conv3 outputs, then the mean and the standard deviation of the frame (the backward kernel reuses them).
- * a1_floats / a2_floats / i1_bytes: the per-frame sizes the caller allocated st_a1 / st_a2 / st_i1 with (what
- *   ss_roi_cnn_stash_size returned).  The forward and the backward kernel each compare them with the layout THEY were
- *   compiled with and return SS_ERR_ARG on a mismatch instead of writing / reading out of bounds (round 1 lost a GPU
- *   process to two objects built against different versions of that layout: DESIGN.md section 9). */
+ * stash_sizes (host memory, 6 ints; may be NULL when the st_* are): the per-frame sizes the caller allocated the six arrays
+ *   with (what ss_roi_cnn_stash_size returned).  The forward and the backward kernel each compare ALL of them with the
+ *   layout THEY were compiled with and return SS_ERR_ARG on a mismatch instead of writing / reading out of bounds (round 1
+ *   lost a GPU process to two objects built against different versions of that layout: DESIGN.md section 9). */
 int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
                          const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
                          const float* bfc, int E, float* out, int ld_out, float* st_a1, uint8_t* st_i1,
-                         float* st_a2, uint8_t* st_i2, uint8_t* st_m3, float* st_feat, int a1_floats, int a2_floats,
-                         int i1_bytes, ss_stream_t stream);
+                         float* st_a2, uint8_t* st_i2, uint8_t* st_m3, float* st_feat, const int* stash_sizes,
+                         ss_stream_t stream);
 
 /* autograd of the above w.r.t. the eight parameter tensors (the uint8 input has no gradient),
  * i.e. what loss.backward() (train_model_official.py:437) leaves in roi_cnn.*.grad.
@@ -112,8 +114,8 @@ int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int standardize,
 int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
                    const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
                    const float* bfc, int E, const float* st_a1, const uint8_t* st_i1, const float* st_a2,
-                   const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat, int a1_floats, int a2_floats,
-                   int i1_bytes, const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
+                   const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat, const int* stash_sizes,
+                   const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
                    float* g_wfc, float* g_bfc, ss_stream_t stream);
 
 /* ---- dense contraction used by a7/a9 and their gradients -----------------------------------
@@ -176,6 +178,10 @@ typedef struct ss_gemm_problem {
 } ss_gemm_problem;
 int ss_gemm_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats);
 int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream);
+
+/* a[0..na) = 0 and b[0..nb) = 0 in one launch (either may be empty; 16-byte aligned): the destinations the d layer_in GEMMs
+ * sum into with float atomics are cleared by this, off the critical path, instead of two library fills */
+int ss_zero_f32x2(float* a, long na, float* b, long nb, ss_stream_t stream);
 
 /* column sums: out[n] += sum_r A[r*lda + n]  (bias gradients) */
 int ss_colsum_f32(const float* A, int rows, int cols, int lda, float* out, ss_stream_t stream);

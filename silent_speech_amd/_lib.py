@@ -28,10 +28,10 @@ SIGNATURES = {
     "ss_feature_fuse": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "ss_roi_crop_idx": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ss_roi_cnn_fwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i, _vp],
-    "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_i, _i, _i, _vp],
+    "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_vp, _vp],
     "ss_roi_cnn_set_max_workgroups": [_i],
-    "ss_roi_cnn_stash_size": [_i, _i, _vp, _vp, _vp],
-    "ss_roi_cnn_bwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_i, _i, _i, _vp, _i] + [_vp] * 8 + [_vp],
+    "ss_roi_cnn_stash_size": [_i, _i, _vp],
+    "ss_roi_cnn_bwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_vp, _vp, _i] + [_vp] * 8 + [_vp],
     "ss_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
     "ss_gemm_f32_batched": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i,
                             _l, _l, _l, _l, _l, _vp],
@@ -56,6 +56,7 @@ SIGNATURES = {
     "ss_gemm_splitk_group_ws_floats": [_vp, _i, _vp],
     "ss_gemm_f32_splitk_group": [_vp, _i, _vp, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
+    "ss_zero_f32x2": [_vp, _l, _vp, _l, _vp],
     "ss_train_prologue": [_vp, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "ss_batch_gather_f32": [_vp, _i, _vp, _l, _vp, _vp, _f, _u64, _vp, _vp],
     "ss_batch_gather_u8": [_vp, _i, _vp, _l, _vp, _vp],
@@ -105,13 +106,26 @@ def load():
     return lib
 
 
-def cnn_stash_sizes(H: int, W: int):
-    """(floats per frame of the stashed pooled-1 map, of the pooled-2 map, bytes of the pool-1 argmax map)."""
-    a1, a2, i1 = C.c_int(0), C.c_int(0), C.c_int(0)
-    st = load().ss_roi_cnn_stash_size(H, W, C.byref(a1), C.byref(a2), C.byref(i1))
+class StashSizes(tuple):
+    """Per-frame sizes of the six ROI-CNN stash arrays (a1 floats, a2 floats, i1 bytes, i2 bytes, m3 bytes, feat floats) as the
+    library reports them; ``.ptr`` is the host int[6] the forward / backward entry points check against their own layout."""
+
+    def __new__(cls, values):
+        self = super().__new__(cls, values)
+        self._arr = (C.c_int * 6)(*values)
+        return self
+
+    @property
+    def ptr(self):
+        return C.cast(self._arr, C.c_void_p)
+
+
+def cnn_stash_sizes(H: int, W: int) -> StashSizes:
+    arr = (C.c_int * 6)()
+    st = load().ss_roi_cnn_stash_size(H, W, arr)
     if st != 0:
         raise RuntimeError(f"ROI size {H}x{W} is not one the CNN kernels are built for")
-    return a1.value, a2.value, i1.value
+    return StashSizes(list(arr))
 
 
 def gru_sync_bytes(B: int, T: int, H: int) -> int:

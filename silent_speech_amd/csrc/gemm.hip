@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 5) void gemm_f32_kernel(GemmParams p) {  // 5 
 
   gemm_epilogue(p, acc, m0, n0, zs, wm, wn, i, g, nullptr,
                 TileId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y});
-  STAMP_WAIT(4);
+  STAMP(4);
   STAMP_FLUSH();
 }
 

@@ -34,7 +34,8 @@
 // with NaN and counts an error in the sync header instead of hanging the GPU.
 //
 // sync_ws layout: [0] generation, [1] finished workgroups of the running launch, [2] sweep time-outs ever seen,
-// [3] workgroup-launches that took the same-XCD fast path,
+// [3] workgroup-launches that took the same-XCD fast path, [4] time-outs at the end of the previous launch, [5] fault
+// injection (tests only, see plays_dead),
 // [.. 64) pad | XCD ids [pairs][P] u64 | forward granules [2][pairs][16][H] u64 | backward granules
 // [2][pairs][P dest][P src][16][H/P] u64.
 // The owner zeroes it once; after that the kernels keep it consistent.
@@ -116,22 +117,33 @@ __device__ __forceinline__ bool sweep_granules(rsrc_t rs, int pair0, unsigned ta
 // sync[2] counts bounded waits that gave up (never reset: the host reads it where it synchronises anyway, see
 // engine.check_gru_sync); sync[4] = its value at the end of the previous launch.  A workgroup that loses a partner poisons
 // element 0 of the result itself, but that element belongs to one (clip 0, t = 0) workgroup which may store it AFTER the
-// poison; so the LAST workgroup of the launch -- every other one has issued its stores by then -- poisons it again whenever the
-// counter moved during this launch.
+// poison; so the LAST workgroup of the launch poisons it again whenever the counter moved during this launch.  Ordering: every
+// thread drains and writes back its own stores at agent scope (__threadfence: the waves of a workgroup count their stores
+// separately, and the owner of element 0 may sit on another XCD's L2) before its workgroup arrives with a release; the last
+// workgroup acquires before it writes the NaN, write-through -- so the owner's store is in memory before the poison is.
 __device__ __forceinline__ void finish_launch(unsigned* sync, unsigned gen, float* poison) {
+  __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned done = atomicAdd(&sync[1], 1u);
+    const unsigned done = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELEASE, SS_AGENT);
     if (done == gridDim.x - 1) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
       const unsigned errs = __hip_atomic_load(&sync[2], __ATOMIC_RELAXED, SS_AGENT);
       if (errs != sync[4]) {
-        *poison = __builtin_nanf("");
+        __hip_atomic_store(poison, __builtin_nanf(""), __ATOMIC_RELAXED, SS_AGENT);
         sync[4] = errs;
       }
       __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, SS_AGENT);
       __hip_atomic_store(&sync[0], gen + 1u, __ATOMIC_RELEASE, SS_AGENT);
     }
   }
+}
+
+// Fault injection for the tests of the failure channel (tests/test_gpu_kernels.py::test_gru_lost_partner_reaches_the_host):
+// sync[5] = 1 + the index of a workgroup that plays dead -- it publishes nothing and only arrives at the end, so its partners'
+// bounded waits run out.  Zero (the cleared state) = off; the owner of the workspace sets it, the kernels never do.
+__device__ __forceinline__ bool plays_dead(const unsigned* sync) {
+  return __hip_atomic_load(&sync[5], __ATOMIC_RELAXED, SS_AGENT) == blockIdx.x + 1u;
 }
 
 template <int H, int P>
@@ -169,6 +181,11 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   const int len = clip_ok ? p.lengths[clip] : 0;
   const int T = p.T;
   if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
+  if (plays_dead(sync)) {  // wave-uniform; tests only
+    __syncthreads();
+    finish_launch(sync, s_gen, p.out);
+    return;
+  }
   // every cycle of this chain is on the step's critical path: issue ahead of the weight-gradient GEMM waves that
   // share the SIMDs
   __builtin_amdgcn_s_setprio(3);
@@ -327,6 +344,11 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   const int len = clip_ok ? p.lengths[clip] : 0;
   const int T = p.T;
   if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
+  if (plays_dead(sync)) {  // wave-uniform; tests only
+    __syncthreads();
+    finish_launch(sync, s_gen, p.d_g);
+    return;
+  }
   __builtin_amdgcn_s_setprio(3);  // as in the forward kernel
 
   // A fragments: A[i = output unit 16*(NT*w + nt) + i][slot (q, e)] = W[row(16q + 4g + e)][unit], local row

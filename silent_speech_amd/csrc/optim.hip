@@ -90,6 +90,18 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(ProloguePar a) {
   }
 }
 
+// clears two float buffers (16-byte aligned) in one launch: the atomically summed destinations of the d layer_in GEMMs
+__global__ __launch_bounds__(256) void zero2_kernel(float* __restrict__ a, long na, float* __restrict__ b, long nb) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x, nthreads = (long)gridDim.x * 256;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4* a4 = reinterpret_cast<f32x4*>(a);
+  for (long q = tid; q < (na >> 2); q += nthreads) a4[q] = z;
+  for (long q = (na & ~3L) + tid; q < na; q += nthreads) a[q] = 0.f;
+  f32x4* b4 = reinterpret_cast<f32x4*>(b);
+  for (long q = tid; q < (nb >> 2); q += nthreads) b4[q] = z;
+  for (long q = (nb & ~3L) + tid; q < nb; q += nthreads) b[q] = 0.f;
+}
+
 // grid (ceil(cols/64), row chunks); thread (c = tid&63, rr = tid>>6) strides rows by 4
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int rows, int cols, int lda,
                                                      int rows_per_block, float* __restrict__ out) {
@@ -203,6 +215,16 @@ extern "C" int ss_train_prologue(float* grads, long n_grads, float* scalars, int
   int blocks = (int)((work + 255) / 256);
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   hipLaunchKernelGGL(train_prologue_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return ss_launch_status();
+}
+
+extern "C" int ss_zero_f32x2(float* a, long na, float* b, long nb, ss_stream_t stream) {
+  SS_REQUIRE(na >= 0 && nb >= 0 && (na == 0 || a) && (nb == 0 || b), SS_ERR_ARG);
+  SS_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0, SS_ERR_ARG);
+  if (na + nb == 0) return SS_OK;
+  long blocks = ((na > nb ? na : nb) / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(zero2_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, na, b, nb);
   return ss_launch_status();
 }
 

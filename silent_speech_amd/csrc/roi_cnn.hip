@@ -489,14 +489,14 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
                                     const float* b1, const float* w2, const float* b2, const float* w3,
                                     const float* b3, const float* wfc, const float* bfc, int E, float* out,
                                     int ld_out, float* st_a1, uint8_t* st_i1, float* st_a2, uint8_t* st_i2,
-                                    uint8_t* st_m3, float* st_feat, int a1_floats, int a2_floats, int i1_bytes,
+                                    uint8_t* st_m3, float* st_feat, const int* stash_sizes,
                                     ss_stream_t stream) {
   SS_REQUIRE(R && w1 && b1 && w2 && b2 && w3 && b3 && wfc && bfc && out, SS_ERR_ARG);
   SS_REQUIRE(N > 0 && E > 0 && ld_out >= E, SS_ERR_ARG);
   SS_REQUIRE(E <= 64, SS_ERR_UNSUPPORTED);
   const bool any = st_a1 || st_i1 || st_a2 || st_i2 || st_m3 || st_feat;
   const bool all = st_a1 && st_i1 && st_a2 && st_i2 && st_m3 && st_feat;
-  SS_REQUIRE(!any || all, SS_ERR_ARG);
+  SS_REQUIRE(!any || (all && stash_sizes), SS_ERR_ARG);
   CnnFwdParams p;
   p.R = R; p.N = N; p.standardize = standardize;
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.wfc = wfc; p.bfc = bfc;
@@ -506,7 +506,7 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
 #define SS_DISPATCH(HH, WW)                                                                                      \
   if (H == HH && W == WW) {                                                                                     \
     using G_ = Geom<HH, WW>;                                                                                    \
-    SS_REQUIRE(!all || (a1_floats == 8 * G_::P1 && a2_floats == 16 * G_::P2 && i1_bytes == 8 * G_::I1S), SS_ERR_ARG); \
+    SS_REQUIRE(!all || stash_sizes_match<G_>(stash_sizes), SS_ERR_ARG);                                         \
     return launch_fwd<G_>(p, s);                                                                                \
   }
   SS_CNN_SHAPES(SS_DISPATCH)
@@ -514,14 +514,12 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
   return SS_ERR_UNSUPPORTED;
 }
 
-extern "C" int ss_roi_cnn_stash_size(int H, int W, int* a1_floats, int* a2_floats, int* i1_bytes) {
-  SS_REQUIRE(a1_floats && a2_floats && i1_bytes, SS_ERR_ARG);
-#define SS_DISPATCH(HH, WW)              \
-  if (H == HH && W == WW) {              \
-    *a1_floats = 8 * Geom<HH, WW>::P1;   \
-    *a2_floats = 16 * Geom<HH, WW>::P2;  \
-    *i1_bytes = 8 * Geom<HH, WW>::I1S;   \
-    return SS_OK;                        \
+extern "C" int ss_roi_cnn_stash_size(int H, int W, int* sizes) {
+  SS_REQUIRE(sizes, SS_ERR_ARG);
+#define SS_DISPATCH(HH, WW)               \
+  if (H == HH && W == WW) {               \
+    stash_sizes_of<Geom<HH, WW>>(sizes);  \
+    return SS_OK;                         \
   }
   SS_CNN_SHAPES(SS_DISPATCH)
 #undef SS_DISPATCH
@@ -533,5 +531,5 @@ extern "C" int ss_roi_cnn_fwd(const uint8_t* R, int N, int H, int W, int standar
                               const float* wfc, const float* bfc, int E, float* out, int ld_out,
                               ss_stream_t stream) {
   return ss_roi_cnn_fwd_stash(R, N, H, W, standardize, w1, b1, w2, b2, w3, b3, wfc, bfc, E, out, ld_out, nullptr,
-                              nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, stream);
+                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }

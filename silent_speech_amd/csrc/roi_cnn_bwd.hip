@@ -942,10 +942,10 @@ extern "C" int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standar
                               const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                               const float* wfc, const float* bfc, int E, const float* st_a1, const uint8_t* st_i1,
                               const float* st_a2, const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat,
-                              int a1_floats, int a2_floats, int i1_bytes, const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
+                              const int* stash_sizes, const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
                               float* g_w3, float* g_b3, float* g_wfc, float* g_bfc, ss_stream_t stream) {
   (void)w1; (void)b1; (void)b2; (void)b3; (void)bfc;  // the stashed activations already contain their effect
-  SS_REQUIRE(R && w2 && w3 && wfc && st_a1 && st_i1 && st_a2 && st_i2 && st_m3 && st_feat && d_out, SS_ERR_ARG);
+  SS_REQUIRE(R && w2 && w3 && wfc && st_a1 && st_i1 && st_a2 && st_i2 && st_m3 && st_feat && stash_sizes && d_out, SS_ERR_ARG);
   SS_REQUIRE(g_w1 && g_b1 && g_w2 && g_b2 && g_w3 && g_b3 && g_wfc && g_bfc, SS_ERR_ARG);
   SS_REQUIRE(N > 0 && E > 0 && ld_dout >= E, SS_ERR_ARG);
   SS_REQUIRE(E <= 64, SS_ERR_UNSUPPORTED);
@@ -959,7 +959,7 @@ extern "C" int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standar
 #define SS_DISPATCH(HH, WW)                                                                             \
   if (H == HH && W == WW) {                                                                            \
     using G_ = Geom<HH, WW>;                                                                           \
-    SS_REQUIRE(a1_floats == 8 * G_::P1 && a2_floats == 16 * G_::P2 && i1_bytes == 8 * G_::I1S, SS_ERR_ARG); \
+    SS_REQUIRE(stash_sizes_match<G_>(stash_sizes), SS_ERR_ARG);                                        \
     return launch_bwd<G_>(p, s);                                                                       \
   }
   SS_CNN_SHAPES(SS_DISPATCH)

@@ -26,6 +26,23 @@ struct Geom {
   static_assert(H % 4 == 0 && W % 32 == 0 && H2 % 2 == 0 && P % 32 == 0 && HW2 % 32 == 0, "unsupported ROI size");
 };
 
+// Per-frame sizes of the six stash arrays as THIS translation unit lays them out: a1 / a2 floats, pool-1 argmax bytes,
+// pool-2 argmax bytes, conv3 sign-mask bytes, floats of an st_feat row.  The caller allocates from ss_roi_cnn_stash_size and
+// hands the same six numbers to the forward and the backward entry point; each compares them with its own Geom.
+constexpr int SS_CNN_STASH_SIZES = 6;
+template <class G>
+inline void stash_sizes_of(int* s) {
+  s[0] = 8 * G::P1; s[1] = 16 * G::P2; s[2] = 8 * G::I1S; s[3] = G::P * 16; s[4] = G::P * 32; s[5] = ST_FEAT;
+}
+template <class G>
+inline bool stash_sizes_match(const int* s) {
+  int mine[SS_CNN_STASH_SIZES];
+  stash_sizes_of<G>(mine);
+  for (int k = 0; k < SS_CNN_STASH_SIZES; ++k)
+    if (s[k] != mine[k]) return false;
+  return true;
+}
+
 }  // namespace
 
 // X(H, W) for every instantiated frame size

@@ -175,17 +175,8 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
       st_last = t_;                            \
     }                                          \
   } while (0)
-#define STAMP_SYNC(k) \
-  do {                \
-    __syncthreads();  \
-    STAMP(k);         \
-  } while (0)
-// stamp after every outstanding memory operation of the wave has returned (delimits a load phase)
-#define STAMP_WAIT(k)                \
-  do {                               \
-    __builtin_amdgcn_s_waitcnt(0);   \
-    STAMP(k);                        \
-  } while (0)
+// (A stamp never contains a barrier or a wait of its own: a diagnostic macro that synchronises only under -DSS_STAMP
+// hid a missing production barrier for a whole round.  Where a stamp wants a barrier in front, the kernel has it.)
 #define STAMP_FLUSH()                                        \
   do {                                                       \
     if (threadIdx.x == 0) STAMP_ADD_(13, wall_clock64());    \
@@ -194,8 +185,6 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #define STAMP_ENTRY
 #define STAMP_DECL
 #define STAMP(k)
-#define STAMP_SYNC(k)
-#define STAMP_WAIT(k)
 #define STAMP_FLUSH()
 #define STAMP_TABLE(reader)
 #endif

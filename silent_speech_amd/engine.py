@@ -140,6 +140,14 @@ def _addr(t: torch.Tensor, offset_elems: int = 0) -> int:
     return t.data_ptr() + offset_elems * t.element_size()
 
 
+def zero_buffers(bufs) -> None:
+    """Clear float tensors on the current stream, two per launch (ss_zero_f32x2): no library fill on the path."""
+    bufs = [b for b in bufs if b is not None and b.numel()]
+    for k in range(0, len(bufs), 2):
+        a, b = bufs[k], bufs[k + 1] if k + 1 < len(bufs) else None
+        L.call("ss_zero_f32x2", a.data_ptr(), a.numel(), L.ptr(b), b.numel() if b is not None else 0, L.stream())
+
+
 def check_gru_sync(ws) -> None:
     """Raise if a bounded wait of the multi-CU GRU recurrence ever gave up on this workspace (a partner workgroup was not
     co-resident: the kernels then poison their result with NaN and count the event in word 2 of the sync header).  Reads
@@ -216,13 +224,16 @@ class Workspace:
             self.dZ = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
             if cfg.use_roi:
                 Hh, Ww = roi_hw
-                n_a1, n_a2, n_i1 = self.cnn_sizes = L.cnn_stash_sizes(Hh, Ww)  # the kernels' own LDS images, kept as they are
+                # every size comes from the library (the kernels' own LDS images, kept as they are) and goes back to it with
+                # each launch, where the forward and the backward object compare it with the layout they were compiled with
+                self.cnn_sizes = L.cnn_stash_sizes(Hh, Ww)
+                n_a1, n_a2, n_i1, n_i2, n_m3, n_feat = self.cnn_sizes
                 self.st_a1 = torch.empty(N, n_a1, **f32)
                 self.st_i1 = torch.empty(N, n_i1, **u8)
                 self.st_a2 = torch.empty(N, n_a2, **f32)
-                self.st_i2 = torch.empty(N, Hh // 4, Ww // 4, 16, **u8)
-                self.st_m3 = torch.empty(N, (Hh // 4) * (Ww // 4), 32, **u8)
-                self.st_feat = torch.empty(N, 52, **f32)  # 24 features, 24 counts, mean, std, pad
+                self.st_i2 = torch.empty(N, n_i2, **u8)     # (H/4, W/4, 16)
+                self.st_m3 = torch.empty(N, n_m3, **u8)     # (H/4 * W/4, 32)
+                self.st_feat = torch.empty(N, n_feat, **f32)  # 24 features, 24 counts, mean, std, pad
 
 
 def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Tensor, R: Optional[torch.Tensor], *,
@@ -251,7 +262,7 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
         st = ([ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
                ws.st_m3.data_ptr(), ws.st_feat.data_ptr()] if stash else [None] * 6)
         L.call("ss_roi_cnn_fwd_stash", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
-               _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, *(ws.cnn_sizes if stash else (0, 0, 0)), s)
+               _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, ws.cnn_sizes.ptr if stash else None, s)
         if ws.train and ws.stagger:  # an event record is a barrier packet on this stream (~6 us): only when somebody waits for it
             ws.ev_cnn_fwd.record()
         layer_in, ld_in = ws_Z.data_ptr(), cfg.in_dim
@@ -316,10 +327,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         side.wait_event(ws.ev_fork)
         # the atomically summed destinations of the d layer_in GEMMs: cleared here, off the critical path, and first --
         # the top layer's d layer_in GEMM waits for them
-        for t_ in ws.d_lower[1:]:
-            t_.zero_()
-        if cfg.use_roi:
-            ws.dZ.zero_()
+        zero_buffers(ws.d_lower[1:] + ([ws.dZ] if cfg.use_roi else []))
         ws.ev_zero.record()
         # LayerNorm gamma / beta and score-weight gradients: column sums of the rows the tail kernel left per clip
         for k_, name_ in enumerate(("head.0.weight", "head.0.bias", "pool.score.weight")):
@@ -377,7 +385,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                 dst, ld_dst = ws.dZ.data_ptr(), cfg.in_dim
             else:
                 dst, ld_dst = d_X.data_ptr(), cfg.x_dim
-                d_X.zero_()
+                zero_buffers([d_X])
             if not zero_waited:  # once per backward pass: every cleared buffer is behind the same event
                 torch.cuda.current_stream().wait_event(ws.ev_zero)
                 zero_waited = True
@@ -410,7 +418,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                  "roi_cnn.net.6.weight", "roi_cnn.net.6.bias", "roi_cnn.fc.weight", "roi_cnn.fc.bias")
         L.call("ss_roi_cnn_bwd", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
                cfg.roi_emb, ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
-               ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), *ws.cnn_sizes, _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
+               ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), ws.cnn_sizes.ptr, _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
                *[G[k].data_ptr() for k in names], s)
     # join the side stream: the caller's next kernels (all-reduce, clip, Adam) read every gradient
     if USE_SIDE_STREAM and not side_joined:

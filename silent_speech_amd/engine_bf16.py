@@ -82,6 +82,7 @@ class WorkspaceBf16:
         self.side = torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[0]) if train else None
         self.ev_fork = torch.cuda.Event() if train else None
         self.ev_join = torch.cuda.Event() if train else None
+        self.ev_cnn_fwd = torch.cuda.Event() if train else None  # recorded after the ROI-CNN forward (Trainer's micro-batch stagger)
         N, H = B * T, cfg.hidden
         f32 = dict(device=device, dtype=torch.float32)
         u8 = dict(device=device, dtype=torch.uint8)
@@ -150,6 +151,8 @@ def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
         L.call("ss_c5_conv_last_fwd", ws.a3.data_ptr(), N, w[3], b[3], P["roi_cnn.fc.weight"].data_ptr(), P["roi_cnn.fc.bias"].data_ptr(),
                cfg.roi_emb, _addr(ws.Z, cfg.x_dim), cfg.in_dim, ws.m4.data_ptr() if stash else None,
                ws.feat.data_ptr() if stash else None, s)
+        if ws.train and ws.stagger:  # only when another micro-batch waits for it (train.Trainer)
+            ws.ev_cnn_fwd.record()
         layer_in, ld_in = ws.Z.data_ptr(), cfg.in_dim
     else:
         layer_in, ld_in = X.data_ptr(), cfg.x_dim
@@ -185,7 +188,7 @@ def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
 def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
              R: Optional[torch.Tensor], d_logits: torch.Tensor, *, train: bool, seed: int = 0,
              d_X: Optional[torch.Tensor] = None) -> None:
-    from .engine import gemm as gemm_f32  # the head's two tiny weight-gradient GEMMs stay f32
+    from .engine import gemm as gemm_f32, zero_buffers  # the head's two tiny weight-gradient GEMMs stay f32
 
     B, T, H, N = ws.B, ws.T, cfg.hidden, ws.B * ws.T
     s = L.stream()
@@ -203,10 +206,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
              accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
     gemm_f32(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(), 2 * H,
              accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
-    for t_ in ws.d_lower[1:]:
-        t_.zero_()
-    if cfg.use_roi:
-        ws.dZ.zero_()
+    zero_buffers(ws.d_lower[1:] + ([ws.dZ] if cfg.use_roi else []))
     use_drop = train and cfg.gru_dropout > 0.0
     for l in range(cfg.gru_layers - 1, -1, -1):
         K = cfg.in_dim if l == 0 else 2 * H
@@ -254,7 +254,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
                     c0 = 0  # 16-byte operand loads: take all columns
                 dst, ld_dst = ws.dZ.data_ptr() + 4 * c0, cfg.in_dim
             else:
-                d_X.zero_()
+                zero_buffers([d_X])
                 dst, ld_dst, c0 = d_X.data_ptr(), cfg.x_dim, 0
             gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(P[wi], c0), K, dst, ld_dst, accumulate=True, atomic=True, batch=2,
                  strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0), tag="gemm_bf16_dX")

@@ -134,6 +134,19 @@ class ClipGateServer:
         n = len(ids)
         if len(set(ids.tolist())) != n:
             raise ValueError("one frame per stream and tick")
+        if n and (ids.min() < 0 or ids.max() >= self.S):
+            raise ValueError(f"stream ids must be in [0, {self.S})")
+        # the kernel indexes feats[i*D + d], rois[i*H*W + c], openness[i], face_present[i] for i < n: a mis-shaped argument
+        # would be an out-of-bounds device read or a garbage clip, not an error -- turn it away here
+        if tuple(feats.shape) != (n, self.D):
+            raise ValueError(f"feats must be ({n}, {self.D}), got {tuple(feats.shape)}")
+        if openness.numel() != n:
+            raise ValueError(f"openness must hold {n} values, got {openness.numel()}")
+        if face_present is not None and face_present.numel() != n:
+            raise ValueError(f"face_present must hold {n} values, got {face_present.numel()}")
+        if rois is not None and self.clip_r is not None:
+            if rois.dtype != torch.uint8 or tuple(rois.shape) != (n, *self.roi_hw):
+                raise ValueError(f"rois must be uint8 ({n}, {self.roi_hw[0]}, {self.roi_hw[1]}), got {rois.dtype} {tuple(rois.shape)}")
         dev = self.device
         ids_d = torch.from_numpy(ids).to(dev)
         feats = feats.to(dev, torch.float32).contiguous()

@@ -91,10 +91,13 @@ def _gru_emulated(gi, whh, bhh, lengths, T, H, reverse):
     return torch.stack(outs, 1), torch.stack(saves, 1)
 
 
-@pytest.mark.parametrize("B,T,H", [(5, 7, 128), (70, 4, 256), (33, 6, 512)])
-def test_gru_bf16_fwd_bwd(L, B, T, H):
+@pytest.mark.parametrize("B,T,H,drop_p", [(5, 7, 128, 0.0), (70, 4, 256, 0.0), (33, 6, 512, 0.0), (33, 6, 512, 0.1), (5, 7, 128, 0.3)])
+def test_gru_bf16_fwd_bwd(L, B, T, H, drop_p):
+    """``drop_p`` > 0: the BPTT kernel re-draws nn.GRU's inter-layer dropout mask while it reads d_out (Philox stream of
+    ss_dropout at the same seed / offset / element index): checked against the mask ss_dropout itself writes."""
     g = torch.Generator().manual_seed(B + T + H)
     N = B * T
+    seed, offset = 77, 3 << 40
     lengths = torch.randint(1, T + 1, (B,), generator=g)
     lengths[0] = T
     if B > 2:
@@ -107,9 +110,17 @@ def test_gru_bf16_fwd_bwd(L, B, T, H):
     outs, saves = zip(*[_gru_emulated(gi_l[d], whh_l[d], bhh[d], lengths, T, H, reverse=bool(d)) for d in range(2)])
     out_ref = torch.cat(outs, 2)                                  # (B,T,2H)
     d_out = torch.randn(B, T, 2 * H, generator=g)
-    (out_ref * d_out).sum().backward()
-
     dev = lambda x: x.contiguous().cuda()
+    keep = torch.ones(B, T, 2 * H)
+    if drop_p > 0:
+        ones = torch.ones(N, 2 * H, device="cuda")
+        km = torch.empty_like(ones)
+        L.call("ss_dropout", ones.data_ptr(), km.data_ptr(), N * 2 * H, drop_p, seed, offset, None, L.stream())
+        keep = km.cpu().view(B, T, 2 * H)
+        frac = float((keep == 0).float().mean())
+        assert abs(frac - drop_p) < 0.03 and float(keep.max()) == pytest.approx(1.0 / (1.0 - drop_p))
+    (out_ref * d_out * keep).sum().backward()
+
     wb = torch.empty(2, 3 * H, H, device="cuda", dtype=torch.int16)
     wtb = torch.empty(2, H, 3 * H, device="cuda", dtype=torch.int16)
     w_f, w_r = dev(whh[0]), dev(whh[1])
@@ -139,7 +150,7 @@ def test_gru_bf16_fwd_bwd(L, B, T, H):
     dG = torch.full((2, N, 4, H), 9.0, device="cuda")
     d_out_d = dev(d_out.reshape(N, 2 * H))
     L.call("ss_gru_bf16_bwd", d_out_d.data_ptr(), out.data_ptr(), save.data_ptr(), wtb.data_ptr(),
-           lens.data_ptr(), B, T, H, dG.data_ptr(), 0.0, 0, 0, ws.data_ptr(), L.stream())
+           lens.data_ptr(), B, T, H, dG.data_ptr(), drop_p, seed, offset, ws.data_ptr(), L.stream())
     torch.cuda.synchronize()
     dGc = dG.cpu().view(2, B, T, 4, H)
     for d in range(2):

@@ -594,20 +594,30 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     R_d = dev(R)
     out = torch.empty(N, 32, device="cuda")
     H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
-    n_a1, n_a2, n_i1 = L.cnn_stash_sizes(H, W)
+    sizes = L.cnn_stash_sizes(H, W)
+    n_a1, n_a2, n_i1, n_i2, n_m3, n_feat = sizes
+    assert (n_i2, n_m3) == (H4 * W4 * 16, H4 * W4 * 32) and n_feat >= 50
+
+    def wrong(k, delta):  # the same six sizes with one of them off: what a stale object / a mis-sized caller would hand in
+        v = list(sizes)
+        v[k] += delta
+        return L.StashSizes(v)
+
     st_a1 = torch.empty(N, n_a1, device="cuda")
     st_i1 = torch.empty(N, n_i1, device="cuda", dtype=torch.uint8)
     st_a2 = torch.empty(N, n_a2, device="cuda")
     st_i2 = torch.empty(N, H4, W4, 16, device="cuda", dtype=torch.uint8)  # pixel-major
     st_m3 = torch.empty(N, H4 * W4, 32, device="cuda", dtype=torch.uint8)  # pixel-major, 24 of 32 channel slots used
-    st_feat = torch.empty(N, 52, device="cuda")  # 24 features, 24 positive-output counts, frame mean / std, pad
+    st_feat = torch.empty(N, n_feat, device="cuda")  # 24 features, 24 positive-output counts, frame mean / std, pad
     st = [st_a1, st_i1, st_a2, st_i2, st_m3, st_feat]
     L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out.data_ptr(), 32,
-           *[s.data_ptr() for s in st], n_a1, n_a2, n_i1, L.stream())
-    # a caller whose buffers were sized for another layout is turned away, not written over
-    with pytest.raises(RuntimeError, match="ss_roi_cnn_fwd_stash"):
-        L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out.data_ptr(), 32,
-               *[s.data_ptr() for s in st], n_a1 - 8, n_a2, n_i1, L.stream())
+           *[s.data_ptr() for s in st], sizes.ptr, L.stream())
+    # a caller whose buffers were sized for another layout is turned away, not written over:
+    # the pooled-1 map and the st_feat row width (the one the round-2 ABI did not check)
+    for bad in (wrong(0, -8), wrong(5, -4)):
+        with pytest.raises(RuntimeError, match="ss_roi_cnn_fwd_stash"):
+            L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out.data_ptr(), 32,
+                   *[s.data_ptr() for s in st], bad.ptr, L.stream())
     sync()
     assert_close("roi_e", out, out_ref, atol=2e-5, rtol=1e-4)
 
@@ -644,11 +654,12 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     assert int(st_m3[:, :, 24:].sum()) == 0
 
     G = [torch.zeros_like(p) for p in P]
-    with pytest.raises(RuntimeError, match="ss_roi_cnn_bwd"):
-        L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
-               n_a1, n_a2, n_i1 + 32, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
+    for bad in (wrong(2, 32), wrong(5, 4), wrong(4, -32)):
+        with pytest.raises(RuntimeError, match="ss_roi_cnn_bwd"):
+            L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
+                   bad.ptr, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
     L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
-           n_a1, n_a2, n_i1, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
+           sizes.ptr, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
     sync()
     for k, gg in zip(CNN_KEYS, G):
         ref = leaves[k].grad
@@ -656,7 +667,7 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
         assert_close("grad " + k, gg, ref, atol=3e-4 * max(scale, 1e-3), rtol=1e-3)
     # gradients accumulate: a second call doubles them
     L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
-           n_a1, n_a2, n_i1, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
+           sizes.ptr, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G], L.stream())
     sync()
     assert_close("accumulate", G[4], 2 * leaves[CNN_KEYS[4]].grad, atol=6e-4 * float(leaves[CNN_KEYS[4]].grad.abs().max()),
                  rtol=1e-3)
@@ -670,14 +681,14 @@ def test_roi_cnn_stash_and_bwd(L, H, W):
     try:
         out2 = torch.empty_like(out)
         L.call("ss_roi_cnn_fwd_stash", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out2.data_ptr(), 32,
-               *[s.data_ptr() for s in st], n_a1, n_a2, n_i1, L.stream())
+               *[s.data_ptr() for s in st], sizes.ptr, L.stream())
         sync()
         assert torch.equal(out2, out), "the forward output of a frame must not depend on which workgroup computes it"
         runs = []
         for _ in range(8):
             G2 = [torch.zeros_like(p) for p in P]
             L.call("ss_roi_cnn_bwd", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
-                   n_a1, n_a2, n_i1, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G2], L.stream())
+                   sizes.ptr, dev(d_out).data_ptr(), 32, *[gg.data_ptr() for gg in G2], L.stream())
             sync()
             runs.append(G2)
         for k, gg in zip(CNN_KEYS, runs[0]):

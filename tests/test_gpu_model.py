@@ -55,6 +55,42 @@ def test_logits_match_reference_golden(ss, golden_dir, name):
     assert err < TIGHT, f"{name}: logit max-abs-err {err:.3e}"
 
 
+def test_gru_lost_partner_reaches_the_host(ss):
+    """The failure channel of the multi-CU GRU recurrence (gru_split.h): a workgroup that never publishes must not hang the
+    GPU -- its partners' bounded sweeps give up, the launch poisons its result with NaN, counts the event in the sync header
+    and ``model.check_health()`` raises.  Forced through the header's fault-injection word (sync[5] = 1 + workgroup index):
+    the owner of the workspace sets it, the kernels only read it.  Afterwards the same workspace serves correct results again
+    (the generation counter moved on; nothing has to be cleared)."""
+    sd = W.make_state_dict(2, 84, 5, False)
+    B, T = 32, 6
+    X, Lh, _, y = W.make_inputs(2, B, T, 84, 5, None)
+    m = ss.BiGRUClassifier(84, 5, use_roi=False)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    Xd = X.cuda()
+    with torch.no_grad():
+        good = m(Xd, Lh).cpu()
+    ws = m._workspace(Xd, None, train=False)
+    if ws.gru_sync is None:
+        pytest.skip("this shape does not take the multi-CU recurrence")
+    m.check_health()
+    assert int(ws.gru_sync[2]) == 0
+    ws.gru_sync[5] = 1 + 7  # workgroup 7 of the layer-0 forward launch (and of every later launch) plays dead
+    with torch.no_grad():
+        bad = m(Xd, Lh).cpu()
+    torch.cuda.synchronize()
+    assert int(ws.gru_sync[2]) > 0, "no bounded wait gave up"
+    assert torch.isnan(bad).any(), "the poisoned result did not reach the logits"
+    with pytest.raises(RuntimeError, match="GRU recurrence"):
+        m.check_health()
+    ws.gru_sync[5] = 0
+    ws.gru_sync[2] = 0  # acknowledge: the counter is never reset by the kernels
+    with torch.no_grad():
+        again = m(Xd, Lh).cpu()
+    assert torch.equal(again, good)
+    m.check_health()
+
+
 def test_state_dict_surface(ss):
     m = ss.BiGRUClassifier(180, 10, use_roi=True)
     ref = W.param_shapes(180, 10, True)
@@ -642,3 +678,12 @@ def test_clip_gate_server_matches_the_restated_state_machine(ss):
         assert float((logits.cpu() - ref).abs().max()) < TIGHT
         n_clips += len(done)
     assert n_clips >= 10 and n_cut >= 1, (n_clips, n_cut)
+    # mis-shaped arguments are turned away on the host: the kernel would index past them
+    ok = dict(feats=torch.zeros(2, Dm), openness=torch.zeros(2, dtype=torch.float64), rois=torch.zeros((2,) + hw, dtype=torch.uint8))
+    for bad in (dict(feats=torch.zeros(1, Dm)), dict(feats=torch.zeros(2, Dm - 1)), dict(openness=torch.zeros(1, dtype=torch.float64)),
+                dict(rois=torch.zeros((2, 16, 16), dtype=torch.uint8)), dict(rois=torch.zeros((2,) + hw)),
+                dict(face_present=torch.ones(3, dtype=torch.uint8))):
+        with pytest.raises(ValueError):
+            srv.push([0, 1], **{**ok, **bad})
+    with pytest.raises(ValueError):
+        srv.push([0, S], **ok)

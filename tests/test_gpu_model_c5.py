@@ -76,12 +76,19 @@ def test_c5_autograd_gradients(ss):
         got = p.grad.cpu()
         # vs the bf16 restatement the kernels differ by gradient roundings (bf16 gradient maps and gate gradients) and, rarely,
         # a flipped ReLU / pool winner; vs the f32 model additionally by the forward roundings (tests/test_oracle_bf16.py)
-        small = float(g_f32[k].norm()) < 0.03 * total  # small tensors: one flipped unit is a visible fraction of them
-        for name, ref, tol, cmin in (("emu", g_emu[k], 4e-2, 0.999), ("f32", g_f32[k], 0.25, 0.97)):
+        # The bf16 restatement rounds where the kernels round, so every tensor, large or small, must agree to 1e-2 relative L2
+        # (measured worst 2e-3: gradient-map roundings and summation order) -- no escape for small tensors.  Against the f32 model
+        # the forward roundings come on top and one ReLU / pool winner flipped by them moves a SMALL tensor visibly: those
+        # (norm under 3 % of the total) are bounded absolutely, by 1 % of the total gradient norm, instead of relatively.
+        small = float(g_f32[k].norm()) < 0.03 * total
+        for name, ref, tol, cmin in (("emu", g_emu[k], 1e-2, 0.9999), ("f32", g_f32[k], 0.25, 0.97)):
             rel = float((got - ref).norm() / ref.norm())
             cos = float((got * ref).sum() / (got.norm() * ref.norm()))
             worst[name] = max(worst.get(name, 0.0), rel)
-            assert (rel < tol and cos > cmin) or (small and cos > 0.9), (k, name, rel, cos)
+            if name == "f32" and small:
+                assert float((got - ref).norm()) < 1e-2 * total and cos > 0.9, (k, name, rel, cos)
+            else:
+                assert rel < tol and cos > cmin, (k, name, rel, cos)
     print("config-5 gradients: worst relative L2 error vs bf16 restatement %.3e, vs f32 model %.3e" % (worst["emu"], worst["f32"]))
 
 
@@ -109,6 +116,27 @@ def test_c5_fused_trainer(ss):
     tr2 = ss.Trainer(m, dropout=True)
     losses = [float(tr2.step(Xd, Ld, Rd, yd)[0]) for _ in range(6)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_c5_micro_batches(ss):
+    """Trainer(micro_batches=2) on the bf16 path (the stagger event did not exist on WorkspaceBf16): two slices on two
+    streams give the step of one slice, up to the order of the float atomics."""
+    sd = W.make_state_dict(6, 84, 100, True, **C5)
+    B, T = 32, 5
+    X, Lh, R, y = W.make_inputs(6, B, T, 84, 100, (96, 96))
+    Xd, Ld, Rd, yd = X.cuda(), Lh.cuda(), R.cuda(), y.cuda()
+    out = []
+    for mb in (1, 2):
+        m = build(ss, sd)
+        tr = ss.Trainer(m, dropout=False, micro_batches=mb)
+        losses = [float(tr.step(Xd, Ld, Rd, yd)[0]) for _ in range(2)]
+        torch.cuda.synchronize()
+        out.append((losses, float(tr.grad_norm()), m.flat_params.clone()))
+    (l1, n1, p1), (l2, n2, p2) = out
+    assert abs(l1[0] - l2[0]) < 1e-5 and abs(l1[1] - l2[1]) < 2e-3, (l1, l2)
+    assert abs(n1 - n2) < 1e-3 * n1
+    # Adam turns gradients within rounding of zero into +-lr steps: compare the bulk
+    assert float((p1 - p2).abs().mean()) < 1e-4
 
 
 def test_c5_full_size_step_properties(ss):
