@@ -96,39 +96,6 @@ def step_gflop_per_clip(T, D, E, H, C, roi, mid=128, fwd_only=False):
     return 2.0 * (3 * fwd - T * conv1) / 1e9
 
 
-PMC_TRAFFIC = os.path.join("profiles", "round2_c_pmc_traffic.json")
-PMC_MFMA = os.path.join("profiles", "round2_c_pmc_mfma.json")
-
-
-def pmc_mfma_busy(kernel_tag):
-    """MFMA-pipe busy fraction of a kernel from the committed rocprofv3 PMC summary (SQ_VALU_MFMA_BUSY_CYCLES over
-    SQ_BUSY_CU_CYCLES-equivalent time; tools/pmc_summary.py mfma)."""
-    path = os.path.join(ROOT, PMC_MFMA)
-    stem = {"ss_roi_cnn_bwd": "roi_cnn_bwd_kernel", "ss_roi_cnn_fwd_stash": "roi_cnn_fwd_kernel"}.get(kernel_tag)
-    if not stem or not os.path.exists(path):
-        return None
-    for name, d in json.load(open(path))["kernels"].items():
-        if stem in name:
-            return d
-    return None
-
-
-def pmc_traffic(kernel_tag):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (made by tools/pmc_summary.py from
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
-    path = os.path.join(ROOT, PMC_TRAFFIC)
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "round1_g_pmc_traffic.json")
-    stem = {"ss_roi_cnn_bwd": "roi_cnn_bwd_kernel", "ss_roi_cnn_fwd_stash": "roi_cnn_fwd_kernel", "ss_gru_fwd": "gru_split_fwd_kernel",
-            "ss_gru_bwd": "gru_split_bwd_kernel"}.get(kernel_tag)
-    if not stem or not os.path.exists(path):
-        return None
-    for name, d in json.load(open(path))["kernels"].items():
-        if stem in name:
-            return int(d["hbm_bytes_per_launch"])
-    return None
-
-
 def host_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box gives one
     GPU's share of a large host; os.cpu_count() would oversubscribe it many times over)."""
@@ -229,6 +196,238 @@ def config4_block(ss, dev, D, C, roi, steps, warmup):
                          "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None}}
 
 
+
+def latest_profile(suffix, exclude=None):
+    """Newest committed rocprofv3 summary under profiles/ whose name ends in ``suffix`` (rounds sort by name)."""
+    pdir = os.path.join(ROOT, "profiles")
+    names = sorted(n for n in (os.listdir(pdir) if os.path.isdir(pdir) else []) if n.endswith(suffix) and not (exclude and exclude in n))
+    return os.path.join(pdir, names[-1]) if names else None
+
+
+def pmc_lookup(path, stems):
+    """Entry of a tools/pmc_summary.py JSON whose kernel name contains every string of ``stems``."""
+    if not path or not os.path.exists(path):
+        return None
+    for name, d in json.load(open(path))["kernels"].items():
+        if all(st in name for st in stems):
+            return d
+    return None
+
+
+# launch tag -> substrings of the kernel's name in the rocprofv3 summaries
+KERNEL_STEMS = {
+    "ss_roi_cnn_bwd": ["roi_cnn_bwd_kernel"], "ss_roi_cnn_fwd_stash": ["roi_cnn_fwd_kernel"], "ss_gru_fwd": ["gru_split_fwd_kernel"],
+    "ss_gru_bwd": ["gru_split_bwd_kernel"], "ss_gru_bf16_fwd": ["gru_pers_fwd_kernel"], "ss_gru_bf16_bwd": ["gru_pers_bwd_kernel"],
+    "ss_c5_conv12_fwd": ["conv12_fwd_kernel"], "ss_c5_conv1_wgrad": ["conv1_wgrad_kernel"], "ss_c5_conv2_wgrad_rc": ["conv_wgrad_kernel<16, 32"],
+    "ss_c5_conv2_dgrad": ["conv_dgrad_kernel<16, 32"], "ss_c5_conv3_wgrad": ["conv_wgrad_kernel<32, 64"],
+    "ss_c5_conv3_dgrad": ["conv_dgrad_kernel<32, 64"], "ss_c5_conv_last_wgrad": ["conv_wgrad_kernel<64, 96"],
+    "ss_c5_conv_last_dgrad": ["conv_dgrad_kernel<64, 96"], "ss_c5_conv3_fwd": ["conv_fwd_kernel<32, 64"],
+    "ss_c5_conv_last_fwd": ["conv_fwd_kernel<64, 96"], "gemm_bf16_dW": ["gemm_bf16_kernel<0, 0>"],
+}
+
+
+def synth_inputs(L, dev, rank, B, T, K, roi_hw, C, with_landmarks=False):
+    """Synthetic clips of SURVEY.md 8(d), generated on the device: jittered landmarks -> ss_feature_fuse, uint8 ROI, full lengths."""
+    D = 2 * K + 4
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    base = torch.rand(B, 1, K, 2, device=dev, generator=g) * torch.tensor([0.4, 0.4], device=dev) + torch.tensor([0.3, 0.4], device=dev)
+    lm = base + 0.004 * torch.randn(B, T, K, 2, device=dev, generator=g)
+    lm[:, :, 8] = torch.tensor([0.42, 0.61], device=dev)   # landmark 61 sits at position 8 of the sorted 40-lip list
+    lm[:, :, 25] = torch.tensor([0.58, 0.61], device=dev)  # 291
+    lm[:, :, 1] = torch.tensor([0.50, 0.59], device=dev)   # 13
+    lm[:, :, 2] = torch.tensor([0.50, 0.63], device=dev)   # 14
+    lm = (lm + 0.002 * torch.randn(B, T, K, 2, device=dev, generator=g)).contiguous()
+    X = torch.empty(B, T, D, device=dev)
+    L.call("ss_feature_fuse", lm.data_ptr(), None, B, T, K, 640, 480, 8, 25, 1, 2, 0, X.data_ptr(), D, None, None, L.stream())
+    R = torch.randint(0, 256, (B, T, roi_hw[0], roi_hw[1]), device=dev, dtype=torch.uint8, generator=g)
+    lengths = torch.full((B,), T, device=dev, dtype=torch.int64)
+    y = torch.randint(0, C, (B,), device=dev, generator=g)
+    if with_landmarks:
+        return X, lengths, R, y, lm
+    return X, lengths, R, y
+
+
+def spec_for(config, B, T, K, roi, C):
+    """What a training block needs to know about a BASELINE config: model arguments, dtype, roofline denominator, FLOP counts."""
+    D = 2 * K + 4
+    if config == 5:
+        E, H = C5["emb"], C5["hidden"]
+        return dict(config=5, B=B, T=T, K=K, D=D, C=C, roi_hw=(C5["roi"], C5["roi"]), E=E, H=H, dtype="bf16", peak=BF16_MFMA_PEAK_TFLOPS,
+                    model_kw=dict(roi_emb=E, hidden=H, cnn_channels=C5["channels"], precision="bf16"),
+                    gflop_per_clip=c5_step_gflop_per_clip(T, D),
+                    workload=(f"BASELINE config 5: landmark (K={K}, D={D}) + 96x96 uint8 ROI CNN (16,32,64,96) + 2-layer BiGRU({H}), T={T}, "
+                              f"C={C} words, bf16 MFMA operands / f32 accumulation and master weights, train step = fwd + CE(ls .05) + "
+                              "bwd + grad all-reduce + clip(1.0) + Adam, dropout on"))
+    roi_hw = roi if isinstance(roi, tuple) else (roi, roi)
+    E, H = 32, 192
+    name = "BASELINE config 2" if config == 2 else "the reference's shipped configuration (train_model_official.py:29-38)"
+    return dict(config=config, B=B, T=T, K=K, D=D, C=C, roi_hw=roi_hw, E=E, H=H, dtype="f32", peak=F32_MFMA_PEAK_TFLOPS, model_kw={},
+                gflop_per_clip=step_gflop_per_clip(T, D, E, H, C, roi_hw),
+                workload=(f"{name}: landmark (K={K}, D={D}) + {roi_hw[0]}x{roi_hw[1]} uint8 ROI CNN + 2-layer BiGRU(192), T={T}, C={C}, "
+                          "train step = fwd + CE(ls .05) + bwd + grad all-reduce + clip(1.0) + Adam, dropout on"))
+
+
+def train_block(ss, L, dev, world, rank, spec, X, lengths, R, y, steps, warmup, kernel_times, micro_batches, dist_on):
+    """W warm-up steps, then exactly K timed steps of the fused training step between barriers (max over ranks); then K more
+    steps on one stream with a HIP-event pair around every launch for the per-kernel table and the dominant kernel's roofline."""
+    import torch.distributed as dist
+
+    B, T, D, C, E, H = spec["B"], spec["T"], spec["D"], spec["C"], spec["E"], spec["H"]
+    torch.manual_seed(0)
+    model = ss.BiGRUClassifier(D, C, use_roi=True, **spec["model_kw"]).to(dev).train()
+    if dist_on:
+        dist.broadcast(model.flat_params, src=0)
+    trainer = ss.Trainer(model, world_size=world, micro_batches=micro_batches, always_allreduce=dist_on)
+
+    def barrier():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gb = B * world
+    for _ in range(warmup):
+        trainer.step(X, lengths, R, y, global_batch=gb)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = trainer.step(X, lengths, R, y, global_batch=gb)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    final_loss = float(loss)
+    assert final_loss == final_loss, "loss is NaN"
+    model.check_health()
+
+    kernels, roof, kernel_tf, allreduce_ms = {}, None, None, None
+    if kernel_times:
+        from silent_speech_amd import engine, engine_bf16
+
+        engine.USE_SIDE_STREAM = engine_bf16.USE_SIDE_STREAM = False  # one stream, so each event pair brackets exactly one kernel
+        mb, trainer.micro_batches = trainer.micro_batches, 1
+        L.PROFILE = {}
+        trainer.allreduce_events = [] if dist_on else None
+        for _ in range(steps):
+            trainer.step(X, lengths, R, y, global_batch=gb)
+        torch.cuda.synchronize()
+        prof, L.PROFILE = L.PROFILE, None
+        engine.USE_SIDE_STREAM = engine_bf16.USE_SIDE_STREAM = True
+        trainer.micro_batches = mb
+        if trainer.allreduce_events:
+            allreduce_ms = sum(a.elapsed_time(b) for a, b in trainer.allreduce_events) / len(trainer.allreduce_events)
+        trainer.allreduce_events = None
+        for tag, evs in prof.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            kernels[tag] = {"launches_per_step": len(ms) / steps, "avg_ms": sum(ms) / len(ms), "ms_per_step": sum(ms) / steps}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        full_size = (B, T) == (256, 30)
+        if spec["config"] == 5:
+            gfs = c5_gflop_per_step(B, T, D)
+            gf = gfs.get(dom)
+            if gf is not None:
+                achieved = gf / kernels[dom]["ms_per_step"]  # GFLOP per step / ms per step = TFLOP/s
+                tr_ = pmc_lookup(latest_profile("_c5_pmc_traffic.json"), KERNEL_STEMS.get(dom, [dom])) if full_size else None
+                roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": int(tr_["hbm_bytes_per_launch"] * kernels[dom]["launches_per_step"]) if tr_ else None,
+                        "algorithmic_gflop_per_step": round(gf, 2), "launches_per_step": kernels[dom]["launches_per_step"],
+                        "ms_per_step": round(kernels[dom]["ms_per_step"], 4)}
+                mb_ = pmc_lookup(latest_profile("_c5_pmc_mfma.json"), KERNEL_STEMS.get(dom, [dom])) if full_size else None
+                if mb_:
+                    roof["mfma_busy_frac"] = mb_.get("mfma_busy_frac")
+            kernel_tf = {k: round(gfs[k] / v["ms_per_step"], 1) for k, v in kernels.items() if k in gfs}
+        else:
+            gf = algorithmic_gflop(dom, B, T, D, E, H, C, spec["roi_hw"])
+            if gf is not None:
+                achieved = gf / kernels[dom]["avg_ms"]  # GFLOP / ms = TFLOP/s
+                at_bench = full_size and spec["roi_hw"] == (64, 64)
+                tr_ = pmc_lookup(latest_profile("_pmc_traffic.json", exclude="_c5_"), KERNEL_STEMS.get(dom, [dom])) if at_bench else None
+                roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": int(tr_["hbm_bytes_per_launch"]) if tr_ else None,
+                        "algorithmic_gflop_per_launch": round(gf, 3), "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
+                mb_ = pmc_lookup(latest_profile("_pmc_mfma.json", exclude="_c5_"), KERNEL_STEMS.get(dom, [dom])) if at_bench else None
+                if mb_:
+                    roof["mfma_busy"] = mb_
+
+    out = {
+        "metric": "clips/sec (%d-frame, fwd+bwd)" % T, "value": round(B * world * steps / elapsed, 1), "unit": "clips/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(1000 * elapsed / steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": spec["dtype"], "data": "synthetic",
+        "config": {"workload": spec["workload"], "batch_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}",
+                   "micro_batches_in_flight": micro_batches},
+        "final_loss": round(final_loss, 5),
+    }
+    if roof:
+        out["roofline"] = roof
+    # whole-step figure of SURVEY.md 8(d): clips/s x algorithmic GFLOP per clip against the dense MFMA peak (of the dtype) of the GPUs used
+    tf = out["value"] * spec["gflop_per_clip"] / 1e3
+    out["step_roofline"] = {"bound": "mfma", "gflop_per_clip": round(spec["gflop_per_clip"], 4), "achieved": round(tf, 2),
+                            "peak": round(spec["peak"] * world, 1), "unit": "TFLOP/s", "frac": round(tf / (spec["peak"] * world), 4)}
+    if kernels:
+        out["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+        if kernel_tf:
+            out["kernels_tflops"] = kernel_tf
+    if allreduce_ms is not None:
+        out["allreduce_ms"] = round(allreduce_ms, 4)  # the flat-bucket all-reduce (RCCL), HIP events around the collective
+        out["allreduce_bytes"] = int(model.flat_grads.numel()) * 4
+    del trainer, model
+    torch.cuda.empty_cache()
+    return out
+
+
+SHIPPED = dict(K=88, T=90, roi_hw=(48, 96), C=10)  # train_model_official.py:29-38, record_landmarks_official.py:30-44: D = 180
+
+
+def shipped_blocks(ss, L, dev, world, rank, args, dist_on):
+    """The configuration the reference actually runs: BATCH_SIZE 16 (as shipped) and 256 clips of MAX_T = 90 frames, 88 landmarks
+    (D = 180), ROI 96 wide x 48 high, 10 words."""
+    out = {}
+    for name, B in (("b16", 16), ("b256", 256)):
+        sp = spec_for("shipped", B, SHIPPED["T"], SHIPPED["K"], SHIPPED["roi_hw"], SHIPPED["C"])
+        X, l, R, y = synth_inputs(L, dev, rank, B, sp["T"], sp["K"], sp["roi_hw"], sp["C"])
+        out[name] = train_block(ss, L, dev, world, rank, sp, X, l, R, y, args.steps, max(2, args.warmup // 2),
+                                not args.no_kernel_times, 1, dist_on)
+        del X, R
+        torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline_c5(args, D, T, seconds):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as W
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    kw = dict(roi_emb=C5["emb"], hidden=C5["hidden"], cnn_channels=C5["channels"])
+    Bc = 32
+    sd = W.make_state_dict(0, D, C5["classes"], True, **kw)
+    X, L_, R, y = W.make_inputs(0, Bc, T, D, C5["classes"], (96, 96), lengths=[T] * Bc)
+    n, el = _cpu_time_steps(sd, X, L_, R, y, seconds, 5)
+    return {"value": round(Bc * n / el, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{n} f32 train steps (fwd+CE+bwd+clip+Adam, dropout off) of the CPU oracle, torch {torch.__version__} ATen CPU "
+                      f"kernels, {cores} threads; config-5 widths (96x96 ROI, CNN 16/32/64/96, H=512, 100 words) at batch {Bc}, T={T}",
+            "ms_per_step": round(1000 * el / n, 1)}
+
+
+def cpu_baseline_shipped(seconds):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as W
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    D, T, C, Bc = 2 * SHIPPED["K"] + 4, SHIPPED["T"], SHIPPED["C"], 16
+    sd = W.make_state_dict(0, D, C, True)
+    X, L_, R, y = W.make_inputs(0, Bc, T, D, C, SHIPPED["roi_hw"], lengths=[T] * Bc)
+    n, el = _cpu_time_steps(sd, X, L_, R, y, seconds, 6)
+    return {"value": round(Bc * n / el, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps (fwd+CE+bwd+clip+Adam, dropout off) of the CPU oracle, torch {torch.__version__} ATen CPU kernels, "
+                      f"{cores} threads; the shipped configuration: batch 16, T=90, D=180, 48x96 ROI, 10 words",
+            "ms_per_step": round(1000 * el / n, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +449,14 @@ def main():
                     help="2 = the headline (f32, 64x64 ROI, H=192, 5 words); 5 = BASELINE config 5 (bf16 MFMA, 96x96 ROI, CNN "
                          "16/32/64/96, H=512, 100 words)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 (hipGraph serving) block of the default run")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (bf16, 96x96 ROI, H=512) block of the default run")
+    ap.add_argument("--no-shipped", action="store_true", help="skip the block at the reference's shipped configuration")
+    ap.add_argument("--shipped", dest="shipped_only", action="store_true",
+                    help="only the reference's shipped configuration (48x96 ROI, 88 landmarks -> D=180, 10 words, T=90; batch 16 as "
+                         "shipped and batch 256), one JSON line with its CPU row")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="join an 'nccl' (= RCCL) process group and run the data-parallel leg -- broadcast of the parameters, the flat "
+                         "gradient all-reduce every step, barriers, max-over-ranks timing -- even with one rank")
     args = ap.parse_args()
     if args.config == 5:
         args.roi, args.classes = C5["roi"], C5["classes"]
@@ -263,33 +470,33 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     import silent_speech_amd as ss
     from silent_speech_amd import _lib as L
 
+    if args.shipped_only:
+        out = shipped_blocks(ss, L, dev, world, rank, args, dist_on)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_shipped(seconds=args.cpu_seconds)
+        if dist_on:
+            dist.destroy_process_group()
+        if rank == 0:
+            head = dict(out["b16"])  # the contract's keys describe the batch the reference ships; b256 rides along
+            head["b256"] = out["b256"]
+            if "cpu_baseline" in out:
+                head["cpu_baseline"] = out["cpu_baseline"]
+            print(json.dumps(head), flush=True)
+        return
     if args.mode == "infer" and args.batch == 256 and args.frames == 30:
         args.batch, args.frames = 4096, 60
     B, T, K, C, roi = args.batch, args.frames, args.landmarks, args.classes, args.roi
-    D, E, H = 2 * K + 4, 32, 192
-    if args.config == 5:
-        E, H = C5["emb"], C5["hidden"]
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    # synthetic clips: landmarks -> K1 feature fuse on device; uint8 ROI; full lengths
-    base = torch.rand(B, 1, K, 2, device=dev, generator=g) * torch.tensor([0.4, 0.4], device=dev) + torch.tensor([0.3, 0.4], device=dev)
-    lm = base + 0.004 * torch.randn(B, T, K, 2, device=dev, generator=g)
-    lm[:, :, 8] = torch.tensor([0.42, 0.61], device=dev)   # landmark 61 sits at position 8 of the sorted 40-lip list
-    lm[:, :, 25] = torch.tensor([0.58, 0.61], device=dev)  # 291
-    lm[:, :, 1] = torch.tensor([0.50, 0.59], device=dev)   # 13
-    lm[:, :, 2] = torch.tensor([0.50, 0.63], device=dev)   # 14
-    lm = (lm + 0.002 * torch.randn(B, T, K, 2, device=dev, generator=g)).contiguous()
-    X = torch.empty(B, T, D, device=dev)
-    L.call("ss_feature_fuse", lm.data_ptr(), None, B, T, K, 640, 480, 8, 25, 1, 2, 0, X.data_ptr(), D, None, None, L.stream())
-    R = torch.randint(0, 256, (B, T, roi, roi), device=dev, dtype=torch.uint8, generator=g)
-    lengths = torch.full((B,), T, device=dev, dtype=torch.int64)
-    y = torch.randint(0, C, (B,), device=dev, generator=g)
+    D = 2 * K + 4
+    X, lengths, R, y, lm = synth_inputs(L, dev, rank, B, T, K, (roi, roi), C, with_landmarks=True)
 
     torch.manual_seed(0)
     if args.mode == "infer":
@@ -420,111 +627,31 @@ def main():
                                        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(u8_ms, 4)},
                           "kernels_ms": {k: round(v, 4) for k, v in k_ms.items()}}))
         return
-    if args.config == 5:
-        model = ss.BiGRUClassifier(D, C, use_roi=True, roi_emb=E, hidden=H, cnn_channels=C5["channels"], precision="bf16").to(dev).train()
-    else:
-        model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).train()
-    if world > 1:
-        dist.broadcast(model.flat_params, src=0)
-    trainer = ss.Trainer(model, world_size=world, micro_batches=args.micro_batches)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    gb = B * world
-    for _ in range(args.warmup):
-        trainer.step(X, lengths, R, y, global_batch=gb)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = trainer.step(X, lengths, R, y, global_batch=gb)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax)
-    final_loss = float(loss)
-    assert final_loss == final_loss, "loss is NaN"
-
-    # ---- per-kernel launch durations over K more steps, HIP events on the launch stream
-    kernels, roof = {}, None
-    if not args.no_kernel_times:
-        from silent_speech_amd import engine, engine_bf16
-
-        engine.USE_SIDE_STREAM = engine_bf16.USE_SIDE_STREAM = False  # one stream, so each event pair brackets exactly one kernel
-        mb, trainer.micro_batches = trainer.micro_batches, 1
-        L.PROFILE = {}
-        for _ in range(args.steps):
-            trainer.step(X, lengths, R, y)
-        torch.cuda.synchronize()
-        prof, L.PROFILE = L.PROFILE, None
-        engine.USE_SIDE_STREAM = engine_bf16.USE_SIDE_STREAM = True
-        trainer.micro_batches = mb
-        for tag, evs in prof.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
-            kernels[tag] = {"launches_per_step": len(ms) / args.steps, "avg_ms": sum(ms) / len(ms),
-                            "ms_per_step": sum(ms) / args.steps}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        if args.config == 5:
-            gfs = c5_gflop_per_step(B, T, D)
-            gf = gfs.get(dom)
-            if gf is not None:
-                achieved = gf / kernels[dom]["ms_per_step"]  # GFLOP per step / ms per step = TFLOP/s
-                roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "algorithmic_gflop_per_step": round(gf, 2), "launches_per_step": kernels[dom]["launches_per_step"],
-                        "ms_per_step": round(kernels[dom]["ms_per_step"], 4)}
-            kernel_tf = {k: round(gfs[k] / v["ms_per_step"], 1) for k, v in kernels.items() if k in gfs}
-        else:
-            gf = algorithmic_gflop(dom, B, T, D, E, H, C, (roi, roi))
-            if gf is not None:
-                achieved = gf / kernels[dom]["avg_ms"]  # GFLOP / ms = TFLOP/s
-                roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": pmc_traffic(dom) if (B, T, roi) == (256, 30, 64) else None,
-                        "algorithmic_gflop_per_launch": round(gf, 3), "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
-                mb_ = pmc_mfma_busy(dom) if (B, T, roi) == (256, 30, 64) else None
-                if mb_:
-                    roof["mfma_busy"] = mb_
-
-    if args.config == 5:
-        workload = (f"BASELINE config 5: landmark (K={K}, D={D}) + 96x96 uint8 ROI CNN (16,32,64,96) + 2-layer BiGRU({H}), T={T}, "
-                    f"C={C} words, bf16 MFMA operands / f32 accumulation and master weights, train step = fwd + CE(ls .05) + bwd + "
-                    "grad all-reduce + clip(1.0) + Adam, dropout on")
-        peak, gpc = BF16_MFMA_PEAK_TFLOPS, c5_step_gflop_per_clip(T, D)
-    else:
-        workload = (f"BASELINE config 2: landmark (K={K}, D={D}) + {roi}x{roi} uint8 ROI CNN + 2-layer BiGRU(192), "
-                    f"T={T}, C={C}, train step = fwd + CE(ls .05) + bwd + grad all-reduce + clip(1.0) + Adam, dropout on")
-        peak, gpc = F32_MFMA_PEAK_TFLOPS, step_gflop_per_clip(T, D, E, H, C, (roi, roi))
-    out = {
-        "metric": "clips/sec (30-frame, fwd+bwd)", "value": round(B * world * args.steps / elapsed, 1), "unit": "clips/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.config == 5 else "f32",
-        "data": "synthetic",
-        "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}",
-                   "micro_batches_in_flight": args.micro_batches},
-        "final_loss": round(final_loss, 5),
-    }
-    if roof:
-        out["roofline"] = roof
-    # whole-step figure of SURVEY.md 8(d): clips/s x algorithmic GFLOP per clip against the dense MFMA peak (of the dtype) of the GPUs used
-    tf = out["value"] * gpc / 1e3
-    out["step_roofline"] = {"bound": "mfma", "gflop_per_clip": round(gpc, 4), "achieved": round(tf, 2),
-                            "peak": round(peak * world, 1), "unit": "TFLOP/s", "frac": round(tf / (peak * world), 4)}
-    if kernels:
-        out["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])}
-        if args.config == 5:
-            out["kernels_tflops"] = kernel_tf
-    if rank == 0 and world == 1 and args.config == 2 and not args.no_config4:
-        del trainer, model
+    spec = spec_for(args.config, B, T, K, roi, C)
+    out = train_block(ss, L, dev, world, rank, spec, X, lengths, R, y, args.steps, args.warmup, not args.no_kernel_times,
+                      args.micro_batches, dist_on)
+    solo = rank == 0 and world == 1
+    # ---- the other BASELINE configs ride along in the default run, so that the driver's one command measures them too
+    if args.config == 2 and not args.no_config5:
+        # BASELINE config 5 is a data-parallel training config like the headline: every rank runs it (one all-reduce per step)
+        torch.cuda.empty_cache()
+        s5 = spec_for(5, 256, 30, K, C5["roi"], C5["classes"])
+        X5, l5, R5, y5 = synth_inputs(L, dev, rank, 256, 30, K, s5["roi_hw"], s5["C"])
+        out["config5"] = train_block(ss, L, dev, world, rank, s5, X5, l5, R5, y5, args.steps, max(2, args.warmup // 2),
+                                     not args.no_kernel_times, 1, dist_on)
+        del X5, R5
+    if args.config == 2 and not args.no_shipped and not args.shipped_only:
+        out["shipped"] = shipped_blocks(ss, L, dev, world, rank, args, dist_on)
+    if solo and args.config == 2 and not args.no_config4:
         torch.cuda.empty_cache()
         out["config4"] = config4_block(ss, dev, D, C, roi, 20, 3)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, D, C, args.config)
-    if world > 1:
+        if "config5" in out:
+            out["config5"]["cpu_baseline"] = cpu_baseline_c5(args, D, 30, seconds=6.0)
+        if "shipped" in out:
+            out["shipped"]["cpu_baseline"] = cpu_baseline_shipped(seconds=5.0)
+    if dist_on:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -61,6 +61,8 @@ class Trainer:
         self.betas, self.eps = betas, eps
         self.world, self.group = world_size, process_group
         self.always_allreduce = always_allreduce
+        # bench.py: when this is a list, every step appends a (start, end) HIP-event pair around the gradient all-reduce
+        self.allreduce_events = None
         self.dropout = dropout
         dev = model.flat_params.device
         self.m = torch.zeros_like(model.flat_params)
@@ -158,7 +160,13 @@ class Trainer:
             L.call("ss_roi_cnn_set_max_workgroups", 0)
         s = L.stream()
         if self.world > 1 or self.always_allreduce:
+            if self.allreduce_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             allreduce_flat_grads(model.flat_grads, self.group, always=self.always_allreduce)
+            if self.allreduce_events is not None:
+                e1.record()
+                self.allreduce_events.append((e0, e1))
         n_el = model.flat_grads.numel()
         L.call("ss_sumsq_f32", model.flat_grads.data_ptr(), n_el, self.scal.data_ptr() + 4, s)
         # d_logits already carries 1/(B*world), so the summed bucket IS the global-mean gradient

@@ -60,6 +60,9 @@ MODEL_CASES = [
     ("model_shipped", "train", 180, 10, (48, 96), 2, 10, [10, 6], 2),
     ("model_live_l1", "live", 84, 5, (64, 64), 2, 6, [6, 3], 1),
     ("model_live_l2", "live", 84, 5, (64, 64), 2, 6, [4, 6], 2),
+    # the reference's shipped shape at its shipped length: MAX_T = 90 frames, 88 landmarks -> D = 180, ROI 48 x 96, 10 words
+    # (train_model_official.py:29-38); one full-length clip and one ragged one
+    ("model_shipped_t90", "train", 180, 10, (48, 96), 2, 90, [90, 53], 2),
 ]
 
 
@@ -367,8 +370,12 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
     tmo, rec, live, tred = import_reference()
+    only = set(sys.argv[1:])  # python make_golden.py [case names]: regenerate only those model cases
     for i, case in enumerate(MODEL_CASES):
-        gen_model_case(tmo, live, *case, seed=100 + i)
+        if not only or case[0] in only:
+            gen_model_case(tmo, live, *case, seed=100 + i)
+    if only:
+        return
     gen_kat(tred)
     gen_features(rec, live)
     gen_crop(rec, live)

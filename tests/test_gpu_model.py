@@ -44,7 +44,7 @@ def build(ss, d, sd, standardize=True):
     return m.cuda().eval()
 
 
-@pytest.mark.parametrize("name", ["model_lm_only", "model_roi64", "model_shipped", "model_live_l1", "model_live_l2"])
+@pytest.mark.parametrize("name", ["model_lm_only", "model_roi64", "model_shipped", "model_live_l1", "model_live_l2", "model_shipped_t90"])
 def test_logits_match_reference_golden(ss, golden_dir, name):
     d, sd, X, Lh, R, y = load_case(golden_dir, name)
     m = build(ss, d, sd, standardize=(str(d["cls"]) == "train"))
@@ -84,7 +84,8 @@ def test_gru_lost_partner_reaches_the_host(ss):
     with pytest.raises(RuntimeError, match="GRU recurrence"):
         m.check_health()
     ws.gru_sync[5] = 0
-    ws.gru_sync[2] = 0  # acknowledge: the counter is never reset by the kernels
+    ws.gru_sync[2] = 0  # acknowledge: the counter is never reset by the kernels ...
+    ws.gru_sync[4] = 0  # ... and neither is their note of its last value
     with torch.no_grad():
         again = m(Xd, Lh).cpu()
     assert torch.equal(again, good)
@@ -105,7 +106,7 @@ def test_state_dict_surface(ss):
         m2(torch.zeros(1, 3, 84), torch.tensor([3]))  # CPU tensors: no CPU path, must fail loudly
 
 
-@pytest.mark.parametrize("name", ["model_lm_only", "model_roi64", "model_shipped"])
+@pytest.mark.parametrize("name", ["model_lm_only", "model_roi64", "model_shipped", "model_shipped_t90"])
 def test_autograd_grads_match_oracle_and_golden(ss, golden_dir, name):
     d, sd, X, Lh, R, y = load_case(golden_dir, name)
     m = build(ss, d, sd)
@@ -125,7 +126,7 @@ def test_autograd_grads_match_oracle_and_golden(ss, golden_dir, name):
                                    rtol=5e-3, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["model_lm_only", "model_roi64"])
+@pytest.mark.parametrize("name", ["model_lm_only", "model_roi64", "model_shipped_t90"])
 def test_fused_trainer_two_steps_match_reference(ss, golden_dir, name):
     d, sd, X, Lh, R, y = load_case(golden_dir, name)
     m = build(ss, d, sd)
@@ -263,6 +264,35 @@ def test_one_rank_rccl_trainer_equals_single_process(ss, tmp_path):
     for k, v in m.state_dict().items():
         atol = 6.1e-4 if k == "pool.score.bias" else 2e-5
         assert float((v.cpu() - got["sd"][k]).abs().max()) <= atol, k
+
+
+def test_bench_multi_rank_branch_runs_under_torchrun(ss):
+    """bench.py's OWN data-parallel branch -- init_process_group("nccl", device_id=), broadcast of the flat parameters, the
+    gradient all-reduce in every step, dist.barrier, all_reduce(MAX) of the wall time -- exactly as the driver starts it for
+    N > 1 (python -m torch.distributed.run ... bench.py --gpus N), here with the one rank this box has (--force-dist), in a
+    fresh child that has not touched the GPU before it joins the group.  The line must carry the all-reduce time."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+           "--batch", "32", "--no-cpu-baseline", "--no-config4", "--no-config5", "--no-shipped"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+    assert d["allreduce_ms"] > 0 and d["allreduce_bytes"] == 4 * 1079588
+    assert d["final_loss"] == d["final_loss"]
 
 
 @pytest.mark.parametrize("layers", [1, 2])
