@@ -240,26 +240,49 @@ int ss_clip_gate(const int32_t* stream_ids, int n, const double* openv, const ui
  *
  * ss_gemm_bf16_batched: C[M,N] (+)= opA * opB (+ bias), the conventions of ss_gemm_f32_batched (f32 operands in HBM,
  *   a_kcontig / b_kcontig, storage-row remap, batch strides in elements); flags bit0 accumulate, bit2 float atomics;
- *   splits > 1 slices K and needs bit0 (atomics into a C the caller initialised).  Contiguous dimensions % 4 == 0. */
-int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
-                         int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
+ *   splits > 1 slices K and needs bit0 (atomics into a C the caller initialised).  Contiguous dimensions % 4 == 0.
+ *   flags bit3: A and B already ARE bf16 in HBM (uint16 bit patterns; lda / ldb / strides in bf16 elements, multiples of 8,
+ *   leading dimensions zero-padded to a multiple of 8 where the extent is not one: ss_cvt_bf16_rows): no conversion pass,
+ *   half the operand bytes, 64-deep k tiles. */
+int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const void* A, int lda, int a_group,
+                         int a_gstride, int a_off, const void* B, int ldb, int b_group, int b_gstride, int b_off,
                          float* C, int ldc, const float* bias, int flags, int splits, int batch, long stride_a,
                          long stride_b, long stride_c, long stride_bias, ss_stream_t stream);
 
-/* GRU recurrence for wide hidden states (H % 128 == 0), one launch per time step, both directions per launch, same
- * masking semantics and buffer layouts as ss_gru_fwd / ss_gru_bwd (gi (2,N,3H), out (N,2H), save / d_g (2,N,4,H)).
+/* GRU recurrence for wide hidden states (H % 128 == 0), both directions, same masking semantics and buffer layouts as
+ * ss_gru_fwd / ss_gru_bwd (gi (2,N,3H), out (N,2H), save / d_g (2,N,4,H)).
  * ss_gru_bf16_prep: W_hh of both directions -> whh_bf16 (2,3H,H) and its transpose whh_t_bf16 (2,H,3H), once per
- *   optimiser step.  ws: ss_gru_bf16_ws_bytes(B, H) bytes (state / gate-gradient hand-over between the step launches).
- * ss_gru_bf16_bwd leaves d_g; bias and weight gradients are column sums / GEMMs over d_g (ss_colsum_f32,
- *   ss_gemm_bf16_batched).  drop_p / seed / offset: the inter-layer dropout mask re-drawn on d_out (see ss_gru_bwd). */
+ *   optimiser step; with wih_bf16 (may be NULL) also W_ih (3H,K) of both directions -> (2,3H,Kp) bf16, Kp = K rounded up
+ *   to 8, zero-padded: the operand of the layer's input-projection / d layer_in GEMMs (ss_gemm_bf16_batched, bit 3).  ws: ss_gru_bf16_ws_bytes(B, H) bytes (state / gate-gradient hand-over between step launches).
+ * Two forms behind one entry point.  With sync_ws (ss_gru_bf16_sync_bytes(B, T, H) bytes, > 0 for H = 128 ... 512;
+ *   ZEROED ONCE by the caller, kept consistent by the kernels afterwards) a layer is ONE persistent launch per clip chunk:
+ *   a (16-clip slice, direction) is spread over H/64 workgroups that keep their rows of W_hh in registers for all T steps
+ *   and exchange the state (forward) / partial d h_prev (backward) through tagged 8-byte granules (csrc/gru_bf16_pers.h).
+ *   sync_ws = NULL, or a shape outside that range: one launch per time step.
+ *   sync_ws words: [0] launch generation, [1] arrivals, [2] bounded waits that gave up (a lost partner: the workgroups
+ *   concerned emit NaN from then on; the owner reads this word where it synchronises), [3] same-XCD fast-path count,
+ *   [5] fault injection for tests (1 + index of a workgroup that plays dead; 0 = off).
+ * By-products (each may be NULL): out_bf16 (N,2H) = bf16 copy of out; out_drop_bf16 (N,2H) = bf16 of dropout(out) with
+ *   ss_dropout's Philox stream at (seed, offset) over the (N,2H) index space -- nn.GRU's inter-layer dropout, ready as
+ *   the next layer's MFMA operand (drop_p = 0: a plain copy); d_g_bf16 (2,N,4,H) = bf16 copy of d_g; g_b* (all four or
+ *   none): d b_ih += column sums of (d r, d z, d n), d b_hh += column sums of (d r, d z, d hn) (what ss_gru_bias_grad
+ *   computes from d_g).  ss_gru_bf16_bwd: drop_p / seed / offset = the same mask re-drawn on d_out (see ss_gru_bwd).
+ * ss_cvt_bf16_rows: y[r][c] = bf16(x[r][c] * mask), c < cols; y[r][cols .. ld_y) = 0 (GEMM operands are read in whole
+ *   8-element chunks); cols, ld_x, ld_y % 4 == 0; the mask indexes the SOURCE element r * ld_x + c. */
 int ss_gru_bf16_prep(const float* w_hh_f, const float* w_hh_r, int H, uint16_t* whh_bf16, uint16_t* whh_t_bf16,
-                     ss_stream_t stream);
+                     const float* w_ih_f, const float* w_ih_r, int K, uint16_t* wih_bf16, ss_stream_t stream);
 int ss_gru_bf16_ws_bytes(int B, int H, long* bytes);
+int ss_gru_bf16_sync_bytes(int B, int T, int H, long* bytes);
 int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const float* b_hh_f, const float* b_hh_r,
-                    const int32_t* lengths, int B, int T, int H, float* out, float* save, void* ws, ss_stream_t stream);
+                    const int32_t* lengths, int B, int T, int H, float* out, float* save, uint16_t* out_bf16,
+                    uint16_t* out_drop_bf16, float drop_p, uint64_t seed, uint64_t offset, void* ws, void* sync_ws,
+                    ss_stream_t stream);
 int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, const uint16_t* whh_t_bf16,
-                    const int32_t* lengths, int B, int T, int H, float* d_g, float drop_p, uint64_t seed,
-                    uint64_t offset, void* ws, ss_stream_t stream);
+                    const int32_t* lengths, int B, int T, int H, float* d_g, uint16_t* d_g_bf16, float drop_p,
+                    uint64_t seed, uint64_t offset, float* g_bih_f, float* g_bhh_f, float* g_bih_r, float* g_bhh_r,
+                    void* ws, void* sync_ws, ss_stream_t stream);
+int ss_cvt_bf16_rows(const float* x, int ld_x, uint16_t* y, int ld_y, long rows, int cols, float drop_p, uint64_t seed,
+                     uint64_t offset, ss_stream_t stream);
 
 /* bf16 ROI-CNN of config 5: 96x96 uint8 frame -> normalise -> [conv3x3 + ReLU + maxpool2] x 3 (1->16->32->64) ->
  * conv3x3 64->96 + ReLU -> global average -> Linear(96 -> E): TinyROICNN (train_model_official.py:209-229) with a fourth

@@ -47,10 +47,12 @@ SIGNATURES = {
     "ss_c5_conv1_wgrad": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_c5_conv12_fwd": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_c5_conv2_wgrad_rc": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
-    "ss_gru_bf16_prep": [_vp, _vp, _i, _vp, _vp, _vp],
+    "ss_gru_bf16_prep": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "ss_gru_bf16_ws_bytes": [_i, _i, _vp],
-    "ss_gru_bf16_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "ss_gru_bf16_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _u64, _u64, _vp, _vp],
+    "ss_gru_bf16_sync_bytes": [_i, _i, _i, _vp],
+    "ss_gru_bf16_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _u64, _u64, _vp, _vp, _vp],
+    "ss_gru_bf16_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ss_cvt_bf16_rows": [_vp, _i, _vp, _i, _l, _i, _f, _u64, _u64, _vp],
     "ss_gemm_splitk_ws_floats": [_i, _i, _i, _i, _i, _vp],
     "ss_gemm_splitk_reduce": [_vp, _i, _i, _i, _i, _i, _vp, _i, _l, _vp],
     "ss_gemm_splitk_group_ws_floats": [_vp, _i, _vp],

@@ -89,7 +89,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         atomicAdd(dst, v);
       } else {
         if (accumulate) v += *dst;
-        if (relu) v = fmaxf(v, 0.f);
+        if (relu) v = relu_f(v);
         *dst = v;
       }
     }
@@ -120,7 +120,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         if (accumulate) v += *dst;
         if (relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
         }
         *dst = v;
       }

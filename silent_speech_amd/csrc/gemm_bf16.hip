@@ -5,6 +5,8 @@
 // rounded to bf16 (nearest even) while they are staged into LDS and multiplied on v_mfma_f32_16x16x32_bf16 with f32
 // accumulation; C, the bias and every accumulation (split-K float atomics) stay f32.
 //
+// Operands may also be bf16 already (flags bit 3: the recurrence kernels and ss_cvt_bf16_rows leave bf16 copies of the layer
+// inputs, the gate gradients and the weights): 16-byte loads straight into LDS, 64-deep k tiles.
 // 128 x 128 x 32 tiles, 4 waves (2 x 2, 64 x 64 each = 16 accumulators), double-buffered LDS, one barrier per k tile,
 // global loads of tile t+1 issued before the MFMAs of tile t.  k-contiguous operands sit in LDS as [row][32 + 8] and
 // are read with ds_read_b128 (row stride 80 B = 20 banks: the 16 rows of a fragment cover all 64 banks); k-major
@@ -14,15 +16,12 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDK = BK + 8;    // [row][k] image, elements per row
-constexpr int LDR = 128 + 8;   // [k][row] image, elements per k line
-constexpr int TILE_ELEMS = (BM * LDK > BK * LDR) ? BM * LDK : BK * LDR;
+constexpr int BM = 128, BN = 128;
 
 struct GemmBfParams {
   int M, N, K;
-  const float* A; int lda, a_group, a_gstride, a_off;
-  const float* B; int ldb, b_group, b_gstride, b_off;
+  const void* A; int lda, a_group, a_gstride, a_off;
+  const void* B; int ldb, b_group, b_gstride, b_off;
   float* C; int ldc;
   const float* bias;
   int flags, splits;
@@ -33,12 +32,19 @@ __device__ __forceinline__ long remap_row(int r, int group, int gstride, int off
   return (long)(r / group) * gstride + (r % group) + off;
 }
 
-// One operand tile (128 rows x 32 k) from HBM into 4 float4 registers per thread.
+// LDS images of one operand tile (128 rows x BK k): k-contiguous operands as [row][BK + 8] (row stride = BK/2 + 4 dwords: the 16
+// rows of a fragment read cover all 64 banks), k-major operands as [k][128 + 8].
+template <int BK> struct Tile {
+  static constexpr int LDK = BK + 8, LDR = 128 + 8;
+  static constexpr int ELEMS = (BM * LDK > BK * LDR) ? BM * LDK : BK * LDR;
+};
+
+// ---- f32 operands in HBM (rounded to bf16 on their way into LDS), BK = 32: 4 float4 per thread and tile
 // KC = 1: storage [row][k]: thread -> (row = idx / 8, k = 4 (idx % 8)), idx = tid + 256 i.
 // KC = 0: storage [k][row]: thread -> (k = idx / 32, row = 4 (idx % 32)).
 template <int KC>
-__device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int group, int gstride, int off, int row0, int rows,
-                                          int k0, int k_end, int tid, f32x4 v[4]) {
+__device__ __forceinline__ void load_tile_f32(const float* __restrict__ src, int ld, int group, int gstride, int off, int row0, int rows,
+                                              int k0, int k_end, int tid, f32x4 v[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + 256 * i;
@@ -55,23 +61,58 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld,
 }
 
 template <int KC>
-__device__ __forceinline__ void store_tile(bf16_t* tile, int tid, const f32x4 v[4]) {
+__device__ __forceinline__ void store_tile_f32(bf16_t* tile, int tid, const f32x4 v[4]) {
+  using T = Tile<32>;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + 256 * i;
-    bf16_t* dst = KC ? tile + (idx >> 3) * LDK + 4 * (idx & 7) : tile + (idx >> 5) * LDR + 4 * (idx & 31);
+    bf16_t* dst = KC ? tile + (idx >> 3) * T::LDK + 4 * (idx & 7) : tile + (idx >> 5) * T::LDR + 4 * (idx & 31);
     *reinterpret_cast<uint2*>(dst) = pack_bf16x4(v[i][0], v[i][1], v[i][2], v[i][3]);
   }
 }
 
-template <int AKC, int BKC>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE_ELEMS];  // A0 B0 A1 B1
+// ---- bf16 operands in HBM, BK = 64: 128 x 64 x 2 B = 16 KB per tile = 4 16-byte chunks per thread, no conversion.
+// KC = 1: thread -> (row = idx / 8, k = 8 (idx % 8));  KC = 0: thread -> (k = idx / 16, row = 8 (idx % 16)).
+// A chunk that starts inside the operand may run past its last row / k into the padding of the leading dimension (the caller
+// pads ld to a multiple of 8 with zeros: ss_cvt_bf16_rows), so only the chunk's first element is tested.
+template <int KC>
+__device__ __forceinline__ void load_tile_b16(const bf16_t* __restrict__ src, int ld, int group, int gstride, int off, int row0, int rows,
+                                              int k0, int k_end, int tid, s16x8 v[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    s16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (KC) {
+      const int r = row0 + (idx >> 3), k = k0 + 8 * (idx & 7);
+      if (r < rows && k < k_end) x = *reinterpret_cast<const s16x8*>(src + remap_row(r, group, gstride, off) * ld + k);
+    } else {
+      const int k = k0 + (idx >> 4), r = row0 + 8 * (idx & 15);
+      if (k < k_end && r < rows) x = *reinterpret_cast<const s16x8*>(src + remap_row(k, group, gstride, off) * ld + r);
+    }
+    v[i] = x;
+  }
+}
+
+template <int KC>
+__device__ __forceinline__ void store_tile_b16(bf16_t* tile, int tid, const s16x8 v[4]) {
+  using T = Tile<64>;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    bf16_t* dst = KC ? tile + (idx >> 3) * T::LDK + 8 * (idx & 7) : tile + (idx >> 4) * T::LDR + 8 * (idx & 15);
+    *reinterpret_cast<s16x8*>(dst) = v[i];
+  }
+}
+
+// SRC16 = 0: f32 operands (BK = 32); 1: bf16 operands (BK = 64).  Two workgroups per CU (the LDS images take 41 / 74 KB).
+template <int AKC, int BKC, int SRC16>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBfParams p) {
+  constexpr int BK = SRC16 ? 64 : 32;
+  using T = Tile<BK>;
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];  // A0 B0 A1 B1
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int batch = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
-  const float* A = p.A + batch * p.sa;
-  const float* B = p.B + batch * p.sb;
   float* C = p.C + batch * p.sc;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   // K range of this split, in whole k tiles
@@ -86,37 +127,59 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (kt0 < kt1) {
-    f32x4 va[4], vb[4];
-    load_tile<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, kt0 * BK, p.K, tid, va);
-    load_tile<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, kt0 * BK, p.K, tid, vb);
-    store_tile<AKC>(lds, tid, va);
-    store_tile<BKC>(lds + TILE_ELEMS, tid, vb);
+  auto mainloop = [&](auto load_a, auto load_b, auto store_a, auto store_b, auto& va, auto& vb) {
+    load_a(kt0 * BK, va);
+    load_b(kt0 * BK, vb);
+    store_a(lds, va);
+    store_b(lds + T::ELEMS, vb);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
       const int cur = (kt - kt0) & 1;
-      const bf16_t* As = lds + (2 * cur) * TILE_ELEMS;
-      const bf16_t* Bs = lds + (2 * cur + 1) * TILE_ELEMS;
+      const bf16_t* As = lds + (2 * cur) * T::ELEMS;
+      const bf16_t* Bs = lds + (2 * cur + 1) * T::ELEMS;
       const bool more = kt + 1 < kt1;
       if (more) {
-        load_tile<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, (kt + 1) * BK, p.K, tid, va);
-        load_tile<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, (kt + 1) * BK, p.K, tid, vb);
-      }
-      s16x8 fa[4], fb[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fa[t] = AKC ? lds_frag(As + (wm + 16 * t + li) * LDK + 8 * g) : lds_frag_tr(As + wm + 16 * t, LDR, lane);
-        fb[t] = BKC ? lds_frag(Bs + (wn + 16 * t + li) * LDK + 8 * g) : lds_frag_tr(Bs + wn + 16 * t, LDR, lane);
+        load_a((kt + 1) * BK, va);
+        load_b((kt + 1) * BK, vb);
       }
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int kk = 0; kk < BK; kk += 32) {
+        s16x8 fa[4], fb[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
+        for (int t = 0; t < 4; ++t) {
+          fa[t] = AKC ? lds_frag(As + (wm + 16 * t + li) * T::LDK + kk + 8 * g) : lds_frag_tr(As + kk * T::LDR + wm + 16 * t, T::LDR, lane);
+          fb[t] = BKC ? lds_frag(Bs + (wn + 16 * t + li) * T::LDK + kk + 8 * g) : lds_frag_tr(Bs + kk * T::LDR + wn + 16 * t, T::LDR, lane);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
+      }
       if (more) {
-        store_tile<AKC>(lds + (2 * (cur ^ 1)) * TILE_ELEMS, tid, va);
-        store_tile<BKC>(lds + (2 * (cur ^ 1) + 1) * TILE_ELEMS, tid, vb);
+        store_a(lds + (2 * (cur ^ 1)) * T::ELEMS, va);
+        store_b(lds + (2 * (cur ^ 1) + 1) * T::ELEMS, vb);
       }
       __syncthreads();
+    }
+  };
+
+  if (kt0 < kt1) {
+    if constexpr (SRC16) {
+      const bf16_t* A = static_cast<const bf16_t*>(p.A) + batch * p.sa;
+      const bf16_t* B = static_cast<const bf16_t*>(p.B) + batch * p.sb;
+      s16x8 va[4], vb[4];
+      mainloop([&](int k0, s16x8* v) { load_tile_b16<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, k0, p.K, tid, v); },
+               [&](int k0, s16x8* v) { load_tile_b16<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, k0, p.K, tid, v); },
+               [&](bf16_t* t, const s16x8* v) { store_tile_b16<AKC>(t, tid, v); },
+               [&](bf16_t* t, const s16x8* v) { store_tile_b16<BKC>(t, tid, v); }, va, vb);
+    } else {
+      const float* A = static_cast<const float*>(p.A) + batch * p.sa;
+      const float* B = static_cast<const float*>(p.B) + batch * p.sb;
+      f32x4 va[4], vb[4];
+      mainloop([&](int k0, f32x4* v) { load_tile_f32<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, k0, p.K, tid, v); },
+               [&](int k0, f32x4* v) { load_tile_f32<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, k0, p.K, tid, v); },
+               [&](bf16_t* t, const f32x4* v) { store_tile_f32<AKC>(t, tid, v); },
+               [&](bf16_t* t, const f32x4* v) { store_tile_f32<BKC>(t, tid, v); }, va, vb);
     }
   }
 
@@ -143,34 +206,57 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBfParams p) {
   }
 }
 
+template <int AKC, int BKC, int SRC16>
+int launch_one(const GemmBfParams& p, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = 4 * Tile<SRC16 ? 64 : 32>::ELEMS * sizeof(bf16_t);
+  static bool attr_set = false;  // the bf16-operand tiles take 72 KB of dynamic LDS: above the 64 KB a launch gets by default
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AKC, BKC, SRC16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return SS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel<AKC, BKC, SRC16>), grid, dim3(256), lds, s, p);
+  return ss_launch_status();
+}
+
+template <int SRC16>
+int launch_gemm_bf16(int a_kcontig, int b_kcontig, const GemmBfParams& p, dim3 grid, hipStream_t s) {
+  if (a_kcontig && b_kcontig) return launch_one<1, 1, SRC16>(p, grid, s);
+  if (a_kcontig) return launch_one<1, 0, SRC16>(p, grid, s);
+  if (b_kcontig) return launch_one<0, 1, SRC16>(p, grid, s);
+  return launch_one<0, 0, SRC16>(p, grid, s);
+}
+
 }  // namespace
 
-extern "C" int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, int a_group,
-                                    int a_gstride, int a_off, const float* B, int ldb, int b_group, int b_gstride, int b_off,
+extern "C" int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const void* A, int lda, int a_group,
+                                    int a_gstride, int a_off, const void* B, int ldb, int b_group, int b_gstride, int b_off,
                                     float* C, int ldc, const float* bias, int flags, int splits, int batch, long stride_a,
                                     long stride_b, long stride_c, long stride_bias, ss_stream_t stream) {
   SS_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && splits > 0, SS_ERR_ARG);
   SS_REQUIRE(a_group > 0 && b_group > 0, SS_ERR_ARG);
-  SS_REQUIRE(!(flags & ~5), SS_ERR_UNSUPPORTED);                 // bit0 accumulate, bit2 atomics
+  SS_REQUIRE(!(flags & ~13), SS_ERR_UNSUPPORTED);                // bit0 accumulate, bit2 atomics, bit3 operands are bf16 in HBM
   SS_REQUIRE(splits == 1 || (flags & 1), SS_ERR_ARG);            // K slices add into a C the caller initialised
   SS_REQUIRE(!(flags & 4) || (flags & 1), SS_ERR_ARG);
-  // 16-byte loads along the contiguous dimension of either layout
-  SS_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && stride_a % 4 == 0 && stride_b % 4 == 0, SS_ERR_UNSUPPORTED);
-  SS_REQUIRE((a_kcontig ? K : M) % 4 == 0 && (b_kcontig ? K : N) % 4 == 0, SS_ERR_UNSUPPORTED);
+  const bool src16 = flags & 8;
+  // 16-byte loads along the contiguous dimension of either layout: 4 floats / 8 bf16 (bf16 operands: the leading dimension is
+  // padded to it, the extent itself need not be)
+  const int q = src16 ? 8 : 4;
+  SS_REQUIRE(lda % q == 0 && ldb % q == 0 && stride_a % q == 0 && stride_b % q == 0, SS_ERR_UNSUPPORTED);
+  SS_REQUIRE(src16 || ((a_kcontig ? K : M) % 4 == 0 && (b_kcontig ? K : N) % 4 == 0), SS_ERR_UNSUPPORTED);
+  SS_REQUIRE(!src16 || ((a_kcontig ? K : M) <= lda && (b_kcontig ? K : N) <= ldb), SS_ERR_ARG);
   SS_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0, SS_ERR_UNSUPPORTED);
   GemmBfParams p;
   p.M = M; p.N = N; p.K = K;
   p.A = A; p.lda = lda; p.a_group = a_group; p.a_gstride = a_gstride; p.a_off = a_off;
   p.B = B; p.ldb = ldb; p.b_group = b_group; p.b_gstride = b_gstride; p.b_off = b_off;
   p.C = C; p.ldc = ldc; p.bias = bias; p.flags = flags;
-  const int nkt = (K + BK - 1) / BK;
+  const int bk = src16 ? 64 : 32;
+  const int nkt = (K + bk - 1) / bk;
   p.splits = splits < nkt ? splits : nkt;
   p.sa = stride_a; p.sb = stride_b; p.sc = stride_c; p.sbias = stride_bias;
   dim3 grid(ceil_div(N, BN), ceil_div(M, BM), batch * p.splits);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (a_kcontig && b_kcontig) hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, dim3(256), 0, s, p);
-  else if (a_kcontig) hipLaunchKernelGGL((gemm_bf16_kernel<1, 0>), grid, dim3(256), 0, s, p);
-  else if (b_kcontig) hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, dim3(256), 0, s, p);
-  return ss_launch_status();
+  return src16 ? launch_gemm_bf16<1>(a_kcontig, b_kcontig, p, grid, s) : launch_gemm_bf16<0>(a_kcontig, b_kcontig, p, grid, s);
 }

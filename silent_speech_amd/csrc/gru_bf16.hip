@@ -13,6 +13,7 @@
 // Packed-sequence semantics by masking, exactly as gru.hip: forward direction t = s, reverse direction t = T-1-s at step
 // s; a step with t >= len[b] leaves the state (and emits zeros); the reverse direction therefore starts at len-1.
 #include "bf16_common.h"
+#include "gru_bf16_pers.h"
 
 namespace {
 
@@ -21,14 +22,27 @@ namespace {
 // as often and a step is one memory round trip either way.)
 constexpr int CT = 4, CG = 16 * CT;
 
-// ---- W_hh (f32, [3H][H]) of both directions -> bf16 copy and bf16 transpose [H][3H]
+// ---- once per optimiser step and layer: W_hh (f32, [3H][H]) of both directions -> bf16 copy and bf16 transpose [H][3H]
+// (blockIdx.z = 0, 1), and W_ih (f32, [3H][K]) of both directions -> bf16 [3H][Kp], Kp = K rounded up to 8, zero-padded
+// (blockIdx.z = 2, 3): the MFMA operands of the recurrence and of the layer's three GEMM families
 __global__ __launch_bounds__(256) void whh_prep_kernel(const float* __restrict__ w_f, const float* __restrict__ w_r, int H,
-                                                       bf16_t* __restrict__ wb, bf16_t* __restrict__ wtb) {
+                                                       bf16_t* __restrict__ wb, bf16_t* __restrict__ wtb,
+                                                       const float* __restrict__ wi_f, const float* __restrict__ wi_r, int K, int Kp,
+                                                       bf16_t* __restrict__ wib) {
   __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;  // rows of W (3H), columns
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (blockIdx.z >= 2) {
+    if (!wib || c0 >= Kp) return;
+    const int dir = blockIdx.z - 2;
+    const float* w = dir ? wi_r : wi_f;
+    for (int i = ty; i < 32; i += 8)
+      if (c0 + tx < Kp) wib[(long)dir * 3 * H * Kp + (long)(r0 + i) * Kp + c0 + tx] = to_bf16(c0 + tx < K ? w[(long)(r0 + i) * K + c0 + tx] : 0.f);
+    return;
+  }
+  if (c0 >= H) return;
   const int dir = blockIdx.z;
   const float* w = dir ? w_r : w_f;
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;  // rows of W (3H), columns (H)
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8) {
     const float v = w[(long)(r0 + i) * H + c0 + tx];
     tile[i][tx] = v;
@@ -286,13 +300,81 @@ void launch_bwd_steps(StepBwdParams p, bf16_t* base, int T, hipStream_t stream) 
   }
 }
 
+// f32 rows -> bf16 rows (optionally through a dropout mask of ss_dropout's Philox stream over the SOURCE index space), 4 elements
+// per thread; destination columns [cols, ld_y) are zero-filled (the GEMM reads whole 8-element chunks)
+__global__ __launch_bounds__(256) void cvt_bf16_rows_kernel(const float* __restrict__ x, int ld_x, bf16_t* __restrict__ y, int ld_y,
+                                                            long rows, int cols, float drop_p, uint64_t seed, uint64_t offset) {
+  const int c4 = ld_y >> 2;
+  const long total = rows * c4;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+    const long r = q / c4;
+    const int c = 4 * (int)(q - r * c4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+      v = *reinterpret_cast<const f32x4*>(x + r * ld_x + c);
+      if (drop_p > 0.f) v *= drop_scale4((r * ld_x + c) >> 2, drop_p, seed, offset);
+    }
+    *reinterpret_cast<uint2*>(y + r * ld_y + c) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+void cvt_rows(const float* x, int ld_x, bf16_t* y, int ld_y, long rows, int cols, float drop_p, uint64_t seed, uint64_t offset,
+              hipStream_t st) {
+  const long total = rows * (ld_y / 4);
+  long blocks = (total + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(cvt_bf16_rows_kernel, dim3((int)blocks), dim3(256), 0, st, x, ld_x, y, ld_y, rows, cols, drop_p, seed, offset);
+}
+
+template <int H>
+void launch_pers_fwd(PersFwdParams p, void* sync_ws, int chunk, hipStream_t st) {
+  constexpr int P = H / PUNITS;
+  unsigned* sy = static_cast<unsigned*>(sync_ws);
+  const int gmax = 2 * ceil_div(chunk, PSLICE);
+  u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
+  u64* hx = xid + pers_xid_granules(gmax, P);
+  for (int c0 = 0; c0 < p.B; c0 += chunk) {
+    p.c0 = c0;
+    p.nc = p.B - c0 < chunk ? p.B - c0 : chunk;
+    hipLaunchKernelGGL(gru_pers_fwd_kernel<H>, dim3(2 * ceil_div(p.nc, PSLICE) * P), dim3(256), 0, st, p, sy, xid, hx);
+  }
+}
+
+template <int H>
+void launch_pers_bwd(PersBwdParams p, void* sync_ws, int chunk, hipStream_t st) {
+  constexpr int P = H / PUNITS;
+  unsigned* sy = static_cast<unsigned*>(sync_ws);
+  const int gmax = 2 * ceil_div(chunk, PSLICE);
+  u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
+  u64* xg = xid + pers_xid_granules(gmax, P) + pers_fwd_granules(gmax, H);
+  for (int c0 = 0; c0 < p.B; c0 += chunk) {
+    p.c0 = c0;
+    p.nc = p.B - c0 < chunk ? p.B - c0 : chunk;
+    hipLaunchKernelGGL(gru_pers_bwd_kernel<H>, dim3(2 * ceil_div(p.nc, PSLICE) * P), dim3(256), 0, st, p, sy, xid, xg);
+  }
+}
+
 }  // namespace
 
 extern "C" int ss_gru_bf16_prep(const float* w_hh_f, const float* w_hh_r, int H, uint16_t* whh_bf16, uint16_t* whh_t_bf16,
-                                ss_stream_t stream) {
+                                const float* w_ih_f, const float* w_ih_r, int K, uint16_t* wih_bf16, ss_stream_t stream) {
   SS_REQUIRE(w_hh_f && w_hh_r && whh_bf16 && whh_t_bf16 && H > 0 && H % 32 == 0, SS_ERR_ARG);
-  hipLaunchKernelGGL(whh_prep_kernel, dim3(H / 32, 3 * H / 32, 2), dim3(256), 0, static_cast<hipStream_t>(stream), w_hh_f, w_hh_r,
-                     H, whh_bf16, whh_t_bf16);
+  SS_REQUIRE(!wih_bf16 || (w_ih_f && w_ih_r && K > 0), SS_ERR_ARG);
+  const int Kp = wih_bf16 ? (K + 7) / 8 * 8 : 0;
+  const int gx = ceil_div(H > Kp ? H : Kp, 32);
+  hipLaunchKernelGGL(whh_prep_kernel, dim3(gx, 3 * H / 32, wih_bf16 ? 4 : 2), dim3(256), 0, static_cast<hipStream_t>(stream), w_hh_f,
+                     w_hh_r, H, whh_bf16, whh_t_bf16, w_ih_f, w_ih_r, K, Kp, wih_bf16);
   return ss_launch_status();
 }
 
@@ -303,17 +385,54 @@ extern "C" int ss_gru_bf16_ws_bytes(int B, int H, long* bytes) {
   return SS_OK;
 }
 
-// All T steps of one layer, both directions (T launches on ``stream``).
+extern "C" int ss_gru_bf16_sync_bytes(int B, int T, int H, long* bytes) {
+  SS_REQUIRE(bytes && B > 0 && T > 0 && H > 0, SS_ERR_ARG);
+  *bytes = 0;
+  if (!pers_supported(H) || T > 1022) return SS_OK;  // step tags are 10 bits
+  const int chunk = pers_chunk_clips(B, H, device_cus());
+  if (chunk <= 0) return SS_OK;
+  const int gmax = 2 * ceil_div(chunk, PSLICE);
+  *bytes = SYNC_HDR_WORDS * 4L + (pers_xid_granules(gmax, H / PUNITS) + pers_fwd_granules(gmax, H) + pers_bwd_granules(gmax, H)) * 8;
+  return SS_OK;
+}
+
+extern "C" int ss_cvt_bf16_rows(const float* x, int ld_x, uint16_t* y, int ld_y, long rows, int cols, float drop_p, uint64_t seed,
+                                uint64_t offset, ss_stream_t stream) {
+  SS_REQUIRE(x && y && rows > 0 && cols > 0 && ld_x >= cols && ld_y >= cols, SS_ERR_ARG);
+  SS_REQUIRE(cols % 4 == 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, SS_ERR_ARG);
+  cvt_rows(x, ld_x, y, ld_y, rows, cols, drop_p, seed, offset, static_cast<hipStream_t>(stream));
+  return ss_launch_status();
+}
+
+// One layer, both directions.  With a sync workspace (ss_gru_bf16_sync_bytes > 0, zeroed once by the caller) ONE persistent
+// launch per clip chunk; otherwise T step launches.
 extern "C" int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const float* b_hh_f, const float* b_hh_r,
-                               const int32_t* lengths, int B, int T, int H, float* out, float* save, void* ws,
+                               const int32_t* lengths, int B, int T, int H, float* out, float* save, uint16_t* out_bf16,
+                               uint16_t* out_drop_bf16, float drop_p, uint64_t seed, uint64_t offset, void* ws, void* sync_ws,
                                ss_stream_t stream) {
   SS_REQUIRE(gi && whh_bf16 && b_hh_f && b_hh_r && lengths && out && ws, SS_ERR_ARG);
-  SS_REQUIRE(B > 0 && T > 0 && H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);  // four waves x whole 32-deep k steps; built: 128..512, 1024
+  SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
+  SS_REQUIRE(H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);  // (step kernels: four waves x whole 32-deep k steps; built: 128..512, 1024)
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunk = (sync_ws && pers_supported(H) && T <= 1022) ? pers_chunk_clips(B, H, device_cus()) : 0;
+  if (chunk > 0) {
+    PersFwdParams q;
+    q.gi = gi; q.whh = whh_bf16; q.bhh_f = b_hh_f; q.bhh_r = b_hh_r; q.lengths = lengths; q.B = B; q.T = T;
+    q.out = out; q.save = save; q.out_bf = out_bf16; q.out_drop_bf = out_drop_bf16; q.drop_p = drop_p; q.seed = seed; q.offset = offset;
+    switch (H) {
+      case 128: launch_pers_fwd<128>(q, sync_ws, chunk, st); break;
+      case 256: launch_pers_fwd<256>(q, sync_ws, chunk, st); break;
+      case 384: launch_pers_fwd<384>(q, sync_ws, chunk, st); break;
+      case 512: launch_pers_fwd<512>(q, sync_ws, chunk, st); break;
+      default: return SS_ERR_UNSUPPORTED;
+    }
+    return ss_launch_status();
+  }
   StepFwdParams p;
   p.gi = gi; p.whh = whh_bf16; p.bhh_f = b_hh_f; p.bhh_r = b_hh_r; p.lengths = lengths;
   p.B = B; p.T = T; p.H = H; p.out = out; p.save = save;
   bf16_t* hb = static_cast<bf16_t*>(ws);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {
     case 128: launch_fwd_steps<128>(p, hb, T, st); break;
     case 256: launch_fwd_steps<256>(p, hb, T, st); break;
@@ -322,22 +441,43 @@ extern "C" int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const 
     case 1024: launch_fwd_steps<1024>(p, hb, T, st); break;
     default: return SS_ERR_UNSUPPORTED;
   }
+  const long N = (long)B * T;
+  if (out_bf16) cvt_rows(out, 2 * H, out_bf16, 2 * H, N, 2 * H, 0.f, 0, 0, st);
+  if (out_drop_bf16) cvt_rows(out, 2 * H, out_drop_bf16, 2 * H, N, 2 * H, drop_p, seed, offset, st);
   return ss_launch_status();
 }
 
 extern "C" int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, const uint16_t* whh_t_bf16,
-                               const int32_t* lengths, int B, int T, int H, float* d_g, float drop_p, uint64_t seed,
-                               uint64_t offset, void* ws, ss_stream_t stream) {
+                               const int32_t* lengths, int B, int T, int H, float* d_g, uint16_t* d_g_bf16, float drop_p,
+                               uint64_t seed, uint64_t offset, float* g_bih_f, float* g_bhh_f, float* g_bih_r, float* g_bhh_r,
+                               void* ws, void* sync_ws, ss_stream_t stream) {
   SS_REQUIRE(d_out && out && save && whh_t_bf16 && lengths && d_g && ws, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
   SS_REQUIRE(H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);
+  const bool want_bias = g_bih_f || g_bhh_f || g_bih_r || g_bhh_r;
+  SS_REQUIRE(!want_bias || (g_bih_f && g_bhh_f && g_bih_r && g_bhh_r), SS_ERR_ARG);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunk = (sync_ws && pers_supported(H) && T <= 1022) ? pers_chunk_clips(B, H, device_cus()) : 0;
+  if (chunk > 0) {
+    PersBwdParams q;
+    q.d_out = d_out; q.out = out; q.save = save; q.whht = whh_t_bf16; q.lengths = lengths; q.B = B; q.T = T;
+    q.dG = d_g; q.dG_bf = d_g_bf16; q.drop_p = drop_p; q.seed = seed; q.offset = offset;
+    q.g_bih[0] = g_bih_f; q.g_bih[1] = g_bih_r; q.g_bhh[0] = g_bhh_f; q.g_bhh[1] = g_bhh_r;
+    switch (H) {
+      case 128: launch_pers_bwd<128>(q, sync_ws, chunk, st); break;
+      case 256: launch_pers_bwd<256>(q, sync_ws, chunk, st); break;
+      case 384: launch_pers_bwd<384>(q, sync_ws, chunk, st); break;
+      case 512: launch_pers_bwd<512>(q, sync_ws, chunk, st); break;
+      default: return SS_ERR_UNSUPPORTED;
+    }
+    return ss_launch_status();
+  }
   StepBwdParams p;
   p.d_out = d_out; p.out = out; p.save = save; p.whht = whh_t_bf16; p.lengths = lengths;
   p.B = B; p.T = T; p.H = H; p.dG = d_g; p.drop_p = drop_p; p.seed = seed; p.offset = offset;
   bf16_t* base = static_cast<bf16_t*>(ws) + 2L * 2 * B * H;  // behind the two forward state slots
   const long slot = 2L * B * 3 * H;
   p.dhz = reinterpret_cast<float*>(base + 2 * slot);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   switch (H) {
     case 128: launch_bwd_steps<128>(p, base, T, st); break;
     case 256: launch_bwd_steps<256>(p, base, T, st); break;
@@ -345,6 +485,12 @@ extern "C" int ss_gru_bf16_bwd(const float* d_out, const float* out, const float
     case 512: launch_bwd_steps<512>(p, base, T, st); break;
     case 1024: launch_bwd_steps<1024>(p, base, T, st); break;
     default: return SS_ERR_UNSUPPORTED;
+  }
+  const long N = (long)B * T;
+  if (d_g_bf16) cvt_rows(d_g, 4 * H, d_g_bf16, 4 * H, 2 * N, 4 * H, 0.f, 0, 0, st);
+  if (want_bias) {
+    const int rc = ss_gru_bias_grad(d_g, (int)N, H, g_bih_f, g_bhh_f, g_bih_r, g_bhh_r, stream);
+    if (rc != SS_OK) return rc;
   }
   return ss_launch_status();
 }

@@ -34,117 +34,17 @@
 // with NaN and counts an error in the sync header instead of hanging the GPU.
 //
 // sync_ws layout: [0] generation, [1] finished workgroups of the running launch, [2] sweep time-outs ever seen,
-// [3] workgroup-launches that took the same-XCD fast path, [4] time-outs at the end of the previous launch, [5] fault
-// injection (tests only, see plays_dead),
+// [3] workgroup-launches that took the same-XCD fast path, [5] fault injection (tests only, see plays_dead),
 // [.. 64) pad | XCD ids [pairs][P] u64 | forward granules [2][pairs][16][H] u64 | backward granules
 // [2][pairs][P dest][P src][16][H/P] u64.
 // The owner zeroes it once; after that the kernels keep it consistent.
 #pragma once
+#include "granule_xchg.h"
 
 namespace {
 
-constexpr int SYNC_HDR_WORDS = 64;
 constexpr int SPLIT_MAX_WGS = 240;   // co-residency bound (256 CUs, one 4-wave workgroup each, some slack)
 constexpr int SPLIT_MAX_T = 1022;
-
-#define SS_AGENT __HIP_MEMORY_SCOPE_AGENT
-typedef unsigned long long u64;
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr int AUX_SC1 = 16;  // cache-policy operand of the raw buffer intrinsics: bit 4 = sc1 (agent scope)
-
-__device__ __forceinline__ rsrc_t granule_rsrc(u64* base, long granules) {
-  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(granules * 8), 0x00020000);
-}
-
-// Two adjacent granules in ONE 16-byte write-through store (each 8-byte half lands whole; a 16-byte sc1 store costs
-// the fabric what an 8-byte one does).  `pair` = index of the granule pair.
-__device__ __forceinline__ void store_granule_pair(rsrc_t rs, int pair, unsigned tag, float v0, float v1, bool same_xcd) {
-  const u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
-  if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(d, rs, pair * 16, 0, 0);  // stays in the shared L2 (wave-uniform branch)
-  else __builtin_amdgcn_raw_buffer_store_b128(d, rs, pair * 16, 0, AUX_SC1);
-}
-
-// Which XCD this workgroup runs on, and whether all P partners of its pair share it.  xid: [pairs][P] granules in the
-// sync header area, tag = generation base + 1023 (step tags are base + 1 .. base + 1022; never 0, the cleared state).
-__device__ __forceinline__ bool partners_share_xcd(u64* xid, int pair, int part, int P, unsigned base, unsigned* errors, int lane) {
-  base += 1023u;
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  xcc &= 15u;
-  u64* mine = xid + (long)pair * P;
-  if (threadIdx.x == 0) __hip_atomic_store(mine + part, ((u64)base << 32) | xcc, __ATOMIC_RELAXED, SS_AGENT);
-  bool same = true;
-  for (int spins = 0;; ++spins) {
-    const u64 x = lane < P ? __hip_atomic_load(mine + lane, __ATOMIC_RELAXED, SS_AGENT) : (((u64)base << 32) | xcc);
-    const bool ok = (unsigned)(x >> 32) == base;
-    if (__all(ok)) {
-      same = __all((unsigned)x == xcc);
-      break;
-    }
-    if (spins > (1 << 20)) {
-      if (lane == 0) atomicAdd(errors, 1u);
-      same = false;
-      break;
-    }
-  }
-  return same;
-}
-
-// One wave re-reads its N granule pairs (pair stride 256: the whole workgroup sweeps a contiguous run) until every
-// tag matches.
-template <int N>
-__device__ __forceinline__ bool sweep_granules(rsrc_t rs, int pair0, unsigned tag, float (&v)[2 * N], unsigned* errors, int lane) {
-  for (int spins = 0;;) {
-    bool ok = true;
-    asm volatile("" ::: "memory");  // every pass really loads again
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, (pair0 + 256 * k) * 16, 0, AUX_SC1);
-      v[2 * k] = __uint_as_float(x[0]);
-      v[2 * k + 1] = __uint_as_float(x[2]);
-      ok &= x[1] == tag && x[3] == tag;
-    }
-    if (__all(ok)) return true;
-    if (++spins > (1 << 20)) {  // ~1 s of sweeping: a partner is gone
-      if (lane == 0) atomicAdd(errors, 1u);
-      return false;
-    }
-  }
-}
-
-// sync[2] counts bounded waits that gave up (never reset: the host reads it where it synchronises anyway, see
-// engine.check_gru_sync); sync[4] = its value at the end of the previous launch.  A workgroup that loses a partner poisons
-// element 0 of the result itself, but that element belongs to one (clip 0, t = 0) workgroup which may store it AFTER the
-// poison; so the LAST workgroup of the launch poisons it again whenever the counter moved during this launch.  Ordering: every
-// thread drains and writes back its own stores at agent scope (__threadfence: the waves of a workgroup count their stores
-// separately, and the owner of element 0 may sit on another XCD's L2) before its workgroup arrives with a release; the last
-// workgroup acquires before it writes the NaN, write-through -- so the owner's store is in memory before the poison is.
-__device__ __forceinline__ void finish_launch(unsigned* sync, unsigned gen, float* poison) {
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned done = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELEASE, SS_AGENT);
-    if (done == gridDim.x - 1) {
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      const unsigned errs = __hip_atomic_load(&sync[2], __ATOMIC_RELAXED, SS_AGENT);
-      if (errs != sync[4]) {
-        __hip_atomic_store(poison, __builtin_nanf(""), __ATOMIC_RELAXED, SS_AGENT);
-        sync[4] = errs;
-      }
-      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, SS_AGENT);
-      __hip_atomic_store(&sync[0], gen + 1u, __ATOMIC_RELEASE, SS_AGENT);
-    }
-  }
-}
-
-// Fault injection for the tests of the failure channel (tests/test_gpu_kernels.py::test_gru_lost_partner_reaches_the_host):
-// sync[5] = 1 + the index of a workgroup that plays dead -- it publishes nothing and only arrives at the end, so its partners'
-// bounded waits run out.  Zero (the cleared state) = off; the owner of the workspace sets it, the kernels never do.
-__device__ __forceinline__ bool plays_dead(const unsigned* sync) {
-  return __hip_atomic_load(&sync[5], __ATOMIC_RELAXED, SS_AGENT) == blockIdx.x + 1u;
-}
 
 template <int H, int P>
 struct SplitCfg {
@@ -183,7 +83,7 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
   if (plays_dead(sync)) {  // wave-uniform; tests only
     __syncthreads();
-    finish_launch(sync, s_gen, p.out);
+    finish_launch(sync, s_gen);
     return;
   }
   // every cycle of this chain is on the step's critical path: issue ahead of the weight-gradient GEMM waves that
@@ -213,13 +113,13 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   __syncthreads();
   const unsigned gen = s_gen;
   const unsigned base = (gen & 0x3FFFFFu) << 10;
-  const bool same_xcd = partners_share_xcd(xid, pair, part, P, base, &sync[2], lane);
+  bool dead = false;  // a partner never arrived: everything this workgroup emits from then on is NaN
+  const bool same_xcd = partners_share_xcd(xid, pair, part, P, base, &sync[2], lane, &dead);
   if (threadIdx.x == 0 && same_xcd) atomicAdd(&sync[3], 1u);  // observability: workgroup-launches on the fast path
 
   f32x4 hp = {0.f, 0.f, 0.f, 0.f};
   const long dir_off = (long)dir * p.B * T;
   const rsrc_t hrs = granule_rsrc(hx, 2L * pairs * SLICE * H);
-  bool dead = false;
   STAMP_ENTRY;
   STAMP_DECL;
   for (int s = 0; s < T; ++s) {
@@ -293,6 +193,7 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
         hp = hn;
         o = hn;
       }
+      if (dead) o = f32x4{NAN_F, NAN_F, NAN_F, NAN_F};  // padding rows too: the tail masks by length, the poison must not hide
       if (s + 1 < T) {  // publish (padding clips too: the partners sweep whole panels)
         const int hw = ((((s & 1) * pairs + pair) * SLICE + i) * H + j0) / 2;
         store_granule_pair(hrs, hw, base + (unsigned)s + 1u, o[0], o[1], same_xcd);
@@ -311,9 +212,8 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
       }
     }
   }
-  if (dead && lane == 0) p.out[0] = __builtin_nanf("");
   STAMP_FLUSH();
-  finish_launch(sync, gen, p.out);
+  finish_launch(sync, gen);
 }
 
 // xg: [2 step parity][pairs][P dest parts][P source parts][16 clips][UP]  partial dh_prev granules
@@ -346,7 +246,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
   if (plays_dead(sync)) {  // wave-uniform; tests only
     __syncthreads();
-    finish_launch(sync, s_gen, p.d_g);
+    finish_launch(sync, s_gen);
     return;
   }
   __builtin_amdgcn_s_setprio(3);  // as in the forward kernel
@@ -369,14 +269,14 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   __syncthreads();
   const unsigned gen = s_gen;
   const unsigned base = (gen & 0x3FFFFFu) << 10;
-  const bool same_xcd = partners_share_xcd(xid, pair, part, P, base, &sync[2], lane);
+  bool dead = false;  // a partner never arrived: every gate gradient this workgroup emits from then on is NaN
+  const bool same_xcd = partners_share_xcd(xid, pair, part, P, base, &sync[2], lane, &dead);
   if (threadIdx.x == 0 && same_xcd) atomicAdd(&sync[3], 1u);  // observability: workgroup-launches on the fast path
 
   f32x4 dh = {0.f, 0.f, 0.f, 0.f};
   GruBiasAcc bacc;
   const long dir_off = (long)dir * p.B * T;
   const rsrc_t xrs = granule_rsrc(xg, 2L * pairs * P * SLICE * H);
-  bool dead = false;
   // inputs of one step (owner waves): loaded a step ahead, while the exchange of the current step is in flight
   f32x4 go, sr, sz, sn, sq, hprev;
   auto load_inputs = [&](int s) {
@@ -421,6 +321,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
           dcarry[e] = d * sz[e];
         }
       }
+      if (dead) dar = daz = dan = dqn = f32x4{NAN_F, NAN_F, NAN_F, NAN_F};
       if (!last) {
         float* dp = &dpan[i * LDP + 16 * ut + 4 * g];
         *reinterpret_cast<f32x4*>(dp) = dar;
@@ -480,10 +381,9 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
     if (owner) dh = dcarry + *reinterpret_cast<const f32x4*>(&dsum[i * C::UP + 16 * ut + 4 * g]);
     STAMP(1);
   }
-  if (dead && lane == 0) p.d_g[0] = __builtin_nanf("");
   if (owner) bacc.flush(p, dir, H, j0, i);  // owner is wave-uniform
   STAMP_FLUSH();
-  finish_launch(sync, gen, p.d_g);
+  finish_launch(sync, gen);
 }
 
 // sync_ws sections, in granules

@@ -130,6 +130,9 @@ __device__ __forceinline__ f32x4 drop_scale4(long q, float p, uint64_t seed, uin
   return f32x4{rnd[0] >= thr ? keep : 0.f, rnd[1] >= thr ? keep : 0.f, rnd[2] >= thr ? keep : 0.f, rnd[3] >= thr ? keep : 0.f};
 }
 
+// ReLU as torch.relu computes it: a NaN stays a NaN (fmaxf(NaN, 0) = 0 would swallow the poison a failed kernel leaves)
+__device__ __forceinline__ float relu_f(float x) { return x < 0.f ? 0.f : x; }
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- diagnostic build only (-DSS_STAMP): per-stage cycle shares of the persistent kernels.

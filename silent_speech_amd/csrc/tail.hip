@@ -167,7 +167,7 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
     for (int u = 0; u < 4; ++u) acc[u] = wave_sum(acc[u]);
     if (lane < 4 && o0 + lane < MID) {
       const int o = o0 + lane;
-      const float a = fmaxf((lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]) + p.b1[o], 0.f);
+      const float a = relu_f((lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]) + p.b1[o]);
       const float ad = a * drop_scale((long)b * MID + o, p.drop_p, p.seed, p.offset);
       midv[o] = ad;
       if (p.mid) p.mid[(long)b * MID + o] = a;

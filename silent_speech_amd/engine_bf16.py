@@ -16,6 +16,7 @@ f32 master weights, f32 gradients, f32 Adam: only MFMA operands are bf16.  The r
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -24,19 +25,20 @@ from . import _lib as L
 
 INT_MAX = 2**31 - 1
 USE_SIDE_STREAM = True  # bench.py turns it off for its per-kernel timing pass (HIP-event pairs need one stream)
+USE_PERSISTENT_GRU = os.environ.get("SS_C5_STEP_GRU", "0") != "1"  # 0: one launch per time step (the round-2 form, kept as the fallback)
 CNN_CHANNELS = (16, 32, 64, 96)
 ROI_HW = (96, 96)
 _IDENT = (INT_MAX, 0, 0)
 
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=False, atomic=False, splits=1, a_map=_IDENT,
-         b_map=_IDENT, batch=1, strides=(0, 0, 0, 0), tag="gemm_bf16"):
-    flags = (1 if accumulate else 0) | (4 if atomic else 0)
+         b_map=_IDENT, batch=1, strides=(0, 0, 0, 0), tag="gemm_bf16", src16=True):
+    """``src16``: A and B are bf16 in HBM (the copies the recurrence kernels / ss_gru_bf16_prep / ss_cvt_bf16_rows leave);
+    leading dimensions and strides then count bf16 elements."""
+    flags = (1 if accumulate else 0) | (4 if atomic else 0) | (8 if src16 else 0)
     L.call("ss_gemm_bf16_batched", int(a_kc), int(b_kc), M, N, K, A, lda, *a_map, B, ldb, *b_map, Cm, ldc, bias, flags, splits,
            batch, *strides, L.stream(), tag=tag)
 
-
-import os
 
 # K slices of the weight-gradient GEMMs aim at this many workgroups (measured 192 / 384 / 768 / 1536: 6.10 / 6.09 / 6.17 / 6.33 ms
 # per step: the GEMMs run beside the BPTT steps on the side stream, fewer float atomics matter more than their own time)
@@ -46,7 +48,7 @@ _SPLITK_TARGET = int(os.environ.get("SS_C5_SPLITK_TARGET", "384"))
 def split_k(M, N, K, batch, target_wgs=None):
     target_wgs = target_wgs or _SPLITK_TARGET
     tiles = -(-M // 128) * -(-N // 128) * batch
-    return max(1, min(-(-K // 32), target_wgs // tiles))
+    return max(1, min(-(-K // 64), target_wgs // tiles))
 
 
 def _pstride(P, a: str, b: str) -> int:
@@ -57,14 +59,19 @@ def _addr(t: torch.Tensor, offset_elems: int = 0) -> int:
     return t.data_ptr() + offset_elems * t.element_size()
 
 
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
 def check_config(cfg, roi_hw) -> None:
     if cfg.hidden % 128 != 0:
         raise RuntimeError("precision='bf16' needs hidden % 128 == 0 (ss_gru_bf16_*); use the f32 path for small hidden sizes")
     if cfg.use_roi and (tuple(cfg.cnn_channels) != CNN_CHANNELS or tuple(roi_hw) != ROI_HW):
         raise RuntimeError(f"the bf16 ROI CNN is built for channels {CNN_CHANNELS} on {ROI_HW[0]}x{ROI_HW[1]} frames "
                            f"(got {tuple(cfg.cnn_channels)} on {tuple(roi_hw)})")
-    if cfg.in_dim % 4 != 0:
-        raise RuntimeError("precision='bf16' needs (x_dim + roi_emb) % 4 == 0 (16-byte operand loads of the GEMM)")
+    if cfg.in_dim % 4 != 0 or (cfg.use_roi and cfg.x_dim % 4 != 0):
+        raise RuntimeError("precision='bf16' needs x_dim % 4 == 0 and (x_dim + roi_emb) % 4 == 0 (vector loads of the operand "
+                           "conversion)")
 
 
 class WorkspaceBf16:
@@ -91,13 +98,24 @@ class WorkspaceBf16:
         self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
         self.gi = [torch.empty(2, N, 3 * H, **f32) for _ in range(cfg.gru_layers)]
         self.out = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers)]
-        self.out_drop = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers - 1)]
+        # bf16 copies that feed MFMAs: the layer inputs (Z; the -- dropped-out -- output of the layer below, left by its recurrence
+        # kernel), the layer outputs (h_prev operand of d W_hh), W_hh / W_hh^T / W_ih (once per step: ss_gru_bf16_prep)
+        self.kin = [cfg.in_dim if l == 0 else 2 * H for l in range(cfg.gru_layers)]
+        self.kp = [_pad8(k) for k in self.kin]
+        self.lin_bf0 = torch.zeros(N, self.kp[0], **i16)
+        self.out_bf = [torch.empty(N, 2 * H, **i16) for _ in range(cfg.gru_layers)]
+        self.out_drop_bf = [torch.empty(N, 2 * H, **i16) for _ in range(cfg.gru_layers - 1)] if train else []
         self.whh = [torch.empty(2, 3 * H, H, **i16) for _ in range(cfg.gru_layers)]
         self.whht = [torch.empty(2, H, 3 * H, **i16) for _ in range(cfg.gru_layers)]
+        self.wih = [torch.empty(2, 3 * H, self.kp[l], **i16) for l in range(cfg.gru_layers)]
         nb = C.c_long(0)
         if L.load().ss_gru_bf16_ws_bytes(B, H, C.byref(nb)) != 0:
             raise RuntimeError("ss_gru_bf16_ws_bytes failed")
         self.gru_ws = torch.empty(nb.value, **u8)
+        # the persistent recurrence's exchange area (tagged granules + launch generation): zeroed ONCE, the kernels keep it consistent
+        if L.load().ss_gru_bf16_sync_bytes(B, T, H, C.byref(nb)) != 0:
+            raise RuntimeError("ss_gru_bf16_sync_bytes failed")
+        self.gru_sync = torch.zeros(nb.value // 4, device=device, dtype=torch.int32) if (nb.value and USE_PERSISTENT_GRU) else None
         self.logits = torch.empty(B, cfg.num_classes, **f32)
         self.attn = torch.empty(B, T, **f32)
         self.mid_drop = torch.empty(B, cfg.head_mid, **f32)
@@ -113,6 +131,7 @@ class WorkspaceBf16:
         if train:
             self.save = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
             self.dG = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
+            self.dG_bf = [torch.empty(2, N, 4, H, **i16) for _ in range(cfg.gru_layers)]
             self.d_out = torch.empty(N, 2 * H, **f32)
             self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
             self.xhat = torch.empty(B, 2 * H, **f32)
@@ -156,22 +175,26 @@ def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
         layer_in, ld_in = ws.Z.data_ptr(), cfg.in_dim
     else:
         layer_in, ld_in = X.data_ptr(), cfg.x_dim
+    X_src, ld_src = (ws.Z.data_ptr(), cfg.in_dim) if cfg.use_roi else (X.data_ptr(), cfg.x_dim)
+    L.call("ss_cvt_bf16_rows", X_src, ld_src, ws.lin_bf0.data_ptr(), ws.kp[0], N, ws.kin[0], 0.0, 0, 0, s)
+    lin = ws.lin_bf0
     for l in range(cfg.gru_layers):
-        K = cfg.in_dim if l == 0 else 2 * H
+        K, Kp = ws.kin[l], ws.kp[l]
         wf, wr = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
         L.call("ss_gru_bf16_prep", P[f"gru.weight_hh_l{l}"].data_ptr(), P[f"gru.weight_hh_l{l}_reverse"].data_ptr(), H,
-               ws.whh[l].data_ptr(), ws.whht[l].data_ptr(), s)
-        gemm(1, 1, N, 3 * H, K, layer_in, ld_in, P[wf].data_ptr(), K, ws.gi[l].data_ptr(), 3 * H, bias=P[f"gru.bias_ih_l{l}"].data_ptr(),
-             batch=2, strides=(0, _pstride(P, wf, wr), N * 3 * H, _pstride(P, f"gru.bias_ih_l{l}", f"gru.bias_ih_l{l}_reverse")),
-             tag="gemm_bf16_ih")
+               ws.whh[l].data_ptr(), ws.whht[l].data_ptr(), P[wf].data_ptr(), P[wr].data_ptr(), K, ws.wih[l].data_ptr(), s)
+        gemm(1, 1, N, 3 * H, K, lin.data_ptr(), Kp, ws.wih[l].data_ptr(), Kp, ws.gi[l].data_ptr(), 3 * H,
+             bias=P[f"gru.bias_ih_l{l}"].data_ptr(), batch=2,
+             strides=(0, 3 * H * Kp, N * 3 * H, _pstride(P, f"gru.bias_ih_l{l}", f"gru.bias_ih_l{l}_reverse")), tag="gemm_bf16_ih")
+        # nn.GRU's inter-layer dropout is a by-product of the recurrence kernel: it leaves bf16(dropout(out)) as the next layer's operand
+        drop = train and l < cfg.gru_layers - 1 and cfg.gru_dropout > 0.0 and ws.train
         L.call("ss_gru_bf16_fwd", ws.gi[l].data_ptr(), ws.whh[l].data_ptr(), P[f"gru.bias_hh_l{l}"].data_ptr(),
                P[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.lengths.data_ptr(), B, T, H, ws.out[l].data_ptr(),
-               ws.save[l].data_ptr() if stash else None, ws.gru_ws.data_ptr(), s)
-        layer_in, ld_in = ws.out[l].data_ptr(), 2 * H
-        if train and l < cfg.gru_layers - 1 and cfg.gru_dropout > 0.0:
-            L.call("ss_dropout", ws.out[l].data_ptr(), ws.out_drop[l].data_ptr(), N * 2 * H, cfg.gru_dropout, seed, (l + 1) << 40,
-                   None, s)
-            layer_in = ws.out_drop[l].data_ptr()
+               ws.save[l].data_ptr() if stash else None, ws.out_bf[l].data_ptr(), ws.out_drop_bf[l].data_ptr() if drop else None,
+               cfg.gru_dropout if drop else 0.0, seed, (l + 1) << 40, ws.gru_ws.data_ptr(), L.ptr(ws.gru_sync), s)
+        lin = ws.out_drop_bf[l] if drop else ws.out_bf[l]
+        ws.lin_bf = getattr(ws, "lin_bf", {})
+        ws.lin_bf[l + 1] = lin
     top = ws.out[cfg.gru_layers - 1]
     p_drop = cfg.head_dropout if train else 0.0
     y_ptr, ls, denom, loss_ptr, correct_ptr = ce if ce is not None else (None, 0.0, 1.0, None, None)
@@ -213,21 +236,20 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         top_layer = l == cfg.gru_layers - 1
         g_in = ws.d_out if top_layer else ws.d_lower[l + 1]
         L.call("ss_gru_bf16_bwd", g_in.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(), ws.whht[l].data_ptr(),
-               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), 0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed,
-               (l + 1) << 40, ws.gru_ws.data_ptr(), s)
-        if l == 0:
-            lin, ld_in = (ws.Z.data_ptr(), cfg.in_dim) if cfg.use_roi else (X.data_ptr(), cfg.x_dim)
-        else:
-            lin, ld_in = (ws.out_drop[l - 1] if use_drop else ws.out[l - 1]).data_ptr(), 2 * H
-        dg = ws.dG[l].data_ptr()
+               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), ws.dG_bf[l].data_ptr(),
+               0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed,
+               (l + 1) << 40, G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
+               G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.gru_ws.data_ptr(),
+               L.ptr(ws.gru_sync), s)
+        Kp = ws.kp[l]
+        lin = (ws.lin_bf0 if l == 0 else ws.lin_bf[l]).data_ptr()  # what the forward pass multiplied W_ih with (dropped out or not)
+        dg = ws.dG_bf[l].data_ptr()
         wi, wir = f"gru.weight_ih_l{l}", f"gru.weight_ih_l{l}_reverse"
 
-        def param_grads(l=l, K=K, lin=lin, ld_in=ld_in, dg=dg, wi=wi, wir=wir):
-            # ---- bias gradients: column sums of d_g (r | z | n | hn), both directions in one launch
-            L.call("ss_gru_bias_grad", dg, N, H, G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
-                   G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.stream())
+        def param_grads(l=l, K=K, Kp=Kp, lin=lin, dg=dg, wi=wi, wir=wir):
+            # (the bias gradients are by-products of the BPTT kernel)
             # ---- weight gradients: d W_ih = dGi^T . layer_in;  d W_hh = dGh^T . h_prev (rows r|z from columns [0,2H), rows n from [3H,4H))
-            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, ld_in, G[wi].data_ptr(), K, accumulate=True, atomic=True,
+            gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, Kp, G[wi].data_ptr(), K, accumulate=True, atomic=True,
                  splits=split_k(3 * H, K, N, 2), batch=2, strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0), tag="gemm_bf16_dW")
             if T > 1:
                 wh, whr = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
@@ -236,10 +258,10 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
                 # forward direction pairs dG[b][t] with out[b][t-1]; the reverse direction dG[b][t] with out[b][t+1]: the same
                 # pairing seen from one row earlier in dG and one row later in out (two pointer shifts = the batch strides)
                 sa, sb, sc = N * 4 * H - 4 * H, H + 2 * H, _pstride(G, wh, whr)
-                hp = ws.out[l].data_ptr()
+                hp = ws.out_bf[l].data_ptr()
                 gemm(0, 0, 2 * H, H, Kh, dg, 4 * H, hp, 2 * H, G[wh].data_ptr(), H, accumulate=True, atomic=True,
                      splits=split_k(2 * H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
-                gemm(0, 0, H, H, Kh, dg + 3 * H * 4, 4 * H, hp, 2 * H, _addr(G[wh], 2 * H * H), H, accumulate=True, atomic=True,
+                gemm(0, 0, H, H, Kh, dg + 3 * H * 2, 4 * H, hp, 2 * H, _addr(G[wh], 2 * H * H), H, accumulate=True, atomic=True,
                      splits=split_k(H, H, Kh, 2), a_map=am, b_map=bm, batch=2, strides=(sa, sb, sc, 0), tag="gemm_bf16_dW")
 
         # ---- d layer_in = dGi_f . W_ih_f + dGi_r . W_ih_r (both directions in one launch, float atomics into a cleared buffer):
@@ -249,15 +271,14 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
             if l > 0:
                 dst, ld_dst, c0 = ws.d_lower[l].data_ptr(), 2 * H, 0
             elif cfg.use_roi:
-                c0 = cfg.x_dim if d_X is None else 0
-                if c0 % 4:
-                    c0 = 0  # 16-byte operand loads: take all columns
+                # nobody asked for d X: only the ROI-embedding columns of d Z feed the CNN backward (from the 8-column chunk they start in)
+                c0 = cfg.x_dim // 8 * 8 if d_X is None else 0
                 dst, ld_dst = ws.dZ.data_ptr() + 4 * c0, cfg.in_dim
             else:
                 zero_buffers([d_X])
                 dst, ld_dst, c0 = d_X.data_ptr(), cfg.x_dim, 0
-            gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(P[wi], c0), K, dst, ld_dst, accumulate=True, atomic=True, batch=2,
-                 strides=(N * 4 * H, _pstride(P, wi, wir), 0, 0), tag="gemm_bf16_dX")
+            gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(ws.wih[l], c0), Kp, dst, ld_dst, accumulate=True, atomic=True, batch=2,
+                 strides=(N * 4 * H, 3 * H * Kp, 0, 0), tag="gemm_bf16_dX")
         if USE_SIDE_STREAM:
             ws.ev_fork.record()
             with torch.cuda.stream(ws.side):

@@ -28,9 +28,20 @@ def bf(x):
 INT_MAX = 2**31 - 1
 
 
+def to_bf16_rows(L, x, drop_p=0.0, seed=0, offset=0):
+    """f32 (rows, cols) device tensor -> int16 (rows, ceil8(cols)) of bf16 bit patterns, zero-padded (ss_cvt_bf16_rows)."""
+    rows, cols = x.shape
+    ld = (cols + 7) // 8 * 8
+    y = torch.full((rows, ld), 0x7fc0, device="cuda", dtype=torch.int16)
+    L.call("ss_cvt_bf16_rows", x.data_ptr(), cols, y.data_ptr(), ld, rows, cols, drop_p, seed, offset, L.stream())
+    return y
+
+
+@pytest.mark.parametrize("src16", [0, 1])
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("M,N,K", [(200, 148, 148), (128, 128, 32), (260, 64, 1000), (16, 1536, 512)])
-def test_gemm_bf16_layouts(L, akc, bkc, M, N, K):
+def test_gemm_bf16_layouts(L, akc, bkc, M, N, K, src16):
+    """``src16``: the operands already are bf16 in HBM (flags bit 3), leading dimensions zero-padded to a multiple of 8."""
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + akc * 2 + bkc)
     A = torch.randn(M, K, generator=g)
     B = torch.randn(K, N, generator=g)
@@ -38,16 +49,21 @@ def test_gemm_bf16_layouts(L, akc, bkc, M, N, K):
     ref = (bf(A).double() @ bf(B).double()).float() + bias
     A_st = (A if akc else A.t()).contiguous().cuda()     # [M][K] or [K][M]
     B_st = (B.t() if bkc else B).contiguous().cuda()     # [N][K] or [K][N]
+    if src16:
+        A_st, B_st = to_bf16_rows(L, A_st), to_bf16_rows(L, B_st)
+        assert torch.equal(A_st.cpu().view(torch.bfloat16).float()[:, : (K if akc else M)], bf(A if akc else A.t()))
+        assert int(A_st[:, (K if akc else M):].abs().sum()) == 0
     C = torch.full((M, N), 7.0, device="cuda")
     bias_d = bias.cuda()
     L.call("ss_gemm_bf16_batched", akc, bkc, M, N, K, A_st.data_ptr(), A_st.shape[1], INT_MAX, 0, 0, B_st.data_ptr(),
-           B_st.shape[1], INT_MAX, 0, 0, C.data_ptr(), N, bias_d.data_ptr(), 0, 1, 1, 0, 0, 0, 0, L.stream())
+           B_st.shape[1], INT_MAX, 0, 0, C.data_ptr(), N, bias_d.data_ptr(), 8 * src16, 1, 1, 0, 0, 0, 0, L.stream())
     torch.cuda.synchronize()
     err = float((C.cpu() - ref).abs().max())
     assert err < 2e-4 * max(1.0, float(ref.abs().max())), err
 
 
-def test_gemm_bf16_batch_splitk_remap(L):
+@pytest.mark.parametrize("src16", [0, 1])
+def test_gemm_bf16_batch_splitk_remap(L, src16):
     """Two problems per launch (both GRU directions), K sliced over workgroups with float atomics into an initialised C,
     and the storage-row remap that pairs dG[b][t] with h[b][t-1] (group T-1 of stride T)."""
     g = torch.Generator().manual_seed(1)
@@ -64,8 +80,10 @@ def test_gemm_bf16_batch_splitk_remap(L):
         ref[d] += (bf(a).double().t() @ bf(h).double()).float()
     C = C0.clone().cuda()
     dGd, Hd = dG.cuda(), Hs.cuda()
+    if src16:
+        dGd, Hd = to_bf16_rows(L, dGd.view(2 * rows, Mm)), to_bf16_rows(L, Hd.view(2 * rows, Nn))
     L.call("ss_gemm_bf16_batched", 0, 0, Mm, Nn, K, dGd.data_ptr(), Mm, T - 1, T, 1, Hd.data_ptr(), Nn, T - 1, T, 0,
-           C.data_ptr(), Nn, None, 1, 3, 2, rows * Mm, rows * Nn, Mm * Nn, 0, L.stream())
+           C.data_ptr(), Nn, None, 1 + 8 * src16, 3, 2, rows * Mm, rows * Nn, Mm * Nn, 0, L.stream())
     torch.cuda.synchronize()
     assert float((C.cpu() - ref).abs().max()) < 3e-4 * float(ref.abs().max())
 
@@ -91,9 +109,15 @@ def _gru_emulated(gi, whh, bhh, lengths, T, H, reverse):
     return torch.stack(outs, 1), torch.stack(saves, 1)
 
 
-@pytest.mark.parametrize("B,T,H,drop_p", [(5, 7, 128, 0.0), (70, 4, 256, 0.0), (33, 6, 512, 0.0), (33, 6, 512, 0.1), (5, 7, 128, 0.3)])
-def test_gru_bf16_fwd_bwd(L, B, T, H, drop_p):
-    """``drop_p`` > 0: the BPTT kernel re-draws nn.GRU's inter-layer dropout mask while it reads d_out (Philox stream of
+@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("B,T,H,drop_p", [(5, 7, 128, 0.0), (70, 4, 256, 0.0), (33, 6, 512, 0.0), (33, 6, 512, 0.1), (5, 7, 128, 0.3),
+                                          (256, 5, 512, 0.1), (300, 3, 512, 0.0), (20, 9, 384, 0.0)])
+def test_gru_bf16_fwd_bwd(L, B, T, H, drop_p, persistent):
+    """Both forms behind the entry points: ``persistent`` = one launch per layer (H/64 workgroups per (16-clip slice, direction)
+    exchanging the state through tagged granules; B = 256 fills the chip and takes the same-XCD path, B = 300 runs as two
+    clip chunks, the small batches take the write-through path), otherwise one launch per time step.  Checked together with
+    the by-products: the bf16 copies of out / dropout(out) / d_g and the bias-gradient column sums.
+    ``drop_p`` > 0: the BPTT kernel re-draws nn.GRU's inter-layer dropout mask while it reads d_out (Philox stream of
     ss_dropout at the same seed / offset / element index): checked against the mask ss_dropout itself writes."""
     g = torch.Generator().manual_seed(B + T + H)
     N = B * T
@@ -124,23 +148,44 @@ def test_gru_bf16_fwd_bwd(L, B, T, H, drop_p):
     wb = torch.empty(2, 3 * H, H, device="cuda", dtype=torch.int16)
     wtb = torch.empty(2, H, 3 * H, device="cuda", dtype=torch.int16)
     w_f, w_r = dev(whh[0]), dev(whh[1])
-    L.call("ss_gru_bf16_prep", w_f.data_ptr(), w_r.data_ptr(), H, wb.data_ptr(), wtb.data_ptr(), L.stream())
+    Kin = 148 if H == 512 else 2 * H  # W_ih rides along: (3H, K) -> (3H, K rounded up to 8) bf16, zero-padded
+    Kp = (Kin + 7) // 8 * 8
+    wih = [torch.randn(3 * H, Kin, generator=g) for _ in range(2)]
+    wi_f, wi_r = dev(wih[0]), dev(wih[1])
+    wib = torch.full((2, 3 * H, Kp), 0x7fc0, device="cuda", dtype=torch.int16)
+    L.call("ss_gru_bf16_prep", w_f.data_ptr(), w_r.data_ptr(), H, wb.data_ptr(), wtb.data_ptr(), wi_f.data_ptr(), wi_r.data_ptr(), Kin,
+           wib.data_ptr(), L.stream())
     torch.cuda.synchronize()
     assert torch.equal(wb.cpu().view(torch.bfloat16).float(), bf(torch.stack(whh)))
     assert torch.equal(wtb.cpu().view(torch.bfloat16).float(), bf(torch.stack(whh)).transpose(1, 2))
+    wic = wib.cpu().view(torch.bfloat16).float()
+    assert torch.equal(wic[:, :, :Kin], bf(torch.stack(wih))) and float(wic[:, :, Kin:].abs().sum()) == 0
     import ctypes
 
     nb = ctypes.c_long(0)
     assert L.load().ss_gru_bf16_ws_bytes(B, H, ctypes.byref(nb)) == 0
     ws = torch.empty(nb.value, device="cuda", dtype=torch.uint8)
+    sync = None
+    if persistent:
+        assert L.load().ss_gru_bf16_sync_bytes(B, T, H, ctypes.byref(nb)) == 0 and nb.value > 0
+        sync = torch.zeros(nb.value // 4, device="cuda", dtype=torch.int32)
     gid = dev(gi.reshape(2, N, 3 * H))
     b_f, b_r = dev(bhh[0]), dev(bhh[1])
     lens = lengths.to(torch.int32).cuda()
     out = torch.full((N, 2 * H), 9.0, device="cuda")
     save = torch.full((2, N, 4, H), 9.0, device="cuda")
+    out_bf = torch.full((N, 2 * H), 0x7fc0, device="cuda", dtype=torch.int16)
+    out_drop_bf = torch.full((N, 2 * H), 0x7fc0, device="cuda", dtype=torch.int16)
     L.call("ss_gru_bf16_fwd", gid.data_ptr(), wb.data_ptr(), b_f.data_ptr(), b_r.data_ptr(), lens.data_ptr(), B, T, H,
-           out.data_ptr(), save.data_ptr(), ws.data_ptr(), L.stream())
+           out.data_ptr(), save.data_ptr(), out_bf.data_ptr(), out_drop_bf.data_ptr(), drop_p, seed, offset, ws.data_ptr(),
+           L.ptr(sync), L.stream())
     torch.cuda.synchronize()
+    if sync is not None:
+        assert int(sync[2]) == 0, "a bounded wait of the persistent recurrence gave up"
+        if B == 256:
+            assert int(sync[3]) == 256, f"same-XCD fast path taken by {int(sync[3])} of 256 workgroups"
+    assert torch.equal(out_bf.cpu().view(torch.bfloat16).float(), bf(out.cpu()))
+    assert torch.equal(out_drop_bf.cpu().view(torch.bfloat16).float(), bf(out.cpu() * keep.reshape(N, 2 * H)))
     err = float((out.cpu().view(B, T, 2 * H) - out_ref.detach()).abs().max())
     assert err < 2e-3, err  # bf16 rounding of the state decides differently only through v_exp/v_rcp noise: amplified by 1 bf16 ulp
     mask = (torch.arange(T)[None] < lengths[:, None]).float()[None, :, :, None, None]
@@ -149,9 +194,20 @@ def test_gru_bf16_fwd_bwd(L, B, T, H, drop_p):
 
     dG = torch.full((2, N, 4, H), 9.0, device="cuda")
     d_out_d = dev(d_out.reshape(N, 2 * H))
+    dG_bf = torch.full((2, N, 4, H), 0x7fc0, device="cuda", dtype=torch.int16)
+    gb = [torch.zeros(3 * H, device="cuda") for _ in range(4)]  # d b_ih fwd, d b_hh fwd, d b_ih rev, d b_hh rev
     L.call("ss_gru_bf16_bwd", d_out_d.data_ptr(), out.data_ptr(), save.data_ptr(), wtb.data_ptr(),
-           lens.data_ptr(), B, T, H, dG.data_ptr(), drop_p, seed, offset, ws.data_ptr(), L.stream())
+           lens.data_ptr(), B, T, H, dG.data_ptr(), dG_bf.data_ptr(), drop_p, seed, offset, *[t_.data_ptr() for t_ in gb],
+           ws.data_ptr(), L.ptr(sync), L.stream())
     torch.cuda.synchronize()
+    if sync is not None:
+        assert int(sync[2]) == 0
+    assert torch.equal(dG_bf.cpu().view(torch.bfloat16).float(), bf(dG.cpu()))
+    dGs = dG.cpu().view(2, N, 4, H).sum(1)  # (2, 4, H) column sums
+    for d in range(2):
+        want_ih, want_hh = dGs[d, :3].reshape(-1), torch.cat([dGs[d, 0], dGs[d, 1], dGs[d, 3]])
+        for got, want in ((gb[2 * d], want_ih), (gb[2 * d + 1], want_hh)):
+            assert float((got.cpu() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
     dGc = dG.cpu().view(2, B, T, 4, H)
     for d in range(2):
         ref = gi_l[d].grad.view(B, T, 3, H)   # d gi = (d r_pre, d z_pre, d n_pre)
