@@ -264,7 +264,8 @@ int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, cons
  *   [5] fault injection for tests (1 + index of a workgroup that plays dead; 0 = off).
  * By-products (each may be NULL): out_bf16 (N,2H) = bf16 copy of out; out_drop_bf16 (N,2H) = bf16 of dropout(out) with
  *   ss_dropout's Philox stream at (seed, offset) over the (N,2H) index space -- nn.GRU's inter-layer dropout, ready as
- *   the next layer's MFMA operand (drop_p = 0: a plain copy); d_g_bf16 (2,N,4,H) = bf16 copy of d_g; g_b* (all four or
+ *   the next layer's MFMA operand (drop_p = 0: a plain copy); d_g_bf16 (2,N,4,H) = bf16 copy of d_g (with it, the
+ *   persistent form also accepts d_g = NULL: 126 MB per launch less to write at config 5); g_b* (all four or
  *   none): d b_ih += column sums of (d r, d z, d n), d b_hh += column sums of (d r, d z, d hn) (what ss_gru_bias_grad
  *   computes from d_g).  ss_gru_bf16_bwd: drop_p / seed / offset = the same mask re-drawn on d_out (see ss_gru_bwd).
  * ss_cvt_bf16_rows: y[r][c] = bf16(x[r][c] * mask), c < cols; y[r][cols .. ld_y) = 0 (GEMM operands are read in whole

@@ -519,58 +519,94 @@ __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
   for (int k = 0; k < 8; ++k) gb[k] = 0.f;
   __syncthreads();
 
+  // Everything a band needs from HBM is requested one band ahead into registers: the frame bytes of the NEXT frame during this
+  // frame's last band, the gradient rows (and stored pool winners) of the NEXT band before this band's MFMAs.  (First version:
+  // loads at the point of use -- a memory latency per band and per frame with nothing else to do, 44 k cycles per frame for
+  // 3.5 k cycles of MFMA.)
+  constexpr int NB = C1_BR * HP * 2 / NT;  // staging items (8 channels of a pooled pixel) per thread and band
+  static_assert(NB * NT == C1_BR * HP * 2, "band items");
+  uint4 px[2];
+  auto load_px = [&](int n) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
+    px[0] = src[tid];
+    px[1] = (tid + NT < HW0 * HW0 / 16) ? src[tid + NT] : uint4{0u, 0u, 0u, 0u};
+  };
+  uint4 dpre[NB];
+  uint2 ipre[NB];
+  auto issue_band = [&](int n, int r0) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int q = tid + k * NT, half = q & 1, pp = q >> 1;
+      const long so = ((long)n * HP * HP + (long)r0 * HP + pp) * C1 + 8 * half;
+      dpre[k] = *reinterpret_cast<const uint4*>(p.da1 + so);
+      ipre[k] = rc ? uint2{0u, 0u} : *reinterpret_cast<const uint2*>(p.i1 + so);
+    }
+  };
+  if ((int)blockIdx.x < p.N) {
+    load_px(blockIdx.x);
+    issue_band(blockIdx.x, 0);
+  }
+
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     if (tid < 256) {
       const float rr = (float)tid / 255.0f;
       s_xn[tid] = p.standardize ? (rr - p.st[2 * (long)n]) / p.st[2 * (long)n + 1] : rr;
     }
     __syncthreads();
-    const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
-    for (int q = tid; q < HW0 * HW0 / 16; q += NT) {
-      const uint4 v = src[q];
-      const int lin = q * 16, r = lin / HW0 + 1, c0 = lin % HW0 + 1;
-      const unsigned wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + k * NT;
+      if (q < HW0 * HW0 / 16) {
+        const int lin = q * 16, r = lin / HW0 + 1, c0 = lin % HW0 + 1;
+        const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const bf16_t xv = to_bf16(s_xn[(wds[e] >> (8 * b)) & 255u]);  // bf16 as in the forward kernel's image
-          const int c = c0 + 4 * e + b;
-          imgE[r * C1_XS + c] = xv;
-          if (c >= 2) imgO[r * C1_XS + c - 2] = xv;
-        }
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const bf16_t xv = to_bf16(s_xn[(wds[e] >> (8 * b)) & 255u]);  // bf16 as in the forward kernel's image
+            const int c = c0 + 4 * e + b;
+            imgE[r * C1_XS + c] = xv;
+            if (c >= 2) imgO[r * C1_XS + c - 2] = xv;
+          }
+      }
     }
-    const bf16_t* da = p.da1 + (long)n * HP * HP * C1;
-    const uint8_t* ix = rc ? nullptr : p.i1 + (long)n * HP * HP * C1;
     for (int r0 = 0; r0 < HP; r0 += C1_BR) {
+      const bool last_band = r0 + C1_BR >= HP;
       if (rc) {  // conv1 again for the band's row pairs: only the pool winners are kept
         __syncthreads();  // the image is complete (first band) / the previous band's bytes have been consumed
         conv1_rows(imgE, [&](int q) { return bq[q]; }, bias1, r0, r0 + C1_BR, r0, nullptr, 0, 0, 0, ibl, wv, g, li);
         __syncthreads();
       }
       // ---- the band's gradients, split by window slot
-      for (int q = tid; q < C1_BR * HP * 2; q += NT) {
-        const int half = q & 1, pp = q >> 1;
-        const long so = ((long)r0 * HP + pp) * C1 + 8 * half;
-        const uint4 dv = *reinterpret_cast<const uint4*>(da + so);
-        const uint2 iv = rc ? *reinterpret_cast<const uint2*>(ibl + pp * C1 + 8 * half) : *reinterpret_cast<const uint2*>(ix + so);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int q = tid + k * NT, half = q & 1, pp = q >> 1;
+        const uint4 dv = dpre[k];
+        const uint2 iv = rc ? *reinterpret_cast<const uint2*>(ibl + pp * C1 + 8 * half) : ipre[k];
         const unsigned d[4] = {dv.x, dv.y, dv.z, dv.w};
         unsigned o[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned ib = (k < 2 ? iv.x : iv.y) >> (16 * (k & 1));
+        for (int kk = 0; kk < 4; ++kk) {
+          const unsigned ib = (kk < 2 ? iv.x : iv.y) >> (16 * (kk & 1));
           const unsigned ia = ib & 255u, ic = (ib >> 8) & 255u;
-          const unsigned lo = d[k] & 0xffffu, hi = d[k] & 0xffff0000u;
-          if (ia < 4u) gb[2 * k] += __uint_as_float(lo << 16);
-          if (ic < 4u) gb[2 * k + 1] += __uint_as_float(hi);
+          const unsigned lo = d[kk] & 0xffffu, hi = d[kk] & 0xffff0000u;
+          if (ia < 4u) gb[2 * kk] += __uint_as_float(lo << 16);
+          if (ic < 4u) gb[2 * kk + 1] += __uint_as_float(hi);
 #pragma unroll
-          for (unsigned e = 0; e < 4; ++e) o[e][k] = (ia == e ? lo : 0u) | (ic == e ? hi : 0u);
+          for (unsigned e = 0; e < 4; ++e) o[e][kk] = (ia == e ? lo : 0u) | (ic == e ? hi : 0u);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           *reinterpret_cast<uint4*>(ae + e * C1_AE + pp * C1 + 8 * half) = uint4{o[e][0], o[e][1], o[e][2], o[e][3]};
       }
       __syncthreads();
+      {  // the next band's (frame's) operands fly under the MFMAs below
+        const int nn = last_band ? n + (int)gridDim.x : n;
+        if (nn < p.N) {
+          issue_band(nn, last_band ? 0 : r0 + C1_BR);
+          if (last_band) load_px(nn);
+        }
+      }
       for (int ch = wv; ch < C1_BR * HP / 32; ch += NW) {
         const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;  // this lane's two pooled pixels of the k step
         const int y0 = r0 + P0 / HP, x0 = P0 % HP, y1 = r0 + P1 / HP, x1 = P1 % HP;

@@ -16,6 +16,8 @@
 
 namespace {
 
+STAMP_TABLE(ss_debug_stamps_gemm_bf16)
+
 constexpr int BM = 128, BN = 128;
 
 struct GemmBfParams {
@@ -33,9 +35,12 @@ __device__ __forceinline__ long remap_row(int r, int group, int gstride, int off
 }
 
 // LDS images of one operand tile (128 rows x BK k): k-contiguous operands as [row][BK + 8] (row stride = BK/2 + 4 dwords: the 16
-// rows of a fragment read cover all 64 banks), k-major operands as [k][128 + 8].
+// rows of a fragment read cover all 64 banks), k-major operands as [k][128 + 24]: a transposing read takes 8-byte pieces of 4 k lines
+// per 16-lane group and two groups (8 k lines apart) per pass -- with a line stride of 76 dwords (== 12 mod 64) the four lines
+// of a group sit 12 banks apart and the second group 32 banks further: no conflicts (128 + 8 gave 2-way ones, a third of the
+// kernel's active LDS cycles).
 template <int BK> struct Tile {
-  static constexpr int LDK = BK + 8, LDR = 128 + 8;
+  static constexpr int LDK = BK + 8, LDR = 128 + 24;
   static constexpr int ELEMS = (BM * LDK > BK * LDR) ? BM * LDK : BK * LDR;
 };
 
@@ -75,23 +80,58 @@ __device__ __forceinline__ void store_tile_f32(bf16_t* tile, int tid, const f32x
 // KC = 1: thread -> (row = idx / 8, k = 8 (idx % 8));  KC = 0: thread -> (k = idx / 16, row = 8 (idx % 16)).
 // A chunk that starts inside the operand may run past its last row / k into the padding of the leading dimension (the caller
 // pads ld to a multiple of 8 with zeros: ss_cvt_bf16_rows), so only the chunk's first element is tested.
+// The storage-row remap (r / group) * gstride + r % group + off is an integer division per chunk: done ONCE, in front of the
+// k loop; a k-major operand then walks its rows tile by tile with an add and one conditional carry (the first version divided
+// per chunk and tile: 10 vector instructions per MFMA, the kernel was VALU-bound at 9 % MFMA occupancy).
+// Loads are BUFFER loads with the range check doing the predication: a chunk outside the operand gets an offset beyond
+// num_records and comes back as zeros.  (Loads inside `if (in range)` branches made hipcc wait vmcnt(0) before the LDS stores --
+// it cannot count loads through divergent branches -- which also waited for the tiles just requested: no prefetch at all.)
+typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFF00u;
 template <int KC>
-__device__ __forceinline__ void load_tile_b16(const bf16_t* __restrict__ src, int ld, int group, int gstride, int off, int row0, int rows,
-                                              int k0, int k_end, int tid, s16x8 v[4]) {
+struct TileLoader16 {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned boff[4];       // KC = 1: byte offset of the chunk's row at k = 0;  KC = 0: of its column in row 0  (OOB: outside)
+  int quo[4], rem[4];     // KC = 0: storage row of the chunk's current k = quo * gstride + rem + off
+  int ld, group, gstride, off, dq, dm, k_end;
+  __device__ __forceinline__ void init(const bf16_t* __restrict__ src, int ld_, int group_, int gstride_, int off_, int row0, int rows,
+                                       int k0, int k_end_, int tid) {
+    ld = ld_; group = group_; gstride = gstride_; off = off_; k_end = k_end_;
+    dq = 64 / group; dm = 64 % group;
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(src), 0, (int)0xFFFFFE00u, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 256 * i;
-    s16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (KC) {
-      const int r = row0 + (idx >> 3), k = k0 + 8 * (idx & 7);
-      if (r < rows && k < k_end) x = *reinterpret_cast<const s16x8*>(src + remap_row(r, group, gstride, off) * ld + k);
-    } else {
-      const int k = k0 + (idx >> 4), r = row0 + 8 * (idx & 15);
-      if (k < k_end && r < rows) x = *reinterpret_cast<const s16x8*>(src + remap_row(k, group, gstride, off) * ld + r);
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      if (KC) {
+        const int r = row0 + (idx >> 3);
+        boff[i] = r < rows ? (unsigned)((remap_row(r, group, gstride, off) * ld + 8 * (idx & 7)) * 2) : OOB;
+        quo[i] = rem[i] = 0;
+      } else {
+        const int c = row0 + 8 * (idx & 15), k = k0 + (idx >> 4);
+        boff[i] = c < rows ? (unsigned)(2 * c) : OOB;
+        quo[i] = k / group; rem[i] = k % group;
+      }
     }
-    v[i] = x;
   }
-}
+  // the tile at k0 (tiles are requested in ascending order, one BK apart)
+  __device__ __forceinline__ void load(int k0, int tid, s16x8 v[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      unsigned o;
+      if (KC) {
+        const int k = k0 + 8 * (idx & 7);
+        o = (boff[i] != OOB && k < k_end) ? boff[i] + 2u * (unsigned)k0 : OOB;
+      } else {
+        const int k = k0 + (idx >> 4);
+        o = (boff[i] != OOB && k < k_end) ? boff[i] + 2u * (unsigned)(((long)quo[i] * gstride + rem[i] + off) * ld) : OOB;
+        quo[i] += dq; rem[i] += dm;
+        if (rem[i] >= group) { rem[i] -= group; ++quo[i]; }
+      }
+      v[i] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, 0, 0));
+    }
+  }
+};
 
 template <int KC>
 __device__ __forceinline__ void store_tile_b16(bf16_t* tile, int tid, const s16x8 v[4]) {
@@ -127,20 +167,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBfParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // k tiles kt0 .. kt1-1.  Two register stages: the loads of tile t + 2 are issued before the MFMAs of tile t and written to LDS
+  // at the end of tile t + 1, so an operand has two tile times (and the other workgroup of the CU) to arrive -- with one stage a
+  // wave sat through a memory latency per tile (MFMA pipes 9 % busy).
+  STAMP_ENTRY;
+  STAMP_DECL;
   auto mainloop = [&](auto load_a, auto load_b, auto store_a, auto store_b, auto& va, auto& vb) {
-    load_a(kt0 * BK, va);
-    load_b(kt0 * BK, vb);
-    store_a(lds, va);
-    store_b(lds + T::ELEMS, vb);
+    load_a(kt0 * BK, va[0]);
+    load_b(kt0 * BK, vb[0]);
+    if (kt0 + 1 < kt1) {
+      load_a((kt0 + 1) * BK, va[1]);
+      load_b((kt0 + 1) * BK, vb[1]);
+    }
+    store_a(lds, va[0]);
+    store_b(lds + T::ELEMS, vb[0]);
     __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int cur = (kt - kt0) & 1;
+    STAMP(15);
+    auto tile = [&](int kt, int cur) {  // cur = (kt - kt0) & 1, a compile-time constant at both call sites
       const bf16_t* As = lds + (2 * cur) * T::ELEMS;
       const bf16_t* Bs = lds + (2 * cur + 1) * T::ELEMS;
-      const bool more = kt + 1 < kt1;
-      if (more) {
-        load_a((kt + 1) * BK, va);
-        load_b((kt + 1) * BK, vb);
+      if (kt + 2 < kt1) {  // stage `cur` was written to LDS at the end of the previous tile
+        load_a((kt + 2) * BK, va[cur]);
+        load_b((kt + 2) * BK, vb[cur]);
       }
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 32) {
@@ -155,27 +203,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBfParams p) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
       }
-      if (more) {
-        store_a(lds + (2 * (cur ^ 1)) * T::ELEMS, va);
-        store_b(lds + (2 * (cur ^ 1) + 1) * T::ELEMS, vb);
+      STAMP(1);
+      if (kt + 1 < kt1) {
+        store_a(lds + (2 * (cur ^ 1)) * T::ELEMS, va[cur ^ 1]);
+        store_b(lds + (2 * (cur ^ 1) + 1) * T::ELEMS, vb[cur ^ 1]);
       }
+      STAMP(2);
       __syncthreads();
+      STAMP(3);
+    };
+    int kt = kt0;
+    for (; kt + 1 < kt1; kt += 2) {
+      tile(kt, 0);
+      tile(kt + 1, 1);
     }
+    if (kt < kt1) tile(kt, 0);
   };
 
   if (kt0 < kt1) {
     if constexpr (SRC16) {
       const bf16_t* A = static_cast<const bf16_t*>(p.A) + batch * p.sa;
       const bf16_t* B = static_cast<const bf16_t*>(p.B) + batch * p.sb;
-      s16x8 va[4], vb[4];
-      mainloop([&](int k0, s16x8* v) { load_tile_b16<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, k0, p.K, tid, v); },
-               [&](int k0, s16x8* v) { load_tile_b16<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, k0, p.K, tid, v); },
+      s16x8 va[2][4], vb[2][4];
+      TileLoader16<AKC> la;
+      TileLoader16<BKC> lb;
+      la.init(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, kt0 * BK, p.K, tid);
+      lb.init(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, kt0 * BK, p.K, tid);
+      mainloop([&](int k0, s16x8* v) { la.load(k0, tid, v); }, [&](int k0, s16x8* v) { lb.load(k0, tid, v); },
                [&](bf16_t* t, const s16x8* v) { store_tile_b16<AKC>(t, tid, v); },
                [&](bf16_t* t, const s16x8* v) { store_tile_b16<BKC>(t, tid, v); }, va, vb);
     } else {
       const float* A = static_cast<const float*>(p.A) + batch * p.sa;
       const float* B = static_cast<const float*>(p.B) + batch * p.sb;
-      f32x4 va[4], vb[4];
+      f32x4 va[2][4], vb[2][4];
       mainloop([&](int k0, f32x4* v) { load_tile_f32<AKC>(A, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, k0, p.K, tid, v); },
                [&](int k0, f32x4* v) { load_tile_f32<BKC>(B, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, k0, p.K, tid, v); },
                [&](bf16_t* t, const f32x4* v) { store_tile_f32<AKC>(t, tid, v); },
@@ -204,7 +264,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBfParams p) {
         else *dst = v;
       }
   }
+  STAMP(4);
+  STAMP_FLUSH();
 }
+
+// (A 256 x 256 x 64 tile with 8 waves of 128 x 64 -- half the operand bytes per FLOP -- was built and measured in round 3: the same
+// 400 - 470 TFLOP/s on the large shapes, half the rate on the small weight-gradient outputs.  The stage timers
+// (tools/gemm_bf16_stamp.py) put a k tile of this kernel at 3.7x its MFMA time inside the multiply phase itself: fragment reads and
+// MFMAs of a wave do not overlap as hipcc schedules them, and the padded [row][k] image is 2-way conflicted under the real lane
+// groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table).  Next step: explicit read-ahead of the fragments and an XOR-swizzled
+// unpadded image; not a bigger tile.)
 
 template <int AKC, int BKC, int SRC16>
 int launch_one(const GemmBfParams& p, dim3 grid, hipStream_t s) {
@@ -246,6 +315,7 @@ extern "C" int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, 
   SS_REQUIRE(lda % q == 0 && ldb % q == 0 && stride_a % q == 0 && stride_b % q == 0, SS_ERR_UNSUPPORTED);
   SS_REQUIRE(src16 || ((a_kcontig ? K : M) % 4 == 0 && (b_kcontig ? K : N) % 4 == 0), SS_ERR_UNSUPPORTED);
   SS_REQUIRE(!src16 || ((a_kcontig ? K : M) <= lda && (b_kcontig ? K : N) <= ldb), SS_ERR_ARG);
+  // (bf16 operands are read through buffer descriptors: an operand of one batch entry must span less than 4 GB)
   SS_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0, SS_ERR_UNSUPPORTED);
   GemmBfParams p;
   p.M = M; p.N = N; p.K = K;

@@ -451,7 +451,7 @@ extern "C" int ss_gru_bf16_bwd(const float* d_out, const float* out, const float
                                const int32_t* lengths, int B, int T, int H, float* d_g, uint16_t* d_g_bf16, float drop_p,
                                uint64_t seed, uint64_t offset, float* g_bih_f, float* g_bhh_f, float* g_bih_r, float* g_bhh_r,
                                void* ws, void* sync_ws, ss_stream_t stream) {
-  SS_REQUIRE(d_out && out && save && whh_t_bf16 && lengths && d_g && ws, SS_ERR_ARG);
+  SS_REQUIRE(d_out && out && save && whh_t_bf16 && lengths && (d_g || d_g_bf16) && ws, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
   SS_REQUIRE(H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);
   const bool want_bias = g_bih_f || g_bhh_f || g_bih_r || g_bhh_r;
@@ -472,6 +472,7 @@ extern "C" int ss_gru_bf16_bwd(const float* d_out, const float* out, const float
     }
     return ss_launch_status();
   }
+  SS_REQUIRE(d_g, SS_ERR_ARG);  // the step kernels hand the gate gradients on through d_g
   StepBwdParams p;
   p.d_out = d_out; p.out = out; p.save = save; p.whht = whh_t_bf16; p.lengths = lengths;
   p.B = B; p.T = T; p.H = H; p.dG = d_g; p.drop_p = drop_p; p.seed = seed; p.offset = offset;

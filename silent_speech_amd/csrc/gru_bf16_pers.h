@@ -206,7 +206,8 @@ struct PersBwdParams {
   const bf16_t* whht;     // (2, H, 3H) bf16 transposed W_hh
   const int* lengths;
   int B, T, c0, nc;
-  float* dG;              // (2, N, 4, H) f32: d gi_r, d gi_z, d gi_n, d(W_hn h + b_hn)
+  float* dG;              // (2, N, 4, H) f32: d gi_r, d gi_z, d gi_n, d(W_hn h + b_hn), or null (126 MB per launch at config 5 that
+                          // nobody reads when the GEMMs take the bf16 copy and the bias sums are made here)
   bf16_t* dG_bf;          // the same as bf16, or null (operand of the d layer_in / weight-gradient GEMMs)
   float drop_p;
   uint64_t seed, offset;
@@ -337,11 +338,13 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
     }
     sb_r += dar; sb_z += daz; sb_n += dan; sb_q += dqn;
     if (clip_ok) {
-      float* gp = p.dG + ((long)dir * N + row) * (4 * H) + u0;
-      *reinterpret_cast<f32x4*>(gp) = dar;
-      *reinterpret_cast<f32x4*>(gp + H) = daz;
-      *reinterpret_cast<f32x4*>(gp + 2 * H) = dan;
-      *reinterpret_cast<f32x4*>(gp + 3 * H) = dqn;
+      if (p.dG) {
+        float* gp = p.dG + ((long)dir * N + row) * (4 * H) + u0;
+        *reinterpret_cast<f32x4*>(gp) = dar;
+        *reinterpret_cast<f32x4*>(gp + H) = daz;
+        *reinterpret_cast<f32x4*>(gp + 2 * H) = dan;
+        *reinterpret_cast<f32x4*>(gp + 3 * H) = dqn;
+      }
       if (p.dG_bf) {
         bf16_t* gb = p.dG_bf + ((long)dir * N + row) * (4 * H) + u0;
         *reinterpret_cast<uint2*>(gb) = br_;

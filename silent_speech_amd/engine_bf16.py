@@ -130,7 +130,8 @@ class WorkspaceBf16:
             self.i3 = torch.empty(N, 12, 12, c3, **u8)
         if train:
             self.save = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
-            self.dG = [torch.empty(2, N, 4, H, **f32) for _ in range(cfg.gru_layers)]
+            # gate gradients: only the bf16 copy (the GEMMs' operand) when the persistent BPTT kernel makes the bias sums itself
+            self.dG = [torch.empty(2, N, 4, H, **f32) if self.gru_sync is None else None for _ in range(cfg.gru_layers)]
             self.dG_bf = [torch.empty(2, N, 4, H, **i16) for _ in range(cfg.gru_layers)]
             self.d_out = torch.empty(N, 2 * H, **f32)
             self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
@@ -236,7 +237,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         top_layer = l == cfg.gru_layers - 1
         g_in = ws.d_out if top_layer else ws.d_lower[l + 1]
         L.call("ss_gru_bf16_bwd", g_in.data_ptr(), ws.out[l].data_ptr(), ws.save[l].data_ptr(), ws.whht[l].data_ptr(),
-               ws.lengths.data_ptr(), B, T, H, ws.dG[l].data_ptr(), ws.dG_bf[l].data_ptr(),
+               ws.lengths.data_ptr(), B, T, H, L.ptr(ws.dG[l]), ws.dG_bf[l].data_ptr(),
                0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed,
                (l + 1) << 40, G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
                G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.gru_ws.data_ptr(),

@@ -203,6 +203,12 @@ def test_gru_bf16_fwd_bwd(L, B, T, H, drop_p, persistent):
     if sync is not None:
         assert int(sync[2]) == 0
     assert torch.equal(dG_bf.cpu().view(torch.bfloat16).float(), bf(dG.cpu()))
+    if sync is not None:  # the f32 gate gradients are optional there: only the bf16 copy
+        dG_bf2 = torch.full_like(dG_bf, 0x7fc0)
+        L.call("ss_gru_bf16_bwd", d_out_d.data_ptr(), out.data_ptr(), save.data_ptr(), wtb.data_ptr(), lens.data_ptr(), B, T, H,
+               None, dG_bf2.data_ptr(), drop_p, seed, offset, None, None, None, None, ws.data_ptr(), L.ptr(sync), L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dG_bf2, dG_bf)
     dGs = dG.cpu().view(2, N, 4, H).sum(1)  # (2, 4, H) column sums
     for d in range(2):
         want_ih, want_hh = dGs[d, :3].reshape(-1), torch.cat([dGs[d, 0], dGs[d, 1], dGs[d, 3]])
