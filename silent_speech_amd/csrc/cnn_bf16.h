@@ -31,22 +31,44 @@ constexpr int row_stride_half_bank(int n) {
 }
 
 // LDS image of a C-channel H x W map with a one-pixel zero halo.  PS = pixel stride, RS = row stride (elements).
-// PS = C + 8 (C >= 32) keeps 16 consecutive pixels on 16 different 16-byte slots of the 256-byte bank row
-// (pixel stride 20 / 36 / 52 dwords, all 4 x odd); the 16-channel map keeps PS = 16 and pads its rows instead.
-template <int C_, int H_, int W_>
-struct Img {
-  static constexpr int C = C_, H = H_, W = W_;
+// The strides decide the bank conflicts of the MFMA operand reads, and those are set by the hardware's lane groups, not by 16
+// consecutive lanes: a ds_read_b128 is served in four groups of 16 lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_
+// MICROARCH.md, LDS table), i.e. pixels 0-3 and 12-15 of an M tile at chunk g together with pixels 4-11 at chunk g + 1.  Round 2's
+// PS = C + 8 was laid out for 16 consecutive lanes and cost every A-fragment read 2 - 3x its cycles (SQ_LDS_BANK_CONFLICT 0.5 - 0.6
+// of the active LDS cycles in the layer 3 / 4 kernels).  ImgLayout holds, per (channels, width), strides found by enumerating the
+// bank of every lane of every read pattern that touches the image (2 x 8-pixel tiles of the pooled forward layers, 16 consecutive
+// pixels of the data-gradient kernels and the last layer, the transposing reads of the weight-gradient kernels): zero conflicts
+// for the ds_read_b128 patterns.  Default (unlisted shapes): the round-2 rule.
+template <int C, int W>
+struct ImgLayout {
   static constexpr int PS = C >= 32 ? C + 8 : C;
   static constexpr int RS = C >= 32 ? (W + 2) * PS : row_stride_half_bank((W + 2) * PS);
+};
+template <> struct ImgLayout<32, 24> { static constexpr int PS = 32, RS = 848; };    // conv3 forward / weight gradient: a2
+template <> struct ImgLayout<64, 12> { static constexpr int PS = 80, RS = 1216; };   // conv4 forward: a3 (16 consecutive pixels)
+template <> struct ImgLayout<32, 48> { static constexpr int PS = 48, RS = 2400; };   // conv2 data gradient: dy2 band
+template <> struct ImgLayout<64, 24> { static constexpr int PS = 80, RS = 2176; };   // conv3 data gradient: dy3 band
+template <> struct ImgLayout<96, 12> { static constexpr int PS = 112, RS = 1600; };  // conv4 data gradient: dy4
+
+// TR = true: the image is read by the transposing reads of a weight-gradient kernel (ds_read_b64_tr_b16, two groups of 32 lanes):
+// those keep the round-2 strides (measured: conv3's weight gradient 0.25 -> 0.30 ms on the ds_read_b128 layout of its input).
+template <int C_, int H_, int W_, bool TR = false>
+struct Img {
+  static constexpr int C = C_, H = H_, W = W_;
+  static constexpr int PS = TR ? (C >= 32 ? C + 8 : C) : ImgLayout<C, W>::PS;
+  static constexpr int RS = TR ? (C >= 32 ? (W + 2) * PS : row_stride_half_bank((W + 2) * PS)) : ImgLayout<C, W>::RS;
+  static_assert(PS >= C && PS % 8 == 0 && RS >= (W + 2) * PS && RS % 8 == 0, "image strides");
   static constexpr int ELEMS = (H + 2) * RS;
   static constexpr int BYTES = ELEMS * 2;
   __device__ static constexpr int at(int y, int x) { return (y + 1) * RS + (x + 1) * PS; }  // (y, x) may be -1 .. H / W
 };
 
-// weights of a conv layer as the B operand: [n][kk], kk = tap * CK + c, rows padded to a multiple of 32 plus 8
+// weights of a conv layer as the B operand: [n][kk], kk = tap * CK + c, rows padded to a multiple of 32 plus 16: a lane group of
+// ds_read_b128 holds rows 0-3, 12-15 at chunk g and rows 4-11 at chunk g + 1, and the 16 reads fall on 16 different 16-byte slots
+// of the 256-byte bank row exactly when the row stride is == 16 (mod 32) elements (KP + 8, the round-2 stride, is 2-way conflicted)
 template <int CK, int CN>
 struct Wmat {
-  static constexpr int K = 9 * CK, KP = round_up(K, 32), LD = KP + 8, KSTEPS = KP / 32;
+  static constexpr int K = 9 * CK, KP = round_up(K, 32), LD = KP + 16, KSTEPS = KP / 32;
   static constexpr int ELEMS = CN * LD, BYTES = ELEMS * 2;
 };
 

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   static_assert(WCO * WCI * WK == NW && H % BH == 0, "wave split");
   static_assert(!RC || (CIN == C1 && H == 48 && W == 48 && !LAST), "recompute form: layer 2");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using IA = Img<CIN, BH, W>;
+  using IA = Img<CIN, BH, W, true>;
   constexpr int PSD = COUT + 8, RSD = W * PSD;           // dense dy band, no halo
   constexpr int DY_BYTES = BH * RSD * 2;
   constexpr int NCO = COUT / 16 / WCO, NCI = CIN / 16 / WCI;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
 
 template <int CIN, int COUT, int W, int BH, bool RC = false>
 constexpr int wgrad_lds() {
-  const int operands = BH * W * (COUT + 8) * 2 + Img<CIN, BH, W>::BYTES + 256 + (64 + 96 + 96) * 4 +
+  const int operands = BH * W * (COUT + 8) * 2 + Img<CIN, BH, W, true>::BYTES + 256 + (64 + 96 + 96) * 4 +
                        (RC ? round_up(98 * RS0 * 2, 16) + 256 * 4 + 12 * 64 * 16 : 0);
   const int halves = (COUT * CIN * 9 * 4 > 120 * 1024) ? 2 : 1;
   const int flush = COUT / halves * CIN * 9 * 4;  // the [co][ci][tap] image the gradients leave through

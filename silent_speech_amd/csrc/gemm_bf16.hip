@@ -34,13 +34,13 @@ __device__ __forceinline__ long remap_row(int r, int group, int gstride, int off
   return (long)(r / group) * gstride + (r % group) + off;
 }
 
-// LDS images of one operand tile (128 rows x BK k): k-contiguous operands as [row][BK + 8] (row stride = BK/2 + 4 dwords: the 16
-// rows of a fragment read cover all 64 banks), k-major operands as [k][128 + 24]: a transposing read takes 8-byte pieces of 4 k lines
+// LDS images of one operand tile (128 rows x BK k): k-contiguous operands as [row][BK + 16] (conflict-free under the lane groups of
+// ds_read_b128: rows 0-3, 12-15 at chunk g with rows 4-11 at chunk g + 1), k-major operands as [k][128 + 24]: a transposing read takes 8-byte pieces of 4 k lines
 // per 16-lane group and two groups (8 k lines apart) per pass -- with a line stride of 76 dwords (== 12 mod 64) the four lines
 // of a group sit 12 banks apart and the second group 32 banks further: no conflicts (128 + 8 gave 2-way ones, a third of the
 // kernel's active LDS cycles).
 template <int BK> struct Tile {
-  static constexpr int LDK = BK + 8, LDR = 128 + 24;
+  static constexpr int LDK = BK + 16, LDR = 128 + 24;  // LDK == 16 (mod 32): see Wmat in cnn_bf16.h
   static constexpr int ELEMS = (BM * LDK > BK * LDR) ? BM * LDK : BK * LDR;
 };
 
