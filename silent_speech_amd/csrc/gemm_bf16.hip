@@ -87,18 +87,26 @@ __device__ __forceinline__ void store_tile_f32(bf16_t* tile, int tid, const f32x
 // num_records and comes back as zeros.  (Loads inside `if (in range)` branches made hipcc wait vmcnt(0) before the LDS stores --
 // it cannot count loads through divergent branches -- which also waited for the tiles just requested: no prefetch at all.)
 typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0xFFFFFF00u;
+constexpr unsigned OOB = 0x80000000u;  // beyond num_records with or without the (small) scalar offset added
+// The kernel is bound by vector-instruction ISSUE, not by the matrix pipes: an MFMA 16x16x32 holds the issue port for 8 of its 16
+// cycles and every other vector instruction adds its full cost (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') -- at 3
+// address / predicate instructions per MFMA a k tile took 2 000 cycles of a SIMD's two waves for 1 024 cycles of MFMA.  So an
+// operand without a row remap (every operand but the two of the d W_hh GEMMs) advances through k with the buffer instruction's
+// SCALAR offset: its per-lane offsets are fixed for the whole K loop and the k range is only tested on a ragged last tile.
 template <int KC>
 struct TileLoader16 {
   __amdgpu_buffer_rsrc_t rs;
-  unsigned boff[4];       // KC = 1: byte offset of the chunk's row at k = 0;  KC = 0: of its column in row 0  (OOB: outside)
-  int quo[4], rem[4];     // KC = 0: storage row of the chunk's current k = quo * gstride + rem + off
+  unsigned boff[4];       // identity map: byte offset of the chunk at k = 0 (OOB: outside the operand)
+                          // remapped:     KC = 1 the chunk's row at k = 0; KC = 0 its column in row 0
+  int quo[4], rem[4];     // remapped, KC = 0: storage row of the chunk's current k = quo * gstride + rem + off
   int ld, group, gstride, off, dq, dm, k_end;
+  bool ident;
   __device__ __forceinline__ void init(const bf16_t* __restrict__ src, int ld_, int group_, int gstride_, int off_, int row0, int rows,
                                        int k0, int k_end_, int tid) {
     ld = ld_; group = group_; gstride = gstride_; off = off_; k_end = k_end_;
     dq = 64 / group; dm = 64 % group;
-    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(src), 0, (int)0xFFFFFE00u, 0x00020000);
+    ident = group == 0x7FFFFFFF && off == 0;
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i;
@@ -108,13 +116,28 @@ struct TileLoader16 {
         quo[i] = rem[i] = 0;
       } else {
         const int c = row0 + 8 * (idx & 15), k = k0 + (idx >> 4);
-        boff[i] = c < rows ? (unsigned)(2 * c) : OOB;
+        boff[i] = c < rows ? (unsigned)(2 * c) + (ident ? (unsigned)(2 * (idx >> 4) * ld) : 0u) : OOB;
         quo[i] = k / group; rem[i] = k % group;
       }
     }
   }
   // the tile at k0 (tiles are requested in ascending order, one BK apart)
   __device__ __forceinline__ void load(int k0, int tid, s16x8 v[4]) {
+    if (ident) {  // wave-uniform
+      const int soff = KC ? 2 * k0 : 2 * k0 * ld;  // scalar: the whole tile's step through k
+      if (k0 + 64 <= k_end) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)boff[i], soff, 0));
+      } else {  // ragged last tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = tid + 256 * i;
+          const int k = KC ? k0 + 8 * (idx & 7) : k0 + (idx >> 4);
+          v[i] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(k < k_end ? boff[i] : OOB), soff, 0));
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i;
@@ -190,19 +213,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBfParams p) {
         load_a((kt + 2) * BK, va[cur]);
         load_b((kt + 2) * BK, vb[cur]);
       }
+      // every fragment of the tile is requested before its first MFMA, behind a scheduling fence.  Stage timers of one workgroup
+      // alone on its CU (a d W_hh slice, 116 k tiles; finer stamps than the ones kept here): issuing the tile's 8 buffer loads and
+      // 32 transposing reads 980 cycles, the reads landing 260, the 32 MFMAs 760 (512 without the timers), the wait for the
+      // operands of the next tile + their LDS stores 970, the barrier 290 -- every phase waits for the one before it.  What the
+      // kernel needs next is the f32 GEMM's recipe (gemm.hip): operands by LDS-DMA into a ring three tiles deep, no staging
+      // registers, no LDS store instructions; the changes of round 3 (counted waits, scalar k advance, conflict-free strides)
+      // moved it from 250 to 400 - 500 TFLOP/s.
+      s16x8 fa[BK / 32][4], fb[BK / 32][4];
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 32) {
-        s16x8 fa[4], fb[4];
+      for (int k2 = 0; k2 < BK / 32; ++k2)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          fa[t] = AKC ? lds_frag(As + (wm + 16 * t + li) * T::LDK + kk + 8 * g) : lds_frag_tr(As + kk * T::LDR + wm + 16 * t, T::LDR, lane);
-          fb[t] = BKC ? lds_frag(Bs + (wn + 16 * t + li) * T::LDK + kk + 8 * g) : lds_frag_tr(Bs + kk * T::LDR + wn + 16 * t, T::LDR, lane);
+          const int kk = 32 * k2;
+          fa[k2][t] = AKC ? lds_frag(As + (wm + 16 * t + li) * T::LDK + kk + 8 * g) : lds_frag_tr(As + kk * T::LDR + wm + 16 * t, T::LDR, lane);
+          fb[k2][t] = BKC ? lds_frag(Bs + (wn + 16 * t + li) * T::LDK + kk + 8 * g) : lds_frag_tr(Bs + kk * T::LDR + wn + 16 * t, T::LDR, lane);
         }
+      SS_SCHED_FENCE();
+#pragma unroll
+      for (int k2 = 0; k2 < BK / 32; ++k2)
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
-      }
+          for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[k2][a], fb[k2][b], acc[a][b]);
+      SS_SCHED_FENCE();
       STAMP(1);
       if (kt + 1 < kt1) {
         store_a(lds + (2 * (cur ^ 1)) * T::ELEMS, va[cur ^ 1]);
