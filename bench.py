@@ -48,6 +48,7 @@ def c5_gflop_per_step(B, T, D):
         "ss_c5_conv_last_wgrad": f(N * (conv[4] + c4 * E)), "ss_c5_conv_last_dgrad": f(N * (conv[4] + c4 * E)),
         "ss_c5_conv3_wgrad": f(N * conv[3]), "ss_c5_conv3_dgrad": f(N * conv[3]),
         "ss_c5_conv2_wgrad_rc": f(N * conv[2]), "ss_c5_conv2_dgrad": f(N * conv[2]), "ss_c5_conv1_wgrad": f(N * conv[1]),
+        "ss_c5_conv2_dgrad_conv1_wgrad": f(N * (conv[2] + conv[1])),
         "gemm_bf16_ih": f(2 * N * 3 * H * ih), "gemm_bf16_dX": f(2 * N * 3 * H * (E + 2 * H)),
         "gemm_bf16_dW": f(2 * N * 3 * H * ih + 2 * 2 * N * 3 * H * H),
         "ss_gru_bf16_fwd": f(2 * 2 * N * 3 * H * H), "ss_gru_bf16_bwd": f(2 * 2 * N * 3 * H * H),
@@ -219,7 +220,7 @@ KERNEL_STEMS = {
     "ss_roi_cnn_bwd": ["roi_cnn_bwd_kernel"], "ss_roi_cnn_fwd_stash": ["roi_cnn_fwd_kernel"], "ss_gru_fwd": ["gru_split_fwd_kernel"],
     "ss_gru_bwd": ["gru_split_bwd_kernel"], "ss_gru_bf16_fwd": ["gru_pers_fwd_kernel"], "ss_gru_bf16_bwd": ["gru_pers_bwd_kernel"],
     "ss_c5_conv12_fwd": ["conv12_fwd_kernel"], "ss_c5_conv1_wgrad": ["conv1_wgrad_kernel"], "ss_c5_conv2_wgrad_rc": ["conv_wgrad_kernel<16, 32"],
-    "ss_c5_conv2_dgrad": ["conv_dgrad_kernel<16, 32"], "ss_c5_conv3_wgrad": ["conv_wgrad_kernel<32, 64"],
+    "ss_c5_conv2_dgrad": ["conv_dgrad_kernel<16, 32"], "ss_c5_conv2_dgrad_conv1_wgrad": ["conv2_dgrad_w1_kernel"], "ss_c5_conv3_wgrad": ["conv_wgrad_kernel<32, 64"],
     "ss_c5_conv3_dgrad": ["conv_dgrad_kernel<32, 64"], "ss_c5_conv_last_wgrad": ["conv_wgrad_kernel<64, 96"],
     "ss_c5_conv_last_dgrad": ["conv_dgrad_kernel<64, 96"], "ss_c5_conv3_fwd": ["conv_fwd_kernel<32, 64"],
     "ss_c5_conv_last_fwd": ["conv_fwd_kernel<64, 96"], "gemm_bf16_dW": ["gemm_bf16_kernel<0, 0>"],

@@ -312,6 +312,12 @@ int ss_c5_conv_last_dgrad(const float* dz, int ld_dz, int E, const float* wfc, c
                           uint16_t* da_in, ss_stream_t stream);
 int ss_c5_conv1_wgrad(const uint8_t* R, int N, int standardize, const float* st, const uint16_t* da1, const uint8_t* i1,
                       const float* w1, const float* b1, float* g_w1, float* g_b1, ss_stream_t stream);
+/* ss_c5_conv_dgrad(2) and ss_c5_conv1_wgrad (recompute form) in ONE kernel: the gradient w.r.t. the pooled conv1 map (73.7 KB per
+ * frame, the largest gradient of the net) is born band by band in LDS and consumed there: 1.13 GB per step at config 5 that no
+ * longer crosses HBM.  da1 may be NULL (the product path); non-NULL: the map is also stored (N,48,48,16), for tests. */
+int ss_c5_conv2_dgrad_conv1_wgrad(const uint16_t* da2, const uint8_t* i2, int N, const float* w2, const uint8_t* R, const float* st,
+                                  int standardize, const float* w1, const float* b1, uint16_t* da1, float* g_w1, float* g_b1,
+                                  ss_stream_t stream);
 /* The fused forms the engine uses (the pooled conv1 map -- 74 KB per frame + 37 KB of argmax bytes, the largest tensor of the
  * net -- never reaches HBM):
  *   ss_c5_conv12_fwd      R -> a2 (N,24,24,32), i2, st: conv1 lands in conv2's LDS image

@@ -45,6 +45,7 @@ SIGNATURES = {
     "ss_c5_conv_last_wgrad": [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "ss_c5_conv_last_dgrad": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "ss_c5_conv1_wgrad": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ss_c5_conv2_dgrad_conv1_wgrad": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_c5_conv12_fwd": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_c5_conv2_wgrad_rc": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "ss_gru_bf16_prep": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],

@@ -643,6 +643,214 @@ __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
   }
 }
 
+// ================================================================================================ conv2 dgrad + conv1 wgrad, fused
+// d a1 = conv_transpose(dy2, W2) is the largest gradient map of the net (73.7 KB per frame as bf16): as two kernels it was written
+// to HBM by conv2's data gradient and read back by conv1's weight gradient, 1.13 GB per step for a tensor nobody else wants.
+// Here a band of 8 rows of d a1 is born in LDS (conv_dgrad_kernel's routine) and consumed on the spot by conv1's weight gradient
+// on the pooled grid (conv1_wgrad_kernel's routine: pool winners recomputed from the frame, four slot-masked images, 4 x 4
+// patches by transposing reads) -- in two halves of 4 rows, so that the masked images fit beside the dy band, the weights and the
+// two copies of the normalised frame.  Optionally (tests) the band is also stored, bit-identical to conv_dgrad_kernel's.
+struct Conv2DgradW1Params {
+  int N;
+  const bf16_t* da2;     // (N, 24, 24, 32) gradient w.r.t. the pooled conv2 output (unmasked)
+  const uint8_t* i2;     // (N, 24, 24, 32) conv2's pool winners
+  const float* w2;       // (32, 16, 3, 3)
+  const uint8_t* R;      // (N, 96, 96)
+  const float* st;       // (N, 2) mean, std from the forward
+  int standardize;
+  const float *w1, *b1;  // conv1 (to recompute its pool winners)
+  bf16_t* da1;           // (N, 48, 48, 16) or null
+  float *g_w1, *g_b1;
+};
+
+constexpr int F_BH = 8, F_HB = 4;                                   // rows of d a1 per band / per conv1-wgrad half band
+using F_ID = Img<C2, F_BH, 48>;                                     // haloed dy2 band
+using F_WM = Wmat<C2, C1>;                                          // [ci][tap' * 32 + co]
+constexpr int F_O_W = F_ID::BYTES;
+constexpr int F_O_OA = F_O_W + round_up(F_WM::BYTES, 16);           // [8 * 48][16] bf16
+constexpr int F_O_IMG = F_O_OA + F_BH * 48 * C1 * 2;                // imgE, imgO
+constexpr int F_AE = F_HB * 48 * C1;                                // elements per masked image of a half band
+constexpr int F_O_AE = F_O_IMG + 2 * C1_IMG * 2;
+constexpr int F_O_XN = F_O_AE + 4 * F_AE * 2;                       // [256] f32, then s_red [256] f32, then ibl bytes
+constexpr int CONV2_DGRAD_W1_LDS = F_O_XN + 256 * 4 + 256 * 4 + F_BH * 48 * C1;
+static_assert(CONV2_DGRAD_W1_LDS <= 160 * 1024, "LDS");
+
+__global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HP = 48, H = 48, W = 48;
+  bf16_t* dyi = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* wl = reinterpret_cast<bf16_t*>(smem + F_O_W);
+  bf16_t* oa = reinterpret_cast<bf16_t*>(smem + F_O_OA);
+  bf16_t* imgE = reinterpret_cast<bf16_t*>(smem + F_O_IMG);
+  bf16_t* imgO = imgE + C1_IMG;
+  bf16_t* ae = reinterpret_cast<bf16_t*>(smem + F_O_AE);
+  float* s_xn = reinterpret_cast<float*>(smem + F_O_XN);
+  float* s_red = s_xn + 256;
+  uint8_t* ibl = reinterpret_cast<uint8_t*>(s_red + 256);            // [8][48][16] recomputed pool winners of the band
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int q4 = li >> 2, p4 = li & 3;
+
+  s16x8 bq[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) bq[q] = conv1_bfrag(p.w1, q, g, li);
+  const float bias1 = p.b1[li];
+  zero_lds(dyi, F_ID::BYTES, tid);
+  zero_lds(imgE, 2 * C1_IMG * 2, tid);
+  for (int q = tid; q < C1 * F_WM::KP; q += NT) {  // flipped, transposed conv2 weights (conv_dgrad_kernel)
+    const int ci = q / F_WM::KP, kk = q % F_WM::KP, tap = kk / C2, co = kk % C2;
+    wl[ci * F_WM::LD + kk] = to_bf16(tap < 9 ? p.w2[((long)co * C1 + ci) * 9 + (8 - tap)] : 0.f);
+  }
+  f32x4 acc1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc1[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gb[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gb[k] = 0.f;
+
+  uint4 px[2];
+  auto load_px = [&](int n) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
+    px[0] = src[tid];
+    px[1] = (tid + NT < HW0 * HW0 / 16) ? src[tid + NT] : uint4{0u, 0u, 0u, 0u};
+  };
+  ExpandLoad<C2, H, W, F_BH + 2> pe;
+  auto issue = [&](int n, int y0) { pe.issue(p.da2 + (long)n * 24 * 24 * C2, p.i2 + (long)n * 24 * 24 * C2, y0 - 1, tid); };
+  if ((int)blockIdx.x < p.N) {
+    load_px(blockIdx.x);
+    issue(blockIdx.x, 0);
+  }
+  __syncthreads();
+
+  constexpr int MT = 3, MTILES = F_BH * W / 16;  // 24 m tiles per band: one unit of 3 per wave
+  static_assert(MTILES / MT == NW, "one d a1 unit per wave");
+  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    // ---- the frame's normalised image, twice (conv1_wgrad_kernel)
+    if (tid < 256) {
+      const float rr = (float)tid / 255.0f;
+      s_xn[tid] = p.standardize ? (rr - p.st[2 * (long)n]) / p.st[2 * (long)n + 1] : rr;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + k * NT;
+      if (q < HW0 * HW0 / 16) {
+        const int lin = q * 16, r = lin / HW0 + 1, c0 = lin % HW0 + 1;
+        const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const bf16_t xv = to_bf16(s_xn[(wds[e] >> (8 * b)) & 255u]);
+            const int c = c0 + 4 * e + b;
+            imgE[r * C1_XS + c] = xv;
+            if (c >= 2) imgO[r * C1_XS + c - 2] = xv;
+          }
+      }
+    }
+    for (int y0 = 0; y0 < H; y0 += F_BH) {
+      const bool last_band = y0 + F_BH >= H;
+      pe.commit(dyi, F_ID::at(-1, 0), F_ID::RS, F_ID::PS, y0 - 1, tid);
+      __syncthreads();  // dy band and (first band) the frame images are complete
+      {
+        const int nn = last_band ? n + (int)gridDim.x : n;
+        if (nn < p.N) {
+          issue(nn, last_band ? 0 : y0 + F_BH);
+          if (last_band) load_px(nn);
+        }
+      }
+      // ---- d a1 rows y0 .. y0+7 -> oa (bf16), one unit per wave
+      {
+        int base[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          const int P = 16 * (wv * MT + a) + li;
+          base[a] = F_ID::at(P / W - 1, P % W - 1) + 8 * g;
+        }
+        f32x4 acc[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < F_WM::KSTEPS; ++s2) {
+          const int tap = (32 * s2) / C2, c0 = (32 * s2) % C2;
+          const int off = (tap / 3) * F_ID::RS + (tap % 3) * F_ID::PS + c0;
+          const s16x8 fb = lds_frag(wl + li * F_WM::LD + 32 * s2 + 8 * g);
+#pragma unroll
+          for (int a = 0; a < MT; ++a) acc[a] = mfma_bf16(lds_frag(dyi + base[a] + off), fb, acc[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oa[(16 * (wv * MT + a) + 4 * g + r) * C1 + li] = to_bf16(acc[a][r]);
+      }
+      // ---- conv1 again for the band's 8 row pairs (one per wave): only the pool winners are kept
+      conv1_rows(imgE, [&](int q) { return bq[q]; }, bias1, y0, y0 + F_BH, y0, nullptr, 0, 0, 0, ibl, wv, g, li);
+      __syncthreads();
+      if (p.da1) {
+        uint4* dst = reinterpret_cast<uint4*>(p.da1 + ((long)n * H + y0) * W * C1);
+        for (int q = tid; q < F_BH * W * C1 * 2 / 16; q += NT) dst[q] = reinterpret_cast<const uint4*>(oa)[q];
+      }
+      // ---- conv1's weight gradient over the band, in two halves of 4 pooled rows
+      for (int hb = 0; hb < F_BH / F_HB; ++hb) {
+        if (tid < F_HB * HP * 2) {  // 8 channels of one pooled pixel per thread: split by window slot
+          const int half = tid & 1, pp = tid >> 1;
+          const int src = (hb * F_HB * HP + pp) * C1 + 8 * half;
+          const uint4 dv = *reinterpret_cast<const uint4*>(oa + src);
+          const uint2 iv = *reinterpret_cast<const uint2*>(ibl + src);
+          const unsigned d[4] = {dv.x, dv.y, dv.z, dv.w};
+          unsigned o[4][4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const unsigned ib = (kk < 2 ? iv.x : iv.y) >> (16 * (kk & 1));
+            const unsigned ia = ib & 255u, ic = (ib >> 8) & 255u;
+            const unsigned lo = d[kk] & 0xffffu, hi = d[kk] & 0xffff0000u;
+            if (ia < 4u) gb[2 * kk] += __uint_as_float(lo << 16);
+            if (ic < 4u) gb[2 * kk + 1] += __uint_as_float(hi);
+#pragma unroll
+            for (unsigned e = 0; e < 4; ++e) o[e][kk] = (ia == e ? lo : 0u) | (ic == e ? hi : 0u);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            *reinterpret_cast<uint4*>(ae + e * F_AE + pp * C1 + 8 * half) = uint4{o[e][0], o[e][1], o[e][2], o[e][3]};
+        }
+        __syncthreads();
+        const int r0 = y0 + hb * F_HB;
+        for (int ch = wv; ch < F_HB * HP / 32; ch += NW) {
+          const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;
+          const int ya = r0 + P0 / HP, xa = P0 % HP, yb = r0 + P1 / HP, xb = P1 % HP;
+          const bf16_t* v0 = ((xa & 1) ? imgO - 2 : imgE) + (2 * ya + p4) * C1_XS + 2 * xa;
+          const bf16_t* v1 = ((xb & 1) ? imgO - 2 : imgE) + (2 * yb + p4) * C1_XS + 2 * xb;
+          const s16x8 fb = tr_pair(v0, v1);
+          const bf16_t* a0 = ae + P0 * C1 + 4 * p4;
+          const bf16_t* a1 = ae + P1 * C1 + 4 * p4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc1[e] = mfma_bf16(tr_pair(a0 + e * F_AE, a1 + e * F_AE), fb, acc1[e]);
+        }
+        __syncthreads();  // the next half / band rewrites ae, oa, ibl and the dy band
+      }
+    }
+  }
+  // ---- fold the slots into the 3 x 3 taps, the waves through LDS, one atomic per element (conv1_wgrad_kernel)
+  for (int q = tid; q < 16 * 16; q += NT) s_red[q] = 0.f;
+  __syncthreads();
+  const int vy = li >> 2, vx = li & 3;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ky = vy - (e >> 1), kx = vx - (e & 1);
+    if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&s_red[(4 * g + r) * 16 + 3 * ky + kx], acc1[e][r]);
+  }
+  if (tid < F_HB * HP * 2)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&s_red[(8 * (tid & 1) + k) * 16 + 9], gb[k]);
+  __syncthreads();
+  if (tid < 16 * 16) {
+    const int c = tid >> 4, k = tid & 15;
+    if (k < 9) atomicAdd(p.g_w1 + c * 9 + k, s_red[tid]);
+    else if (k == 9) atomicAdd(p.g_b1 + c, s_red[tid]);
+  }
+}
+
 // wgs_per_cu: workgroups the LDS footprint lets a CU hold; the grid is that many times the 256 CUs (a persistent workgroup walks
 // its share of the frames), so one workgroup's commit / barrier phases run under another's MFMAs
 template <class P, class K>
@@ -681,13 +889,23 @@ extern "C" int ss_c5_conv2_wgrad_rc(const uint8_t* R, const float* st, int stand
                            static_cast<hipStream_t>(stream));
 }
 
+// conv2's data gradient and conv1's weight gradient in one kernel: d a1 never reaches HBM (da1 = NULL; a non-NULL da1 also gets the
+// map, for tests).  da2 / i2 (N,24,24,32), R (N,96,96), st (N,2) from the forward, w2 (32,16,3,3), w1 / b1 conv1.
+extern "C" int ss_c5_conv2_dgrad_conv1_wgrad(const uint16_t* da2, const uint8_t* i2, int N, const float* w2, const uint8_t* R,
+                                             const float* st, int standardize, const float* w1, const float* b1, uint16_t* da1,
+                                             float* g_w1, float* g_b1, ss_stream_t stream) {
+  SS_REQUIRE(da2 && i2 && w2 && R && st && w1 && b1 && g_w1 && g_b1 && N > 0, SS_ERR_ARG);
+  Conv2DgradW1Params p{N, da2, i2, w2, R, st, standardize, w1, b1, da1, g_w1, g_b1};
+  return launch_persistent(conv2_dgrad_w1_kernel, p, CONV2_DGRAD_W1_LDS, N, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int ss_c5_conv_dgrad(int layer, const uint16_t* da_out, const uint8_t* idx, int N, const float* w, uint16_t* da_in,
                                 ss_stream_t stream) {
   SS_REQUIRE(da_out && idx && w && da_in && N > 0, SS_ERR_ARG);
   ConvBwdParams p{};
   p.N = N; p.da_out = da_out; p.idx = idx; p.w = w; p.da_in = da_in;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (layer == 2) return launch_persistent(conv_dgrad_kernel<C1, C2, 48, 48, false, 8, 6, true>, p, dgrad_lds<C1, C2, 48, 8, true>(), N, s, 2);
+  if (layer == 2) return launch_persistent(conv_dgrad_kernel<C1, C2, 48, 48, false, 8, 3, true>, p, dgrad_lds<C1, C2, 48, 8, true>(), N, s, 2);
   if (layer == 3) return launch_persistent(conv_dgrad_kernel<C2, C3, 24, 24, false, 4, 3, true>, p, dgrad_lds<C2, C3, 24, 4, true>(), N, s, 2);
   return SS_ERR_UNSUPPORTED;
 }
@@ -711,7 +929,7 @@ extern "C" int ss_c5_conv_last_dgrad(const float* dz, int ld_dz, int E, const fl
   SS_REQUIRE(E > 0 && E <= 64 && ld_dz >= E, SS_ERR_UNSUPPORTED);
   ConvBwdParams p{};
   p.N = N; p.dz = dz; p.ld_dz = ld_dz; p.E = E; p.wfc = wfc; p.mask = mask; p.w = w; p.da_in = da_in;
-  return launch_persistent(conv_dgrad_kernel<C3, C4, 12, 12, true, 12, 9, false>, p, dgrad_lds<C3, C4, 12, 12, false>(), N,
+  return launch_persistent(conv_dgrad_kernel<C3, C4, 12, 12, true, 12, 3, false>, p, dgrad_lds<C3, C4, 12, 12, false>(), N,
                            static_cast<hipStream_t>(stream));
 }
 

@@ -549,3 +549,22 @@ def test_c5_conv12_fused_forward_and_recomputing_backward(L, N, wg_cap):
     torch.cuda.synchronize()
     assert float((g1.cpu() - g1_ref).abs().max()) < 3e-4 * float(g1_ref.abs().max())
     assert float((gb1.cpu() - dy1.double().sum(dim=(0, 2, 3)).float()).abs().max()) < 3e-4 * float(gb1.abs().max())
+
+    # ---- conv2's data gradient + conv1's weight gradient fused (d a1 stays in LDS): the same numbers as the two kernels in a row
+    da1_two = torch.empty(N, 48, 48, 16, device="cuda", dtype=torch.int16)
+    L.call("ss_c5_conv_dgrad", 2, da2_d.data_ptr(), idx2_d.data_ptr(), N, w2_d.data_ptr(), da1_two.data_ptr(), L.stream())
+    g1a, gb1a = torch.zeros(16, 1, 3, 3, device="cuda"), torch.zeros(16, device="cuda")
+    L.call("ss_c5_conv1_wgrad", R_d.data_ptr(), N, 1, st.data_ptr(), da1_two.data_ptr(), None, w1_d.data_ptr(), b1_d.data_ptr(),
+           g1a.data_ptr(), gb1a.data_ptr(), L.stream())
+    da1_f = torch.full_like(da1_two, 0x7fc0)
+    g1f, gb1f = torch.zeros(16, 1, 3, 3, device="cuda"), torch.zeros(16, device="cuda")
+    L.call("ss_c5_conv2_dgrad_conv1_wgrad", da2_d.data_ptr(), idx2_d.data_ptr(), N, w2_d.data_ptr(), R_d.data_ptr(), st.data_ptr(), 1,
+           w1_d.data_ptr(), b1_d.data_ptr(), da1_f.data_ptr(), g1f.data_ptr(), gb1f.data_ptr(), L.stream())
+    g1n, gb1n = torch.zeros(16, 1, 3, 3, device="cuda"), torch.zeros(16, device="cuda")
+    L.call("ss_c5_conv2_dgrad_conv1_wgrad", da2_d.data_ptr(), idx2_d.data_ptr(), N, w2_d.data_ptr(), R_d.data_ptr(), st.data_ptr(), 1,
+           w1_d.data_ptr(), b1_d.data_ptr(), None, g1n.data_ptr(), gb1n.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(da1_f, da1_two), "the fused kernel's d a1 band differs from conv_dgrad's"
+    for got_w, got_b in ((g1f, gb1f), (g1n, gb1n)):
+        assert float((got_w - g1a).abs().max()) < 1e-4 * float(g1a.abs().max())
+        assert float((got_b - gb1a).abs().max()) < 1e-4 * float(gb1a.abs().max())
