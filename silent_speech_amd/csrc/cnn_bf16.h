@@ -89,10 +89,54 @@ __device__ __forceinline__ s16x8 conv1_bfrag(const float* __restrict__ w1, int q
 
 // conv1 of the row pairs [yp0, yp1) of a frame whose normalised bf16 image sits at img ([98][RS0]): pooled ReLU output
 // (bf16) into dst(yp, xp)[c], dst(yp, xp) = a1 + off0 + (yp - ypb) * RS + xp * PS; optionally the argmax bytes into
-// ib[((yp - ypb) * 48 + xp) * 16 + c].  bq = the 12 constant B fragments (output position q of a patch).
+// ib[((yp - ypb) * 48 + xp) * 16 + c].  getb(q) = the 12 constant weight fragments (output position q of a patch), bias4 = the
+// biases of channels 4g .. 4g+3.
+// The product is taken TRANSPOSED (round 3): the constant weight fragment is the A operand, the patch the B operand -- the same
+// register contents, the operands swapped -- so D[row = channel][column = patch]: a lane then holds FOUR CHANNELS of one pooled
+// pixel, which leave as one 8-byte LDS store (and one 4-byte store of argmax bytes) after two v_cvt_pk_bf16_f32, where the
+// [patch][channel] form wrote twelve 2-byte values per lane with one convert each.  The epilogue is what this routine costs (its
+// twelve MFMAs take 192 cycles): 123 -> 74 vector instructions per row pair, and three kernels recompute conv1 with it.
 template <class GETB>
-__device__ __forceinline__ void conv1_rows(const bf16_t* img, GETB getb, float bias, int yp0, int yp1, int ypb, bf16_t* a1, int off0,
+__device__ __forceinline__ void conv1_rows(const bf16_t* img, GETB getb, f32x4 bias4, int yp0, int yp1, int ypb, bf16_t* a1, int off0,
                                            int RS, int PS, uint8_t* ib, int wv, int g, int li) {
+  for (int yp = yp0 + wv; yp < yp1; yp += NW) {
+    const unsigned* ap = reinterpret_cast<const unsigned*>(img + (2 * yp + g) * RS0 + 6 * li);
+    const s16x8 fa = __builtin_bit_cast(s16x8, uint4{ap[0], ap[1], ap[2], ap[3]});
+    f32x4 acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = mfma_bf16(getb(q), fa, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {  // pooled pixel xp = 3 li + w of the row pair; r = channel 4g + r
+      f32x4 v;
+      unsigned ibytes = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float best = acc[2 * w][r];
+        int bi = 0;
+        if (ib) {
+          if (acc[2 * w + 1][r] > best) { best = acc[2 * w + 1][r]; bi = 1; }
+          if (acc[6 + 2 * w][r] > best) { best = acc[6 + 2 * w][r]; bi = 2; }
+          if (acc[6 + 2 * w + 1][r] > best) { best = acc[6 + 2 * w + 1][r]; bi = 3; }
+        } else {
+          best = fmaxf(fmaxf(best, acc[2 * w + 1][r]), fmaxf(acc[6 + 2 * w][r], acc[6 + 2 * w + 1][r]));
+        }
+        v[r] = fmaxf(best + bias4[r], 0.f);
+        if (ib) ibytes |= (unsigned)(v[r] > 0.f ? bi : IDX_DEAD) << (8 * r);
+      }
+      const int xp = 3 * li + w;
+      if (a1) *reinterpret_cast<uint2*>(a1 + off0 + (yp - ypb) * RS + xp * PS + 4 * g) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+      if (ib) *reinterpret_cast<unsigned*>(ib + ((yp - ypb) * 48 + xp) * C1 + 4 * g) = ibytes;
+    }
+  }
+}
+
+
+// The pool winners alone (conv1's weight gradient recomputes them from the frame): the [patch][channel] product of round 2 --
+// lane (g, li) holds channel li of the pooled pixels 3 (4g + r) + w -- kept for this use: measured, the transposed form with its
+// packed 4-byte stores made the fused conv2-dgrad / conv1-wgrad kernel slower (0.72 -> 0.77 ms).  bias = b1[li].
+template <class GETB>
+__device__ __forceinline__ void conv1_winners(const bf16_t* img, GETB getb, float bias, int yp0, int yp1, int ypb, uint8_t* ib, int wv,
+                                              int g, int li) {
   for (int yp = yp0 + wv; yp < yp1; yp += NW) {
     const unsigned* ap = reinterpret_cast<const unsigned*>(img + (2 * yp + g) * RS0 + 6 * li);
     const s16x8 fa = __builtin_bit_cast(s16x8, uint4{ap[0], ap[1], ap[2], ap[3]});
@@ -110,8 +154,7 @@ __device__ __forceinline__ void conv1_rows(const bf16_t* img, GETB getb, float b
         if (acc[6 + 2 * w + 1][r] > best) { best = acc[6 + 2 * w + 1][r]; bi = 3; }
         const float v = fmaxf(best + bias, 0.f);
         const int xp = 3 * (4 * g + r) + w;
-        if (a1) a1[off0 + (yp - ypb) * RS + xp * PS + li] = to_bf16(v);
-        if (ib) ib[((yp - ypb) * 48 + xp) * C1 + li] = (uint8_t)(v > 0.f ? bi : IDX_DEAD);
+        ib[((yp - ypb) * 48 + xp) * C1 + li] = (uint8_t)(v > 0.f ? bi : IDX_DEAD);
       }
   }
 }

@@ -19,6 +19,8 @@ extern int ss_cnn_max_wgs;  // roi_cnn.hip: test hook, workgroups per launch (0 
 namespace {
 using namespace c5;
 
+STAMP_TABLE(ss_debug_stamps_c5_fwd)
+
 __device__ __forceinline__ void zero_lds(void* base, int bytes, int tid) {
   uint4* p = reinterpret_cast<uint4*>(base);
   for (int q = tid; q < bytes / 16; q += NT) p[q] = uint4{0u, 0u, 0u, 0u};
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(NT, 2) void conv1_fwd_kernel(Conv1Params p) {
   unsigned* s_red = reinterpret_cast<unsigned*>(s_misc);                 // [NW][2]
   float* s_stat = s_misc + 32;
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: as an SGPR the tile / row arithmetic that hangs on it runs on the scalar unit
   zero_lds(img, o_tab, tid);
   // constant B fragments: output position q = (oy, ox) of a patch reads patch cell (oy + ky, ox + kx)
   s16x8 bq[12];
@@ -222,7 +225,8 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
   float* s_bias = reinterpret_cast<float*>(smem + round_up(o_misc, 16));      // [COUT]
   float* s_feat = s_bias + COUT;                                              // [COUT]
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: as an SGPR the tile / row arithmetic that hangs on it runs on the scalar unit
   zero_lds(img, IM::BYTES, tid);
   stage_weights<CIN, COUT>(p.w, wl, tid);
   for (int q = tid; q < COUT; q += NT) s_bias[q] = p.b[q];
@@ -373,6 +377,7 @@ struct Conv12Params {
 };
 
 __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
+  STAMP_ENTRY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using IM = Img<C1, 48, 48>;
   using WM = Wmat<C1, C2>;
@@ -391,7 +396,8 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
   unsigned* s_red = reinterpret_cast<unsigned*>(s_misc);
   float* s_stat = s_misc + 32;
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: as an SGPR the tile / row arithmetic that hangs on it runs on the scalar unit
   zero_lds(smem, o_tab, tid);
   zero_lds(a1, IM::BYTES, tid);
   stage_weights<C1, C2>(p.w2, wl, tid);
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
     }
     bq[q] = f;
   }
-  const float bias1 = p.b1[li];
+  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(p.b1 + 4 * g);  // channels 4g .. 4g+3 (conv1_rows)
   const int chunk = g & 1, hi = g >> 1;
   uint4 px[2];
   auto load_px = [&](int n) {
@@ -418,8 +424,10 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
   };
   if ((int)blockIdx.x < p.N) load_px(blockIdx.x);
   __syncthreads();
+  STAMP_DECL;
 
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    STAMP(15);
     // ---- statistics, table, bf16 image (as conv1_fwd_kernel)
     unsigned su = 0, sq = 0;
 #pragma unroll
@@ -472,10 +480,13 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
       }
     }
     __syncthreads();
+    STAMP(0);
     if (n + (int)gridDim.x < p.N) load_px(n + gridDim.x);  // the next frame's bytes, under both convolutions
     // ---- conv1 -> conv2's haloed input image
     conv1_rows(img, [&](int q) { return bq[q]; }, bias1, 0, 48, 0, a1, IM::at(0, 0), IM::RS, IM::PS, nullptr, wv, g, li);
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
     // ---- conv2 in two halves of 12 pooled rows (the staging area holds one)
     for (int half = 0; half < 2; ++half) {
       constexpr int MT = 3, UNITS = HH * 6 / MT;  // 72 m tiles of 2 rows x 8 columns per half
@@ -524,14 +535,19 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
           }
         }
       }
+      STAMP(3);
       __syncthreads();
+      STAMP(4);
       uint4* da = reinterpret_cast<uint4*>(p.a2 + ((long)n * HO + half * HH) * WO * C2);
       for (int q = tid; q < HH * WO * C2 * 2 / 16; q += NT) da[q] = reinterpret_cast<const uint4*>(oa)[q];
       uint4* di = reinterpret_cast<uint4*>(p.i2 + ((long)n * HO + half * HH) * WO * C2);
       for (int q = tid; q < HH * WO * C2 / 16; q += NT) di[q] = reinterpret_cast<const uint4*>(oi)[q];
+      STAMP(5);
       __syncthreads();  // the second half's (and the next frame's) epilogues rewrite the staging area
+      STAMP(6);
     }
   }
+  STAMP_FLUSH();
 }
 
 constexpr int CONV12_LDS = round_up(98 * RS0 * 2, 16) + (256 + 64) * 4 + Img<C1, 48, 48>::BYTES + round_up(Wmat<C1, C2>::BYTES, 16) +

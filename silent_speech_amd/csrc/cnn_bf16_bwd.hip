@@ -22,6 +22,8 @@ extern int ss_cnn_max_wgs;  // roi_cnn.hip: test hook, workgroups per launch (0 
 namespace {
 using namespace c5;
 
+STAMP_TABLE(ss_debug_stamps_c5_bwd)
+
 __device__ __forceinline__ void zero_lds(void* base, int bytes, int tid) {
   uint4* p = reinterpret_cast<uint4*>(base);
   for (int q = tid; q < bytes / 16; q += NT) p[q] = uint4{0u, 0u, 0u, 0u};
@@ -143,6 +145,7 @@ template <int CIN, int COUT, int H, int W, bool LAST, int BH, int WCO, int WCI, 
 __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   static_assert(WCO * WCI * WK == NW && H % BH == 0, "wave split");
   static_assert(!RC || (CIN == C1 && H == 48 && W == 48 && !LAST), "recompute form: layer 2");
+  STAMP_ENTRY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using IA = Img<CIN, BH, W, true>;
   constexpr int PSD = COUT + 8, RSD = W * PSD;           // dense dy band, no halo
@@ -163,9 +166,10 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   bf16_t* bqs = reinterpret_cast<bf16_t*>(s_xn + 256);
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  // (wv as an SGPR -- readfirstlane, as in the forward kernels -- was measured here: the last layer's weight gradient 0.32 -> 0.47 ms)
   const int q4 = li >> 2, p4 = li & 3;
   const int wco = wv % WCO, wci = (wv / WCO) % WCI, wk = wv / (WCO * WCI);
-  float bias1 = 0.f;
+  f32x4 bias1 = {0.f, 0.f, 0.f, 0.f};
   uint4 px[2];
   auto load_px = [&](int n) {
     const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
     if (wv == 0)
 #pragma unroll
       for (int q = 0; q < 12; ++q) *reinterpret_cast<s16x8*>(bqs + (q * 64 + lane) * 8) = conv1_bfrag(p.w1, q, g, li);
-    bias1 = p.b1[li];
+    bias1 = *reinterpret_cast<const f32x4*>(p.b1 + 4 * g);  // channels 4g .. 4g+3 (conv1_rows)
     if ((int)blockIdx.x < p.N) load_px(blockIdx.x);
   }
   static_assert((COUT + 8) * 2 <= ZB, "zero pixel");
@@ -212,7 +216,9 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
     if (!RC) pa.issue(p.a_in + (long)n * H * W * CIN, y0 - 1, tid);
   };
   if ((int)blockIdx.x < p.N) issue(blockIdx.x, 0);
+  STAMP_DECL;
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    STAMP(15);
     if (RC) {  // the frame's normalised image (statistics from the forward pass), once per frame
       if (tid < 256) {
         const float rr = (float)tid / 255.0f;
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
       if (n + (int)gridDim.x < p.N) load_px(n + gridDim.x);
       __syncthreads();
     }
+    STAMP(0);
     for (int y0 = 0; y0 < H; y0 += BH) {
       if (LAST) {
         if (tid < p.E) s_dz[tid] = pm.dz;
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
       } else {
         pe.commit(dyi, 0, RSD, PSD, y0, tid);
       }
+      STAMP(1);
       if (RC) {
         // a1 rows y0-1 .. y0+BH of the band: recomputed inside the frame, zero outside it
         const int yp0 = y0 > 0 ? y0 - 1 : 0, yp1 = y0 + BH + 1 < H ? y0 + BH + 1 : H;
@@ -268,12 +276,15 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
       } else {
         pa.commit(ai, -1, tid);
       }
+      STAMP(2);
       __syncthreads();
+      STAMP(3);
       {  // the next unit's loads fly under the MFMAs below
         const bool last_band = y0 + BH >= H;
         const int nn = last_band ? n + (int)gridDim.x : n;
         if (nn < p.N) issue(nn, last_band ? 0 : y0 + BH);
       }
+      STAMP(4);
       for (int ch = wk; ch < NCH; ch += WK) {
         // this lane's two pixels of the k step: rows q4 and q4 + 4 of its 8-pixel group
         const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;
@@ -302,9 +313,12 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
           }
         }
       }
+      STAMP(5);
       __syncthreads();
+      STAMP(6);
     }
   }
+  STAMP_FLUSH();
   // ---- hand the register-resident gradients over: D row 4 g + r = co, column li = ci.  Always through LDS, in [co][ci][tap]
   // order: (i) the WK waves that share a tile set (K split) are summed there first -- 256 workgroups x 8 waves of float atomics
   // onto the 4.6 k addresses of a small layer serialise at the memory side; (ii) an accumulator register holds elements that lie
@@ -383,6 +397,7 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
   float* s_dz = reinterpret_cast<float*>(smem + o_out + (STAGE ? BH * W * CIN * 2 : 0));  // [64]
   float* s_dfeat = s_dz + 64;                                                   // [96]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  // (wv as an SGPR -- readfirstlane, as in the forward kernels -- was measured here: the last layer's weight gradient 0.32 -> 0.47 ms)
 
   zero_lds(dyi, ID::BYTES, tid);
   for (int q = tid; q < CIN * WM::KP; q += NT) {
@@ -500,6 +515,7 @@ __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
   float* s_red = s_xn + 256;                                // [16 c][16]: 9 weights + 1 bias per channel
   uint8_t* ibl = reinterpret_cast<uint8_t*>(s_red + 16 * 16);  // [C1_BR][48][16] recomputed pool winners of the band
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  // (wv as an SGPR -- readfirstlane, as in the forward kernels -- was measured here: the last layer's weight gradient 0.32 -> 0.47 ms)
   const int q4 = li >> 2, p4 = li & 3;
   const bool rc = p.i1 == nullptr;
   static_assert(C1_XS == RS0, "conv1_rows reads the image with row stride RS0");
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
       const bool last_band = r0 + C1_BR >= HP;
       if (rc) {  // conv1 again for the band's row pairs: only the pool winners are kept
         __syncthreads();  // the image is complete (first band) / the previous band's bytes have been consumed
-        conv1_rows(imgE, [&](int q) { return bq[q]; }, bias1, r0, r0 + C1_BR, r0, nullptr, 0, 0, 0, ibl, wv, g, li);
+        conv1_winners(imgE, [&](int q) { return bq[q]; }, bias1, r0, r0 + C1_BR, r0, ibl, wv, g, li);
         __syncthreads();
       }
       // ---- the band's gradients, split by window slot
@@ -676,6 +692,7 @@ constexpr int CONV2_DGRAD_W1_LDS = F_O_XN + 256 * 4 + 256 * 4 + F_BH * 48 * C1;
 static_assert(CONV2_DGRAD_W1_LDS <= 160 * 1024, "LDS");
 
 __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Params p) {
+  STAMP_ENTRY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HP = 48, H = 48, W = 48;
   bf16_t* dyi = reinterpret_cast<bf16_t*>(smem);
@@ -688,12 +705,13 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
   float* s_red = s_xn + 256;
   uint8_t* ibl = reinterpret_cast<uint8_t*>(s_red + 256);            // [8][48][16] recomputed pool winners of the band
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  // (wv as an SGPR -- readfirstlane, as in the forward kernels -- was measured here: the last layer's weight gradient 0.32 -> 0.47 ms)
   const int q4 = li >> 2, p4 = li & 3;
 
   s16x8 bq[12];
 #pragma unroll
   for (int q = 0; q < 12; ++q) bq[q] = conv1_bfrag(p.w1, q, g, li);
-  const float bias1 = p.b1[li];
+  const float bias_li = p.b1[li];
   zero_lds(dyi, F_ID::BYTES, tid);
   zero_lds(imgE, 2 * C1_IMG * 2, tid);
   for (int q = tid; q < C1 * F_WM::KP; q += NT) {  // flipped, transposed conv2 weights (conv_dgrad_kernel)
@@ -720,10 +738,12 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
     issue(blockIdx.x, 0);
   }
   __syncthreads();
+  STAMP_DECL;
 
   constexpr int MT = 3, MTILES = F_BH * W / 16;  // 24 m tiles per band: one unit of 3 per wave
   static_assert(MTILES / MT == NW, "one d a1 unit per wave");
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    STAMP(15);
     // ---- the frame's normalised image, twice (conv1_wgrad_kernel)
     if (tid < 256) {
       const float rr = (float)tid / 255.0f;
@@ -747,10 +767,13 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
           }
       }
     }
+    STAMP(0);
     for (int y0 = 0; y0 < H; y0 += F_BH) {
       const bool last_band = y0 + F_BH >= H;
       pe.commit(dyi, F_ID::at(-1, 0), F_ID::RS, F_ID::PS, y0 - 1, tid);
+      STAMP(1);
       __syncthreads();  // dy band and (first band) the frame images are complete
+      STAMP(2);
       {
         const int nn = last_band ? n + (int)gridDim.x : n;
         if (nn < p.N) {
@@ -782,9 +805,12 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
 #pragma unroll
           for (int r = 0; r < 4; ++r) oa[(16 * (wv * MT + a) + 4 * g + r) * C1 + li] = to_bf16(acc[a][r]);
       }
+      STAMP(3);
       // ---- conv1 again for the band's 8 row pairs (one per wave): only the pool winners are kept
-      conv1_rows(imgE, [&](int q) { return bq[q]; }, bias1, y0, y0 + F_BH, y0, nullptr, 0, 0, 0, ibl, wv, g, li);
+      conv1_winners(imgE, [&](int q) { return bq[q]; }, bias_li, y0, y0 + F_BH, y0, ibl, wv, g, li);
+      STAMP(4);
       __syncthreads();
+      STAMP(5);
       if (p.da1) {
         uint4* dst = reinterpret_cast<uint4*>(p.da1 + ((long)n * H + y0) * W * C1);
         for (int q = tid; q < F_BH * W * C1 * 2 / 16; q += NT) dst[q] = reinterpret_cast<const uint4*>(oa)[q];
@@ -812,7 +838,9 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
           for (int e = 0; e < 4; ++e)
             *reinterpret_cast<uint4*>(ae + e * F_AE + pp * C1 + 8 * half) = uint4{o[e][0], o[e][1], o[e][2], o[e][3]};
         }
+        STAMP(6);
         __syncthreads();
+        STAMP(7);
         const int r0 = y0 + hb * F_HB;
         for (int ch = wv; ch < F_HB * HP / 32; ch += NW) {
           const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;
@@ -825,10 +853,13 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc1[e] = mfma_bf16(tr_pair(a0 + e * F_AE, a1 + e * F_AE), fb, acc1[e]);
         }
+        STAMP(8);
         __syncthreads();  // the next half / band rewrites ae, oa, ibl and the dy band
+        STAMP(9);
       }
     }
   }
+  STAMP_FLUSH();
   // ---- fold the slots into the 3 x 3 taps, the waves through LDS, one atomic per element (conv1_wgrad_kernel)
   for (int q = tid; q < 16 * 16; q += NT) s_red[q] = 0.f;
   __syncthreads();

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBfParams p) {
   constexpr int BK = SRC16 ? 64 : 32;
   using T = Tile<BK>;
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];  // A0 B0 A1 B1
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int batch = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
   float* C = p.C + batch * p.sc;

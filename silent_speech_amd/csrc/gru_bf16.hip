@@ -13,6 +13,9 @@
 // Packed-sequence semantics by masking, exactly as gru.hip: forward direction t = s, reverse direction t = T-1-s at step
 // s; a step with t >= len[b] leaves the state (and emits zeros); the reverse direction therefore starts at len-1.
 #include "bf16_common.h"
+namespace {
+STAMP_TABLE(ss_debug_stamps_gru_bf16)
+}
 #include "gru_bf16_pers.h"
 
 namespace {

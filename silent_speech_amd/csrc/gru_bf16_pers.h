@@ -49,6 +49,25 @@ __device__ __forceinline__ bool sweep_pairs(rsrc_t rs, int pair0, int stride, un
   }
 }
 
+// A sweep in two halves: issue the first pass, do something else while its loads fly, then look at the tags (and fall back to the
+// spinning form when a partner has not published yet)
+template <int N>
+__device__ __forceinline__ void sweep_issue(rsrc_t rs, int pair0, int stride, u32x4 (&raw)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (pair0 + stride * k) * 16, 0, AUX_SC1);
+}
+template <int N>
+__device__ __forceinline__ bool sweep_check(const u32x4 (&raw)[N], unsigned tag, unsigned (&v)[2 * N]) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    v[2 * k] = raw[k][0];
+    v[2 * k + 1] = raw[k][2];
+    ok &= raw[k][1] == tag && raw[k][3] == tag;
+  }
+  return __all(ok);
+}
+
 __device__ __forceinline__ void store_pair_raw(rsrc_t rs, int pair, unsigned tag, unsigned p0, unsigned p1, bool same_xcd) {
   const u32x4 d = {p0, tag, p1, tag};
   if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(d, rs, pair * 16, 0, 0);
@@ -80,7 +99,7 @@ __device__ __forceinline__ void pers_ids(int P, int& groups, int& group, int& pa
 template <int H>
 __global__ __launch_bounds__(256) void gru_pers_fwd_kernel(PersFwdParams p, unsigned* sync, u64* xid, u64* hx) {
   constexpr int P = H / PUNITS, KS = H / 32;
-  constexpr int LDH = H + 8;                    // panel row stride (bf16): rows 4 banks apart
+  constexpr int LDH = H + 16;                   // panel row stride (bf16) == 16 (mod 32): conflict-free under ds_read_b128's lane groups
   constexpr int NGP = H / 64;                   // granule pairs per thread in a sweep of the 16 x H panel (4 H / 256)
   __shared__ __attribute__((aligned(16))) bf16_t hpan[PSLICE * LDH];
   __shared__ unsigned s_gen;
@@ -125,7 +144,35 @@ __global__ __launch_bounds__(256) void gru_pers_fwd_kernel(PersFwdParams p, unsi
   const rsrc_t hrs = granule_rsrc(hx, 2L * groups * PSLICE * (H / 2));
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 hp = z4;
+  // The stores of a step (out, its bf16 copies, the dropout draw, the saved gates) are not on the recurrence's critical path but
+  // their issue was: 1 800 of a step's 9 000 cycles (stage timers).  They are kept in registers and issued in the NEXT step,
+  // between the request of the sweep's first pass and the look at its tags.
+  f32x4 st_o = z4, st_r = z4, st_z = z4, st_n = z4, st_q = z4;
+  long st_row = 0;
+  bool st_valid = false, st_have = false;
+  auto flush_stores = [&]() {
+    if (!st_have || !clip_ok) return;
+    const f32x4 o = st_o;
+    const uint2 ob = pack_bf16x4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<f32x4*>(p.out + st_row * (2 * H) + dir * H + u0) = o;
+    if (p.out_bf) *reinterpret_cast<uint2*>(p.out_bf + st_row * (2 * H) + dir * H + u0) = ob;
+    if (p.out_drop_bf) {
+      f32x4 od = o;
+      if (p.drop_p > 0.f) od *= drop_scale4((st_row * (2 * H) + dir * H + u0) >> 2, p.drop_p, p.seed, p.offset);
+      *reinterpret_cast<uint2*>(p.out_drop_bf + st_row * (2 * H) + dir * H + u0) = pack_bf16x4(od[0], od[1], od[2], od[3]);
+    }
+    if (p.save && st_valid) {
+      float* sv = p.save + ((long)dir * N + st_row) * (4 * H) + u0;
+      *reinterpret_cast<f32x4*>(sv) = st_r;
+      *reinterpret_cast<f32x4*>(sv + H) = st_z;
+      *reinterpret_cast<f32x4*>(sv + 2 * H) = st_n;
+      *reinterpret_cast<f32x4*>(sv + 3 * H) = st_q;
+    }
+  };
+  STAMP_ENTRY;
+  STAMP_DECL;
   for (int s = 0; s < T; ++s) {
+    STAMP(15);
     const int t = dir ? (T - 1 - s) : s;
     const long row = (long)clip * T + t;
     const bool valid = t < len;
@@ -141,26 +188,31 @@ __global__ __launch_bounds__(256) void gru_pers_fwd_kernel(PersFwdParams p, unsi
       // the full previous state of the slice: every thread sweeps NGP granule pairs (4 units of one clip each) into the panel
       unsigned hv[2 * NGP];
       const int pr = (((s - 1) & 1) * groups + group) * (PSLICE * H / 4) + tid;
-      if (!dead) dead = !sweep_pairs<NGP>(hrs, pr, 256, base + (unsigned)s, hv, &sync[2], lane);
+      u32x4 raw[NGP];
+      if (!dead) sweep_issue<NGP>(hrs, pr, 256, raw);
+      flush_stores();  // the previous step's, under the sweep's first pass
+      if (!dead && !sweep_check<NGP>(raw, base + (unsigned)s, hv)) dead = !sweep_pairs<NGP>(hrs, pr, 256, base + (unsigned)s, hv, &sync[2], lane);
+      STAMP(0);
 #pragma unroll
       for (int k = 0; k < NGP; ++k) {
         const int q = tid + 256 * k;  // clip = q / (H/4), units 4 (q % (H/4)) ..
         *reinterpret_cast<uint2*>(&hpan[(q / (H / 4)) * LDH + 4 * (q % (H / 4))]) = uint2{hv[2 * k], hv[2 * k + 1]};
       }
       __syncthreads();
+      STAMP(1);
+      s16x8 fb[KS];  // every B fragment of the step requested before the first MFMA (one LDS latency instead of four)
 #pragma unroll
-      for (int kb = 0; kb < KS; kb += 4) {
-        s16x8 fb[4];
+      for (int ks = 0; ks < KS; ++ks) fb[ks] = *reinterpret_cast<const s16x8*>(&hpan[li * LDH + 32 * ks + 8 * g]);
+      SS_SCHED_FENCE();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) fb[k] = *reinterpret_cast<const s16x8*>(&hpan[li * LDH + 32 * (kb + k) + 8 * g]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          ar = mfma_bf16(fa[0][kb + k], fb[k], ar);
-          az = mfma_bf16(fa[1][kb + k], fb[k], az);
-          an = mfma_bf16(fa[2][kb + k], fb[k], an);
-        }
+      for (int ks = 0; ks < KS; ++ks) {
+        ar = mfma_bf16(fa[0][ks], fb[ks], ar);
+        az = mfma_bf16(fa[1][ks], fb[ks], az);
+        an = mfma_bf16(fa[2][ks], fb[ks], an);
       }
+      SS_SCHED_FENCE();
     }
+    STAMP(2);
     f32x4 r, z, n, o = z4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -174,28 +226,17 @@ __global__ __launch_bounds__(256) void gru_pers_fwd_kernel(PersFwdParams p, unsi
       o = hp;
     }
     if (dead) o = f32x4{NAN_F, NAN_F, NAN_F, NAN_F};
-    const uint2 ob = pack_bf16x4(o[0], o[1], o[2], o[3]);
     if (s + 1 < T) {  // publish (padding clips too: the partners sweep whole panels)
+      const uint2 ob = pack_bf16x4(o[0], o[1], o[2], o[3]);
       const int pw = ((s & 1) * groups + group) * (PSLICE * H / 4) + li * (H / 4) + (u0 >> 2);
       store_pair_raw(hrs, pw, base + (unsigned)s + 1u, ob.x, ob.y, same_xcd);
     }
-    if (clip_ok) {
-      *reinterpret_cast<f32x4*>(p.out + row * (2 * H) + dir * H + u0) = o;
-      if (p.out_bf) *reinterpret_cast<uint2*>(p.out_bf + row * (2 * H) + dir * H + u0) = ob;
-      if (p.out_drop_bf) {
-        f32x4 od = o;
-        if (p.drop_p > 0.f) od *= drop_scale4((row * (2 * H) + dir * H + u0) >> 2, p.drop_p, p.seed, p.offset);
-        *reinterpret_cast<uint2*>(p.out_drop_bf + row * (2 * H) + dir * H + u0) = pack_bf16x4(od[0], od[1], od[2], od[3]);
-      }
-      if (p.save && valid) {
-        float* sv = p.save + ((long)dir * N + row) * (4 * H) + u0;
-        *reinterpret_cast<f32x4*>(sv) = r;
-        *reinterpret_cast<f32x4*>(sv + H) = z;
-        *reinterpret_cast<f32x4*>(sv + 2 * H) = n;
-        *reinterpret_cast<f32x4*>(sv + 3 * H) = an;
-      }
-    }
+    STAMP(3);
+    st_o = o; st_r = r; st_z = z; st_n = n; st_q = an; st_row = row; st_valid = valid; st_have = true;
+    STAMP(4);
   }
+  flush_stores();
+  STAMP_FLUSH();
   finish_launch(sync, gen);
 }
 
@@ -268,15 +309,18 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 dh = z4;
   f32x4 sb_r = z4, sb_z = z4, sb_n = z4, sb_q = z4;  // bias-gradient sums of this lane's (clip, 4 units)
-  f32x4 go, sr, sz, sn, sq, hprev;
+  f32x4 go, gsc, sr, sz, sn, sq, hprev;
   auto load_inputs = [&](int s) {
     const int t = dir ? s : (T - 1 - s);
     const int tp = dir ? t + 1 : t - 1;
     go = sr = sz = sn = sq = hprev = z4;
+    gsc = f32x4{1.f, 1.f, 1.f, 1.f};
     if (t < len) {
       const long row = (long)clip * T + t;
       go = *reinterpret_cast<const f32x4*>(p.d_out + row * (2 * H) + dir * H + u0);
-      if (p.drop_p > 0.f) go *= drop_scale4((row * (2 * H) + dir * H + u0) >> 2, p.drop_p, p.seed, p.offset);
+      // the dropout scale stays beside the raw load: multiplying here made the wave sit through the load's whole latency in
+      // every step of a layer with dropout (2 700 of 12 200 cycles, stage timers)
+      if (p.drop_p > 0.f) gsc = drop_scale4((row * (2 * H) + dir * H + u0) >> 2, p.drop_p, p.seed, p.offset);
       const float* sv = p.save + ((long)dir * N + row) * (4 * H) + u0;
       sr = *reinterpret_cast<const f32x4*>(sv);
       sz = *reinterpret_cast<const f32x4*>(sv + H);
@@ -286,7 +330,10 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
     }
   };
   load_inputs(0);
+  STAMP_ENTRY;
+  STAMP_DECL;
   for (int s = 0; s < T; ++s) {
+    STAMP(15);
     const int t = dir ? s : (T - 1 - s);
     const long row = (long)clip * T + t;
     const bool valid = t < len;
@@ -296,7 +343,7 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
     if (valid) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float d = go[e] + dh[e];
+        const float d = go[e] * gsc[e] + dh[e];
         const float dn = d * (1.0f - sz[e]);
         const float dz = d * (hprev[e] - sn[e]);
         dan[e] = dn * (1.0f - sn[e] * sn[e]);
@@ -314,7 +361,9 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
       *reinterpret_cast<uint2*>(dp) = br_;
       *reinterpret_cast<uint2*>(dp + PUNITS) = bz_;
       *reinterpret_cast<uint2*>(dp + 2 * PUNITS) = bq_;
+      STAMP(5);
       __syncthreads();
+      STAMP(6);
       f32x4 acc[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = z4;
@@ -335,6 +384,7 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
         const uint2 pb = pack_bf16x4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
         store_pair_raw(xrs, dst, base + (unsigned)s + 1u, pb.x, pb.y, same_xcd);
       }
+      STAMP(7);
     }
     sb_r += dar; sb_z += daz; sb_n += dan; sb_q += dqn;
     if (clip_ok) {
@@ -354,12 +404,15 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
       }
     }
     if (last) break;
+    STAMP(8);
     load_inputs(s + 1);
+    STAMP(9);
     // sum the P partials of this part's units: thread -> granule pair tid of the [clip][64] tile (clip tid / 16, units
     // 4 (tid % 16) ..), one per source part
     unsigned xv[2 * P];
     const int xr = ((((s & 1) * groups + group) * P + part) * P) * (PSLICE * PUNITS / 4) + tid;
     if (!dead) dead = !sweep_pairs<P>(xrs, xr, PSLICE * PUNITS / 4, base + (unsigned)s + 1u, xv, &sync[2], lane);
+    STAMP(10);
     {
       f32x4 sm = z4;
 #pragma unroll
@@ -373,7 +426,9 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
     }
     __syncthreads();
     dh = dcarry + *reinterpret_cast<const f32x4*>(&dsum[li * LDS_ + ul]);
+    STAMP(11);
   }
+  STAMP_FLUSH();
   if (p.g_bih[0]) {  // sum over the 16 clips of the slice (the lanes of a row), one atomic per unit and workgroup
     float* gbi = p.g_bih[dir];
     float* gbh = p.g_bhh[dir];

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-stage cycle shares of three config-5 CNN kernels (needs the -DSS_STAMP build: python -m silent_speech_amd.build
+--stamp).  Thread 0 of every workgroup accumulates clock64() deltas between the stamps; cycles per frame = table / frames walked."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("SS_HOTPATH_LIB", os.path.join(ROOT, "silent_speech_amd", "libss_hotpath_stamp.so"))
+from silent_speech_amd import _lib as L  # noqa: E402
+
+N = 7680
+FPW = N // 256
+
+
+def read(fn):
+    buf = np.zeros(512 * 24, np.uint64)
+    assert fn(buf.ctypes.data) == 0
+    return buf.reshape(512, 24).astype(np.float64)[:256, :16]
+
+
+def report(title, t, names, launches):
+    t = t / launches / FPW
+    tot = sum(t[:, k].mean() for k in names)
+    print(f"{title}: {tot:.0f} cycles per frame (stamped stages)")
+    for k, nm in names.items():
+        print(f"   {nm:64s} {t[:, k].mean():8.0f}  {100 * t[:, k].mean() / tot:5.1f} %")
+
+
+def main():
+    lib = L.load()
+    ffwd, fbwd = lib.ss_debug_stamps_c5_fwd, lib.ss_debug_stamps_c5_bwd
+    for f in (ffwd, fbwd):
+        f.argtypes, f.restype = [C.c_void_p], C.c_int
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    R = torch.randint(0, 256, (N, 96, 96), device=dev, dtype=torch.uint8, generator=g)
+    w1, b1 = torch.randn(16, 1, 3, 3, device=dev) / 3, torch.randn(16, device=dev) * 0.1
+    w2, b2 = torch.randn(32, 16, 3, 3, device=dev) / 12, torch.randn(32, device=dev) * 0.1
+    a2 = torch.empty(N, 24, 24, 32, device=dev, dtype=torch.int16)
+    i2 = torch.empty(N, 24, 24, 32, device=dev, dtype=torch.uint8)
+    st = torch.empty(N, 2, device=dev)
+    read(ffwd); read(fbwd)
+    reps = 3
+    for _ in range(reps):
+        L.call("ss_c5_conv12_fwd", R.data_ptr(), N, 1, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), a2.data_ptr(), i2.data_ptr(),
+               st.data_ptr(), L.stream())
+    report("conv12_fwd", read(ffwd), {15: "frame top", 0: "statistics, table, bf16 image (3 barriers inside)", 1: "conv1 rows", 2: "barrier",
+                                      3: "conv2 half: MFMAs + epilogue", 4: "barrier", 5: "copy-out of the half", 6: "barrier"}, reps)
+    da2 = torch.randint(-300, 300, (N, 24, 24, 32), device=dev, dtype=torch.int16)
+    gw2, gb2 = torch.zeros(32, 16, 3, 3, device=dev), torch.zeros(32, device=dev)
+    for _ in range(reps):
+        L.call("ss_c5_conv2_wgrad_rc", R.data_ptr(), st.data_ptr(), 1, w1.data_ptr(), b1.data_ptr(), da2.data_ptr(), i2.data_ptr(), N,
+               gw2.data_ptr(), gb2.data_ptr(), L.stream())
+    report("conv2_wgrad_rc", read(fbwd), {15: "frame top", 0: "frame image (RC)", 1: "dy expand commit", 2: "conv1 rows (RC) / a_in commit", 3: "barrier",
+                                          4: "issue of the next band's loads", 5: "MFMAs", 6: "barrier"}, reps)
+    gw1, gb1 = torch.zeros(16, 1, 3, 3, device=dev), torch.zeros(16, device=dev)
+    for _ in range(reps):
+        L.call("ss_c5_conv2_dgrad_conv1_wgrad", da2.data_ptr(), i2.data_ptr(), N, w2.data_ptr(), R.data_ptr(), st.data_ptr(), 1, w1.data_ptr(),
+               b1.data_ptr(), None, gw1.data_ptr(), gb1.data_ptr(), L.stream())
+    report("conv2_dgrad_conv1_wgrad", read(fbwd), {15: "frame top", 0: "frame images", 1: "dy expand commit", 2: "barrier", 3: "issue + d a1 MFMAs + oa stores",
+                                                   4: "conv1 rows (pool winners)", 5: "barrier", 6: "slot-masked images of a half band", 7: "barrier",
+                                                   8: "conv1-wgrad MFMAs of a half band", 9: "barrier"}, reps)
+
+
+if __name__ == "__main__":
+    main()
