@@ -12,8 +12,17 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   float acc = 0.f;
   const long n4 = n >> 2;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
-    f32x4 v = x4[q];
+  // four 16-byte loads in flight per thread (a dependent chain of single loads made the 28 MB bucket of config 5 a 28 us kernel:
+  // 1 TB/s; one launch's atomics -- one per workgroup on one address, ~12 ns each -- bound the workgroup count from above)
+  const long stride = (long)gridDim.x * 256;
+  long q = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; q + 3 * stride < n4; q += 4 * stride) {
+    const f32x4 v0 = x4[q], v1 = x4[q + stride], v2 = x4[q + 2 * stride], v3 = x4[q + 3 * stride];
+    acc += (v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3]) + (v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2] + v1[3] * v1[3]) +
+           (v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2] + v2[3] * v2[3]) + (v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2] + v3[3] * v3[3]);
+  }
+  for (; q < n4; q += stride) {
+    const f32x4 v = x4[q];
     acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -167,7 +176,7 @@ extern "C" int ss_sumsq_f32(const float* x, long n, float* sumsq, ss_stream_t st
   SS_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, SS_ERR_ARG);
   // every block ends in one float atomic on the same word (~11 ns each, serialised): 128 blocks, not 1024
   int blocks = (int)(((n >> 2) + 255) / 256);
-  blocks = blocks < 1 ? 1 : (blocks > 128 ? 128 : blocks);
+  blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, sumsq);
   return ss_launch_status();
 }

@@ -91,6 +91,7 @@ class WorkspaceBf16:
         self.ev_fork = torch.cuda.Event() if train else None
         self.ev_join = torch.cuda.Event() if train else None
         self.ev_cnn_fwd = torch.cuda.Event() if train else None  # recorded after the ROI-CNN forward (Trainer's micro-batch stagger)
+        self.ev_zero = torch.cuda.Event() if train else None     # the cleared d layer_in destinations (side stream)
         N, H = B * T, cfg.hidden
         f32 = dict(device=device, dtype=torch.float32)
         u8 = dict(device=device, dtype=torch.uint8)
@@ -225,13 +226,27 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
            ws.mid.data_ptr(), d_logits.data_ptr(), B, T, 2 * H, MID, Cn, p_drop, seed, 7 << 40, ws.d_mid.data_ptr(),
            ws.d_out.data_ptr(), G["head.0.weight"].data_ptr(), G["head.0.bias"].data_ptr(), G["pool.score.weight"].data_ptr(),
            G["pool.score.bias"].data_ptr(), ws.tail_part.data_ptr(), s)
-    for k_, name_ in enumerate(("head.0.weight", "head.0.bias", "pool.score.weight")):
-        L.call("ss_colsum_f32", _addr(ws.tail_part, k_ * 2 * H), B, 2 * H, 3 * 2 * H, G[name_].data_ptr(), s)
-    gemm_f32(0, 0, Cn, MID, B, d_logits.data_ptr(), Cn, ws.mid_drop.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
-             accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
-    gemm_f32(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(), 2 * H,
-             accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
-    zero_buffers(ws.d_lower[1:] + ([ws.dZ] if cfg.use_roi else []))
+    def head_grads():
+        # the atomically summed destinations of the d layer_in GEMMs first (the top layer's GEMM waits for them), then what only
+        # feeds parameter gradients of the head: column sums of the rows the tail kernel left per clip, the two Linear weight
+        # gradients (f32, K = B: latency-bound launches that leave the chip empty -- beside the top layer's BPTT kernel they are free)
+        zero_buffers(ws.d_lower[1:] + ([ws.dZ] if cfg.use_roi else []))
+        ws.ev_zero.record()
+        for k_, name_ in enumerate(("head.0.weight", "head.0.bias", "pool.score.weight")):
+            L.call("ss_colsum_f32", _addr(ws.tail_part, k_ * 2 * H), B, 2 * H, 3 * 2 * H, G[name_].data_ptr(), L.stream())
+        gemm_f32(0, 0, Cn, MID, B, d_logits.data_ptr(), Cn, ws.mid_drop.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
+                 accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
+        gemm_f32(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(), 2 * H,
+                 accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
+
+    if USE_SIDE_STREAM:
+        ws.ev_fork.record()
+        with torch.cuda.stream(ws.side):
+            ws.side.wait_event(ws.ev_fork)
+            head_grads()
+    else:
+        head_grads()
+    zero_waited = False
     use_drop = train and cfg.gru_dropout > 0.0
     for l in range(cfg.gru_layers - 1, -1, -1):
         K = cfg.in_dim if l == 0 else 2 * H
@@ -279,6 +294,9 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
             else:
                 zero_buffers([d_X])
                 dst, ld_dst, c0 = d_X.data_ptr(), cfg.x_dim, 0
+            if USE_SIDE_STREAM and not zero_waited:  # once per backward pass: every cleared buffer is behind the same event
+                torch.cuda.current_stream().wait_event(ws.ev_zero)
+                zero_waited = True
             gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(ws.wih[l], c0), Kp, dst, ld_dst, accumulate=True, atomic=True, batch=2,
                  strides=(N * 4 * H, 3 * H * Kp, 0, 0), tag="gemm_bf16_dX")
         if USE_SIDE_STREAM:
