@@ -267,18 +267,26 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NTL; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // operand fragments one k step ahead of the MFMAs (two register sets, the loop is fully unrolled): left alone hipcc reads a
+      // step's fragments, waits, multiplies -- an LDS latency per k step that the SIMD's other wave only partly covers
+      s16x8 fa[2][MT], fb[2][NTL];
+      auto read_step = [&](int s, s16x8 (&xa)[MT], s16x8 (&xb)[NTL]) {
+        const int off = (CIN >= 32) ? koff<IM>(s, 0) : (hi ? koff<IM>(s, 1) : koff<IM>(s, 0));
+#pragma unroll
+        for (int a = 0; a < MT; ++a) xa[a] = lds_frag(img + base[a] + off);
+#pragma unroll
+        for (int b = 0; b < NTL; ++b) xb[b] = lds_frag(wl + (16 * (ng * NTL + b) + li) * WM::LD + 32 * s + 8 * g);
+      };
+      read_step(0, fa[0], fb[0]);
 #pragma unroll
       for (int s = 0; s < WM::KSTEPS; ++s) {
-        const int off = (CIN >= 32) ? koff<IM>(s, 0) : (hi ? koff<IM>(s, 1) : koff<IM>(s, 0));
-        s16x8 fa[MT], fb[NTL];
-#pragma unroll
-        for (int a = 0; a < MT; ++a) fa[a] = lds_frag(img + base[a] + off);
-#pragma unroll
-        for (int b = 0; b < NTL; ++b) fb[b] = lds_frag(wl + (16 * (ng * NTL + b) + li) * WM::LD + 32 * s + 8 * g);
+        if (s + 1 < WM::KSTEPS) read_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+        SS_SCHED_FENCE();
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
-          for (int b = 0; b < NTL; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
+          for (int b = 0; b < NTL; ++b) acc[a][b] = mfma_bf16(fa[s & 1][a], fb[s & 1][b], acc[a][b]);
+        SS_SCHED_FENCE();
       }
       // ---- epilogue
 #pragma unroll

@@ -278,16 +278,20 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   const long dir_off = (long)dir * p.B * T;
   const rsrc_t xrs = granule_rsrc(xg, 2L * pairs * P * SLICE * H);
   // inputs of one step (owner waves): loaded a step ahead, while the exchange of the current step is in flight
-  f32x4 go, sr, sz, sn, sq, hprev;
+  f32x4 go, gsc, sr, sz, sn, sq, hprev;
   auto load_inputs = [&](int s) {
     const int t = dir ? s : (T - 1 - s);
     const int tp = dir ? t + 1 : t - 1;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     go = sr = sz = sn = sq = hprev = zero;
+    gsc = f32x4{1.f, 1.f, 1.f, 1.f};
     if (owner && t < len) {
       const long frame = (long)clip * T + t;
       go = *reinterpret_cast<const f32x4*>(p.d_out + frame * (2 * H) + dir * H + j0);
-      if (p.drop_p > 0.f) go *= drop_scale4((frame * (2 * H) + dir * H + j0) >> 2, p.drop_p, p.drop_seed, p.drop_off);
+      // the dropout scale stays beside the raw load and is applied where the gradient is used, a step later: multiplying here
+      // made the wave wait for the load it had just issued -- a memory latency in front of every sweep of a layer with dropout
+      // (found with the stage timers of the bf16 kernel, which had inherited the line)
+      if (p.drop_p > 0.f) gsc = drop_scale4((frame * (2 * H) + dir * H + j0) >> 2, p.drop_p, p.drop_seed, p.drop_off);
       const float* sp = p.save + (dir_off + frame) * (4 * H) + j0;
       sr = *reinterpret_cast<const f32x4*>(sp);
       sz = *reinterpret_cast<const f32x4*>(sp + H);
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
       if (valid) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float d = go[e] + dh[e];
+          const float d = go[e] * gsc[e] + dh[e];
           const float dn = d * (1.0f - sz[e]);
           const float dz = d * (hprev[e] - sn[e]);
           dan[e] = dn * (1.0f - sn[e] * sn[e]);
