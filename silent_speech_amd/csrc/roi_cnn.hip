@@ -136,6 +136,10 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
     }
   };
   if ((int)blockIdx.x < p.N) load_frame(blockIdx.x);
+  // (Round 3 experiment: the second workgroup of every CU started 16 k / 32 k / 49 k cycles late, so that its vector-heavy stages
+  // -- statistics, conv1 -- would meet the first one's MFMA-heavy ones -- conv2, conv3 -- instead of its own kind: 471.8 / 469.7 /
+  // 473.2 us per launch against 462.6, i.e. the sleep itself and nothing else.  The two workgroups of a CU do not get in each
+  // other's way whatever their phase: each is bound by its own chain of reads, MFMAs and barriers, not by a shared pipe.)
   STAMP_DECL;
 
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {

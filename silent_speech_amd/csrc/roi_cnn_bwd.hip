@@ -49,11 +49,12 @@ struct BwdLds {
   // phase 2: dy2 | xh | i1
   static constexpr int o_ph = 8 * G::P1;
   static constexpr int o_dy3h = o_ph + 16 * G::P2;
-  // dy3 is pixel-major with a pixel stride of DS = 28 floats (24 channels + 4 of padding): S2 reads 16 consecutive pixels per
-  // ds_read_b128 pass, and 96-byte pixels would put them on 4 of the 8 bank groups (4-way conflicts: S2 was LDS-bound, 8.2 k
-  // cycles for 6.9 k of MFMAs); 112 bytes spread them over all 8 (the 2-way minimum of a 16-lane b128 pass).  Phase 1 is the
-  // smaller of the two phases, so the padding costs no LDS
-  static constexpr int DS = 28;
+  // dy3 is pixel-major, pixel stride DS floats.  S2 reads the 16 pixels of a row tile with one ds_read_b128 (channels 4g .. 4g+3)
+  // and one ds_read_b64 (channels 16+2g, 17+2g) per lane.  The hardware serves a b128 read in groups of 16 lanes that are pixels
+  // 0-3 and 12-15 at chunk g with pixels 4-11 at chunk g + 1 (MI355X_MICROARCH.md, LDS table): conflict-free iff DS/4 == 2 (mod 4),
+  // i.e. 24 floats, no padding (round 2 had reasoned with 16 consecutive lanes and padded to 28: 2-way on the b128 reads,
+  // conflict-free on the b64 ones; A/B on one box: 716.6 -> 715.0 us per launch -- S2 is not LDS-bound any more either way)
+  static constexpr int DS = 24;
   static constexpr int o_da2m = o_dy3h + DS * G::P2;
   static constexpr int o_i2b = o_da2m + 16 * G::P;
   static constexpr int end1a = (o_i2b + 4 * G::P + 3) & ~3;
@@ -110,7 +111,7 @@ struct CnnBwdParams {
 // tile 2 = (tap b, n 8..23); the ninth tap takes a full tile and a half-empty one.  The four k-quarter waves of each half of
 // the workgroup own taps {0..3} + (tap 8, n 0..15) resp. {4..7} + (tap 8, n 16..23): seven tiles either way.
 // dy3 is pixel-major [haloed pixel][24]: byte offset of tap (ky, kx) relative to the lane base at (y, x) of the haloed image
-constexpr int DY3_STRIDE = 28;  // == BwdLds::DS (asserted in the kernel)
+constexpr int DY3_STRIDE = 24;  // == BwdLds::DS (asserted in the kernel)
 template <int S2>
 __device__ constexpr int s1_off(int tap) { return ((2 - tap / 3) * S2 + (2 - tap % 3)) * DY3_STRIDE; }
 
