@@ -80,3 +80,27 @@ def test_shard_range_partitions():
         assert got[0][0] == 0 and got[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
     assert [hi - lo for lo, hi in (shard_range(2048, r, 8) for r in range(8))] == [256] * 8
+
+
+def test_host_side_size_queries_need_no_gpu():
+    """The size queries of the ABI are host code: the six stash sizes of every ROI shape the CNN kernels are built for, and the
+    exchange workspace of the persistent recurrences (0 = the shape stays on the other form)."""
+    import ctypes as C
+
+    from silent_speech_amd import _lib
+
+    lib = _lib.load()
+    for H, W in ((64, 64), (48, 96), (32, 32)):
+        a1, a2, i1, i2, m3, feat = _lib.cnn_stash_sizes(H, W)
+        assert a1 >= 8 * (H // 2 + 2) * (W // 2 + 2) and a2 >= 16 * (H // 4 + 2) * (W // 4 + 2)
+        assert (i1, i2, m3) == (8 * (H // 2) * (W // 2), 16 * (H // 4) * (W // 4), 32 * (H // 4) * (W // 4)) and feat >= 50
+    with pytest.raises(RuntimeError):
+        _lib.cnn_stash_sizes(40, 40)
+    n = C.c_long(-1)
+    assert lib.ss_gru_bf16_sync_bytes(256, 30, 512, C.byref(n)) == 0 and n.value > 0          # persistent bf16 recurrence
+    big = n.value
+    assert lib.ss_gru_bf16_sync_bytes(2048, 30, 512, C.byref(n)) == 0 and n.value == big       # clip chunks reuse one area
+    assert lib.ss_gru_bf16_sync_bytes(256, 30, 1024, C.byref(n)) == 0 and n.value == 0         # W_hh no longer fits the registers
+    assert lib.ss_gru_bf16_sync_bytes(256, 2000, 512, C.byref(n)) == 0 and n.value == 0        # step tags are 10 bits
+    assert lib.ss_gru_bf16_sync_bytes(0, 30, 512, C.byref(n)) != 0
+    assert _lib.gru_sync_bytes(256, 30, 192) > 0 and _lib.gru_sync_bytes(4096, 60, 192) == 0   # f32: one CU per slice for big batches
