@@ -155,7 +155,6 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   bf16_t* dyi = reinterpret_cast<bf16_t*>(smem);
   bf16_t* ai = reinterpret_cast<bf16_t*>(smem + DY_BYTES);
   constexpr int ZB = 256;  // a pixel's worth of zeros (COUT <= 96 channels + the lane's piece): what pixels past the band read
-  bf16_t* zeros = reinterpret_cast<bf16_t*>(smem + DY_BYTES + IA::BYTES);
   float* s_dz = reinterpret_cast<float*>(smem + DY_BYTES + IA::BYTES + ZB);  // [64]
   float* s_dfeat = s_dz + 64;                                                // [COUT]
   float* s_feat = s_dfeat + 96;                                              // [COUT]
@@ -206,6 +205,31 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   for (int k = 0; k < FCN; ++k) fcw[k] = 0.f;
   __syncthreads();
 
+  // This lane's operand addresses of its k steps (two pixels each: rows q4 and q4 + 4 of the lane's 8-pixel group) depend on
+  // nothing but the lane and the k step -- the dy and input images are band-local -- so they are made ONCE: the loop below had
+  // ~110 vector instructions of pixel -> (row, column) -> address arithmetic per k step beside its 20 - 30 MFMAs, and these
+  // kernels are bound by the vector issue port
+  // (only where a wave has few k steps per band -- layer 2: three; with nine (layer 3) or five (layer 4) offset sets the register
+  // allocation spilled)
+  constexpr int NCHW = (NCH + WK - 1) / WK;
+  constexpr bool PRE = RC && NCHW <= 3;
+  const bf16_t* lds_b = reinterpret_cast<const bf16_t*>(smem);
+  const bf16_t* zeros = reinterpret_cast<const bf16_t*>(smem + DY_BYTES + IA::BYTES);
+  int o_dy0[PRE ? NCHW : 1], o_dy1[PRE ? NCHW : 1], o_a0[PRE ? NCHW : 1], o_a1[PRE ? NCHW : 1];
+  if constexpr (PRE) {
+    const int z_off = (DY_BYTES + IA::BYTES) / 2, a_off = DY_BYTES / 2;  // element offsets of `zeros` and `ai`
+#pragma unroll
+    for (int k = 0; k < NCHW; ++k) {
+      const int ch = wk + k * WK;
+      const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;
+      const bool in0 = P0 < NPIX, in1 = P1 < NPIX;
+      const int y0l = P0 / W, x0l = P0 % W, y1l = P1 / W, x1l = P1 % W;
+      o_dy0[k] = (in0 ? y0l * RSD + x0l * PSD : z_off) + 4 * p4;
+      o_dy1[k] = (in1 ? y1l * RSD + x1l * PSD : z_off) + 4 * p4;
+      o_a0[k] = a_off + (in0 ? IA::at(y0l - 1, x0l - 1) : IA::at(0, 0)) + 4 * p4;
+      o_a1[k] = a_off + (in1 ? IA::at(y1l - 1, x1l - 1) : IA::at(0, 0)) + 4 * p4;
+    }
+  }
   // units = (frame, band), band-minor; the operands of unit u + 1 are in flight (registers) while unit u is multiplied
   ExpandLoad<COUT, H, W, BH> pe;
   MaskLoad<COUT, H * W> pm;
@@ -285,15 +309,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
         if (nn < p.N) issue(nn, last_band ? 0 : y0 + BH);
       }
       STAMP(4);
-      for (int ch = wk; ch < NCH; ch += WK) {
-        // this lane's two pixels of the k step: rows q4 and q4 + 4 of its 8-pixel group
-        const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;
-        const bool in0 = P0 < NPIX, in1 = P1 < NPIX;
-        const int y0l = P0 / W, x0l = P0 % W, y1l = P1 / W, x1l = P1 % W;
-        const bf16_t* dy0 = in0 ? dyi + y0l * RSD + x0l * PSD + 4 * p4 : zeros + 4 * p4;
-        const bf16_t* dy1 = in1 ? dyi + y1l * RSD + x1l * PSD + 4 * p4 : zeros + 4 * p4;
-        const bf16_t* a0 = ai + (in0 ? IA::at(y0l - 1, x0l - 1) : IA::at(0, 0)) + 4 * p4;
-        const bf16_t* a1 = ai + (in1 ? IA::at(y1l - 1, x1l - 1) : IA::at(0, 0)) + 4 * p4;
+      auto k_step = [&](const bf16_t* dy0, const bf16_t* dy1, const bf16_t* a0, const bf16_t* a1) {
         s16x8 fa[NCO];
 #pragma unroll
         for (int a = 0; a < NCO; ++a) {
@@ -311,6 +327,22 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
 #pragma unroll
             for (int a = 0; a < NCO; ++a) acc[a][b][t] = mfma_bf16(fa[a], fb, acc[a][b][t]);
           }
+        }
+      };
+      if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < NCHW; ++k) {
+          if (wk + k * WK >= NCH) break;  // wave-uniform
+          k_step(lds_b + o_dy0[k], lds_b + o_dy1[k], lds_b + o_a0[k], lds_b + o_a1[k]);
+        }
+      } else {
+        for (int ch = wk; ch < NCH; ch += WK) {
+          // this lane's two pixels of the k step: rows q4 and q4 + 4 of its 8-pixel group
+          const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;
+          const bool in0 = P0 < NPIX, in1 = P1 < NPIX;
+          const int y0l = P0 / W, x0l = P0 % W, y1l = P1 / W, x1l = P1 % W;
+          k_step(in0 ? dyi + y0l * RSD + x0l * PSD + 4 * p4 : zeros + 4 * p4, in1 ? dyi + y1l * RSD + x1l * PSD + 4 * p4 : zeros + 4 * p4,
+                 ai + (in0 ? IA::at(y0l - 1, x0l - 1) : IA::at(0, 0)) + 4 * p4, ai + (in1 ? IA::at(y1l - 1, x1l - 1) : IA::at(0, 0)) + 4 * p4);
         }
       }
       STAMP(5);
@@ -667,8 +699,8 @@ __global__ __launch_bounds__(NT, 2) void conv1_wgrad_kernel(Conv1BwdParams p) {
 // to HBM by conv2's data gradient and read back by conv1's weight gradient, 1.13 GB per step for a tensor nobody else wants.
 // Here a band of 8 rows of d a1 is born in LDS (conv_dgrad_kernel's routine) and consumed on the spot by conv1's weight gradient
 // on the pooled grid (conv1_wgrad_kernel's routine: pool winners recomputed from the frame, four slot-masked images, 4 x 4
-// patches by transposing reads) -- in two halves of 4 rows, so that the masked images fit beside the dy band, the weights and the
-// two copies of the normalised frame.  Optionally (tests) the band is also stored, bit-identical to conv_dgrad_kernel's.
+// patches by transposing reads).  The band itself never exists as an image: the data gradient's epilogue routes every value
+// straight into the slot-masked images.  Optionally (tests) the band is also stored, bit-identical to conv_dgrad_kernel's.
 struct Conv2DgradW1Params {
   int N;
   const bf16_t* da2;     // (N, 24, 24, 32) gradient w.r.t. the pooled conv2 output (unmasked)
@@ -682,13 +714,12 @@ struct Conv2DgradW1Params {
   float *g_w1, *g_b1;
 };
 
-constexpr int F_BH = 8, F_HB = 4;                                   // rows of d a1 per band / per conv1-wgrad half band
+constexpr int F_BH = 8;                                             // rows of d a1 per band
 using F_ID = Img<C2, F_BH, 48>;                                     // haloed dy2 band
 using F_WM = Wmat<C2, C1>;                                          // [ci][tap' * 32 + co]
 constexpr int F_O_W = F_ID::BYTES;
-constexpr int F_O_OA = F_O_W + round_up(F_WM::BYTES, 16);           // [8 * 48][16] bf16
-constexpr int F_O_IMG = F_O_OA + F_BH * 48 * C1 * 2;                // imgE, imgO
-constexpr int F_AE = F_HB * 48 * C1;                                // elements per masked image of a half band
+constexpr int F_O_IMG = F_O_W + round_up(F_WM::BYTES, 16);          // imgE, imgO
+constexpr int F_AE = F_BH * 48 * C1;                                // elements per slot-masked image of a band
 constexpr int F_O_AE = F_O_IMG + 2 * C1_IMG * 2;
 constexpr int F_O_XN = F_O_AE + 4 * F_AE * 2;                       // [256] f32, then s_red [256] f32, then ibl bytes
 constexpr int CONV2_DGRAD_W1_LDS = F_O_XN + 256 * 4 + 256 * 4 + F_BH * 48 * C1;
@@ -700,15 +731,13 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
   constexpr int HP = 48, H = 48, W = 48;
   bf16_t* dyi = reinterpret_cast<bf16_t*>(smem);
   bf16_t* wl = reinterpret_cast<bf16_t*>(smem + F_O_W);
-  bf16_t* oa = reinterpret_cast<bf16_t*>(smem + F_O_OA);
   bf16_t* imgE = reinterpret_cast<bf16_t*>(smem + F_O_IMG);
   bf16_t* imgO = imgE + C1_IMG;
-  bf16_t* ae = reinterpret_cast<bf16_t*>(smem + F_O_AE);
+  bf16_t* ae = reinterpret_cast<bf16_t*>(smem + F_O_AE);             // [4 slots][8 * 48 pooled pixels][16 channels]
   float* s_xn = reinterpret_cast<float*>(smem + F_O_XN);
   float* s_red = s_xn + 256;
   uint8_t* ibl = reinterpret_cast<uint8_t*>(s_red + 256);            // [8][48][16] recomputed pool winners of the band
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
-  // (wv as an SGPR -- readfirstlane, as in the forward kernels -- was measured here: the last layer's weight gradient 0.32 -> 0.47 ms)
   const int q4 = li >> 2, p4 = li & 3;
 
   s16x8 bq[12];
@@ -724,9 +753,7 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
   f32x4 acc1[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc1[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float gb[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) gb[k] = 0.f;
+  f32x4 gb = {0.f, 0.f, 0.f, 0.f};  // bias gradient of channels 4g .. 4g+3 (the lane's four rows of the transposed product)
 
   uint4 px[2];
   auto load_px = [&](int n) {
@@ -743,11 +770,25 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
   __syncthreads();
   STAMP_DECL;
 
+  // operand addresses of this lane's k steps of conv1's weight gradient, band-relative: made once (see conv_wgrad_kernel)
+  constexpr int F_NCH = (F_BH * HP / 32 + NW - 1) / NW;
+  int o_v0[F_NCH], o_v1[F_NCH], o_ae0[F_NCH];
+#pragma unroll
+  for (int k = 0; k < F_NCH; ++k) {
+    const int P0 = 32 * (wv + k * NW) + 8 * g + q4, P1 = P0 + 4;
+    const int ya = P0 / HP, xa = P0 % HP, yb = P1 / HP, xb = P1 % HP;
+    // patch row vy = p4 of the window: haloed image row 2 yq + p4, haloed columns 2 xq .. 2 xq + 3 (odd xq: the shifted copy)
+    o_v0[k] = ((xa & 1) ? C1_IMG - 2 : 0) + (2 * ya + p4) * C1_XS + 2 * xa;
+    o_v1[k] = ((xb & 1) ? C1_IMG - 2 : 0) + (2 * yb + p4) * C1_XS + 2 * xb;
+    o_ae0[k] = P0 * C1 + 4 * p4;
+  }
   constexpr int MT = 3, MTILES = F_BH * W / 16;  // 24 m tiles per band: one unit of 3 per wave
   static_assert(MTILES / MT == NW, "one d a1 unit per wave");
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     STAMP(15);
-    // ---- the frame's normalised image, twice (conv1_wgrad_kernel)
+    // ---- the frame's normalised image, twice (conv1_wgrad_kernel).  The last band's MFMAs of the previous frame still read the
+    // images: a barrier in front (the frame loop has two barriers per band and none behind the last one)
+    __syncthreads();
     if (tid < 256) {
       const float rr = (float)tid / 255.0f;
       s_xn[tid] = p.standardize ? (rr - p.st[2 * (long)n]) / p.st[2 * (long)n + 1] : rr;
@@ -770,12 +811,17 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
           }
       }
     }
+    __syncthreads();  // the images are complete: conv1 reads them below
     STAMP(0);
     for (int y0 = 0; y0 < H; y0 += F_BH) {
       const bool last_band = y0 + F_BH >= H;
+      // Two barriers per band.  Before the first: the dy band (from the prefetched registers) and conv1's pool winners of the band's
+      // 8 row pairs (one per wave) -- both write what only the phase behind the barrier reads.
       pe.commit(dyi, F_ID::at(-1, 0), F_ID::RS, F_ID::PS, y0 - 1, tid);
       STAMP(1);
-      __syncthreads();  // dy band and (first band) the frame images are complete
+      conv1_winners(imgE, [&](int q) { return bq[q]; }, bias_li, y0, y0 + F_BH, y0, ibl, wv, g, li);
+      STAMP(4);
+      __syncthreads();
       STAMP(2);
       {
         const int nn = last_band ? n + (int)gridDim.x : n;
@@ -784,7 +830,11 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
           if (last_band) load_px(nn);
         }
       }
-      // ---- d a1 rows y0 .. y0+7 -> oa (bf16), one unit per wave
+      // ---- d a1 rows y0 .. y0+7, one unit of 3 m tiles per wave, as a TRANSPOSED product (weights = A operand): the lane ends up
+      // with channels 4g .. 4g+3 of pixel 16 (3 wv + a) + li -- and routes them on the spot: the pool winner of each (pixel,
+      // channel) picks ONE of the four slot-masked images conv1's weight gradient multiplies, the other three get zeros.  The
+      // band of d a1 itself exists in registers only (first version: a bf16 staging image, a separate masking pass over it in
+      // two half bands and four more barriers per band -- 20 k of the kernel's 69 k cycles per frame).
       {
         int base[MT];
 #pragma unroll
@@ -801,68 +851,48 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
           const int off = (tap / 3) * F_ID::RS + (tap % 3) * F_ID::PS + c0;
           const s16x8 fb = lds_frag(wl + li * F_WM::LD + 32 * s2 + 8 * g);
 #pragma unroll
-          for (int a = 0; a < MT; ++a) acc[a] = mfma_bf16(fb, lds_frag(dyi + base[a] + off), acc[a]);  // transposed: see conv_dgrad_kernel
+          for (int a = 0; a < MT; ++a) acc[a] = mfma_bf16(fb, lds_frag(dyi + base[a] + off), acc[a]);
         }
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
-          *reinterpret_cast<uint2*>(oa + (16 * (wv * MT + a) + li) * C1 + 4 * g) = pack_bf16x4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+        for (int a = 0; a < MT; ++a) {
+          const int P = 16 * (wv * MT + a) + li;  // pooled pixel of the band, row-major
+          const uint2 ob = pack_bf16x4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+          if (p.da1) *reinterpret_cast<uint2*>(p.da1 + (((long)n * H + y0) * W + P) * C1 + 4 * g) = ob;
+          const unsigned iv = *reinterpret_cast<const unsigned*>(ibl + P * C1 + 4 * g);  // the four channels' winners
+          const unsigned s0 = iv & 255u, s1 = (iv >> 8) & 255u, s2 = (iv >> 16) & 255u, s3 = iv >> 24;
+          const unsigned l0 = ob.x & 0xffffu, h0 = ob.x & 0xffff0000u, l1 = ob.y & 0xffffu, h1 = ob.y & 0xffff0000u;
+          if (s0 < 4u) gb[0] += __uint_as_float(l0 << 16);
+          if (s1 < 4u) gb[1] += __uint_as_float(h0);
+          if (s2 < 4u) gb[2] += __uint_as_float(l1 << 16);
+          if (s3 < 4u) gb[3] += __uint_as_float(h1);
+#pragma unroll
+          for (unsigned e = 0; e < 4; ++e)
+            *reinterpret_cast<uint2*>(ae + e * F_AE + P * C1 + 4 * g) =
+                uint2{(s0 == e ? l0 : 0u) | (s1 == e ? h0 : 0u), (s2 == e ? l1 : 0u) | (s3 == e ? h1 : 0u)};
+        }
       }
       STAMP(3);
-      // ---- conv1 again for the band's 8 row pairs (one per wave): only the pool winners are kept
-      conv1_winners(imgE, [&](int q) { return bq[q]; }, bias_li, y0, y0 + F_BH, y0, ibl, wv, g, li);
-      STAMP(4);
       __syncthreads();
       STAMP(5);
-      if (p.da1) {
-        uint4* dst = reinterpret_cast<uint4*>(p.da1 + ((long)n * H + y0) * W * C1);
-        for (int q = tid; q < F_BH * W * C1 * 2 / 16; q += NT) dst[q] = reinterpret_cast<const uint4*>(oa)[q];
+      // ---- conv1's weight gradient over the band: 12 k steps of 32 pooled pixels (conv1_wgrad_kernel's routine)
+#pragma unroll
+      for (int k = 0; k < F_NCH; ++k) {
+        if (wv + k * NW >= F_BH * HP / 32) break;  // wave-uniform
+        const int boff = 2 * y0 * C1_XS;           // the band's rows of the frame images
+        const s16x8 fb = tr_pair(imgE + o_v0[k] + boff, imgE + o_v1[k] + boff);
+        const bf16_t* a0 = ae + o_ae0[k];
+        const bf16_t* a1 = a0 + 4 * C1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc1[e] = mfma_bf16(tr_pair(a0 + e * F_AE, a1 + e * F_AE), fb, acc1[e]);
       }
-      // ---- conv1's weight gradient over the band, in two halves of 4 pooled rows
-      for (int hb = 0; hb < F_BH / F_HB; ++hb) {
-        if (tid < F_HB * HP * 2) {  // 8 channels of one pooled pixel per thread: split by window slot
-          const int half = tid & 1, pp = tid >> 1;
-          const int src = (hb * F_HB * HP + pp) * C1 + 8 * half;
-          const uint4 dv = *reinterpret_cast<const uint4*>(oa + src);
-          const uint2 iv = *reinterpret_cast<const uint2*>(ibl + src);
-          const unsigned d[4] = {dv.x, dv.y, dv.z, dv.w};
-          unsigned o[4][4];
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const unsigned ib = (kk < 2 ? iv.x : iv.y) >> (16 * (kk & 1));
-            const unsigned ia = ib & 255u, ic = (ib >> 8) & 255u;
-            const unsigned lo = d[kk] & 0xffffu, hi = d[kk] & 0xffff0000u;
-            if (ia < 4u) gb[2 * kk] += __uint_as_float(lo << 16);
-            if (ic < 4u) gb[2 * kk + 1] += __uint_as_float(hi);
-#pragma unroll
-            for (unsigned e = 0; e < 4; ++e) o[e][kk] = (ia == e ? lo : 0u) | (ic == e ? hi : 0u);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            *reinterpret_cast<uint4*>(ae + e * F_AE + pp * C1 + 8 * half) = uint4{o[e][0], o[e][1], o[e][2], o[e][3]};
-        }
-        STAMP(6);
-        __syncthreads();
-        STAMP(7);
-        const int r0 = y0 + hb * F_HB;
-        for (int ch = wv; ch < F_HB * HP / 32; ch += NW) {
-          const int P0 = 32 * ch + 8 * g + q4, P1 = P0 + 4;
-          const int ya = r0 + P0 / HP, xa = P0 % HP, yb = r0 + P1 / HP, xb = P1 % HP;
-          const bf16_t* v0 = ((xa & 1) ? imgO - 2 : imgE) + (2 * ya + p4) * C1_XS + 2 * xa;
-          const bf16_t* v1 = ((xb & 1) ? imgO - 2 : imgE) + (2 * yb + p4) * C1_XS + 2 * xb;
-          const s16x8 fb = tr_pair(v0, v1);
-          const bf16_t* a0 = ae + P0 * C1 + 4 * p4;
-          const bf16_t* a1 = ae + P1 * C1 + 4 * p4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc1[e] = mfma_bf16(tr_pair(a0 + e * F_AE, a1 + e * F_AE), fb, acc1[e]);
-        }
-        STAMP(8);
-        __syncthreads();  // the next half / band rewrites ae, oa, ibl and the dy band
-        STAMP(9);
-      }
+      STAMP(8);
+      // no barrier here: the next band's commit / winners rewrite the dy band and ibl, which this band read before its second
+      // barrier; ae is rewritten behind the next band's FIRST barrier, which every wave reaches after these MFMAs
     }
   }
   STAMP_FLUSH();
   // ---- fold the slots into the 3 x 3 taps, the waves through LDS, one atomic per element (conv1_wgrad_kernel)
+  __syncthreads();
   for (int q = tid; q < 16 * 16; q += NT) s_red[q] = 0.f;
   __syncthreads();
   const int vy = li >> 2, vx = li & 3;
@@ -873,9 +903,8 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(&s_red[(4 * g + r) * 16 + 3 * ky + kx], acc1[e][r]);
   }
-  if (tid < F_HB * HP * 2)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) atomicAdd(&s_red[(8 * (tid & 1) + k) * 16 + 9], gb[k]);
+  for (int r = 0; r < 4; ++r) atomicAdd(&s_red[(4 * g + r) * 16 + 9], gb[r]);
   __syncthreads();
   if (tid < 16 * 16) {
     const int c = tid >> 4, k = tid & 15;
