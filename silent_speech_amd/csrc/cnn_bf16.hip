@@ -424,6 +424,11 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
   }
   const f32x4 bias1 = *reinterpret_cast<const f32x4*>(p.b1 + 4 * g);  // channels 4g .. 4g+3 (conv1_rows)
   const int chunk = g & 1, hi = g >> 1;
+  int lane_s[WM::KSTEPS];  // conv2: this lane's pixel of a 2 x 8 tile + its k chunk + the tap of k step s
+#pragma unroll
+  for (int s = 0; s < WM::KSTEPS; ++s)
+    lane_s[s] = ((li >> 1) & 1) * IM::RS + (2 * (li >> 2) + (li & 1)) * IM::PS + 8 * chunk + (hi ? koff<IM>(s, 1) : koff<IM>(s, 0));
+  const int lane_o = g * C2 + li;  // conv2's staged output: window g of a tile, channel li (+ 16 per n tile)
   uint4 px[2];
   auto load_px = [&](int n) {
     const uint4* src = reinterpret_cast<const uint4*>(p.R + (long)n * HW0 * HW0);
@@ -499,23 +504,21 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
     for (int half = 0; half < 2; ++half) {
       constexpr int MT = 3, UNITS = HH * 6 / MT;  // 72 m tiles of 2 rows x 8 columns per half
       for (int u = wv; u < UNITS; u += NW) {
-        int base[MT];
-#pragma unroll
-        for (int a = 0; a < MT; ++a) {
-          const int mt = half * HH * 6 + u * MT + a;
-          const int yp = mt / 6, xt = mt % 6;
-          const int y = 2 * yp + ((li >> 1) & 1), x = 8 * xt + 2 * (li >> 2) + (li & 1);
-          base[a] = IM::at(y - 1, x - 1) + 8 * chunk;
-        }
+        // a unit = three neighbouring m tiles = half a pooled row: (pooled row, first tile) are SCALAR (wv is an SGPR), the lane's
+        // place inside a 2 x 8 tile, its k chunk and the tap of every k step are loop-invariant (lane_s[], made once per kernel):
+        // an operand address is scalar + lane_s[s] + an immediate per tile.  (The pixel -> address arithmetic per tile and step
+        // was 54 of the unit's 171 vector instructions beside its 30 MFMAs; the kernel is bound by the vector issue port.)
+        const int ypl = u >> 1, xt0 = 3 * (u & 1);                 // pooled row inside the half, first m tile of the unit
+        const int ubase = IM::at(2 * (half * HH + ypl) - 1, 8 * xt0 - 1);
         f32x4 acc[MT][2];
 #pragma unroll
         for (int a = 0; a < MT; ++a) acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < WM::KSTEPS; ++s) {
-          const int off = hi ? koff<IM>(s, 1) : koff<IM>(s, 0);
           s16x8 fa[MT], fb[2];
+          const bf16_t* ap = a1 + ubase + lane_s[s];
 #pragma unroll
-          for (int a = 0; a < MT; ++a) fa[a] = lds_frag(a1 + base[a] + off);
+          for (int a = 0; a < MT; ++a) fa[a] = lds_frag(ap + a * 8 * IM::PS);
 #pragma unroll
           for (int b = 0; b < 2; ++b) fb[b] = lds_frag(wl + (16 * b + li) * WM::LD + 32 * s + 8 * g);
 #pragma unroll
@@ -523,13 +526,13 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = mfma_bf16(fa[a], fb[b], acc[a][b]);
         }
+        bf16_t* oap = oa + (ypl * WO + 4 * xt0) * C2 + lane_o;
+        uint8_t* oip = oi + (ypl * WO + 4 * xt0) * C2 + lane_o;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const int co = 16 * b + li;
-          const float bias = s_bias[co];
+          const float bias = s_bias[16 * b + li];
 #pragma unroll
           for (int a = 0; a < MT; ++a) {
-            const int mt = u * MT + a;  // within the half
             const f32x4 v = acc[a][b];
             float best = v[0];
             int bi = 0;
@@ -537,9 +540,8 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
             if (v[2] > best) { best = v[2]; bi = 2; }
             if (v[3] > best) { best = v[3]; bi = 3; }
             const float x = fmaxf(best + bias, 0.f);
-            const int o = ((mt / 6) * WO + 4 * (mt % 6) + g) * C2 + co;
-            oa[o] = to_bf16(x);
-            oi[o] = (uint8_t)(x > 0.f ? bi : IDX_DEAD);
+            oap[a * 4 * C2 + 16 * b] = to_bf16(x);
+            oip[a * 4 * C2 + 16 * b] = (uint8_t)(x > 0.f ? bi : IDX_DEAD);
           }
         }
       }
