@@ -178,6 +178,12 @@ typedef struct ss_gemm_problem {
 } ss_gemm_problem;
 int ss_gemm_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats);
 int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream);
+/* The same for bf16 operands (config 5; csrc/gemm_bf16.hip): A and B point at bf16 data (k-major, a_kcontig = b_kcontig = 0; lda /
+ * ldb / strides in bf16 elements, multiples of 8; K a multiple of 64), C[b] += A[b]^T B[b] in f32.  The K tiles of the whole group
+ * are dealt evenly over the CUs ("stream-K": `splits` is ignored), every workgroup leaves raw accumulators in `ws`
+ * (ss_gemm_bf16_splitk_group_ws_floats() floats, 16-byte aligned, contents irrelevant) and a second launch folds them into C. */
+int ss_gemm_bf16_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats);
+int ss_gemm_bf16_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream);
 
 /* a[0..na) = 0 and b[0..nb) = 0 in one launch (either may be empty; 16-byte aligned): the destinations the d layer_in GEMMs
  * sum into with float atomics are cleared by this, off the critical path, instead of two library fills */

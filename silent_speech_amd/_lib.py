@@ -58,6 +58,8 @@ SIGNATURES = {
     "ss_gemm_splitk_reduce": [_vp, _i, _i, _i, _i, _i, _vp, _i, _l, _vp],
     "ss_gemm_splitk_group_ws_floats": [_vp, _i, _vp],
     "ss_gemm_f32_splitk_group": [_vp, _i, _vp, _vp],
+    "ss_gemm_bf16_splitk_group_ws_floats": [_vp, _i, _vp],
+    "ss_gemm_bf16_splitk_group": [_vp, _i, _vp, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
     "ss_zero_f32x2": [_vp, _l, _vp, _l, _vp],
     "ss_train_prologue": [_vp, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -155,12 +157,13 @@ def gemm_group(problems):
     return arr, len(problems)
 
 
-def gemm_group_ws_floats(problems) -> int:
+def gemm_group_ws_floats(problems, bf16: bool = False) -> int:
     arr, n = gemm_group(problems)
     out = C.c_long(0)
-    st = load().ss_gemm_splitk_group_ws_floats(arr, n, C.byref(out))
+    name = "ss_gemm_bf16_splitk_group_ws_floats" if bf16 else "ss_gemm_splitk_group_ws_floats"
+    st = getattr(load(), name)(arr, n, C.byref(out))
     if st != 0:
-        raise RuntimeError(f"ss_gemm_splitk_group_ws_floats -> {st}")
+        raise RuntimeError(f"{name} -> {st}")
     return out.value
 
 

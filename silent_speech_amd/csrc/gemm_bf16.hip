@@ -12,6 +12,8 @@
 // are read with ds_read_b128 (row stride 80 B = 20 banks: the 16 rows of a fragment cover all 64 banks); k-major
 // operands sit as [k][128 + 8] (written with 8-byte stores as they arrive) and are read with the transposing
 // ds_read_b64_tr_b16 -- no transpose pass, no strided global loads.
+#include <stdlib.h>
+
 #include "bf16_common.h"
 
 namespace {
@@ -309,6 +311,431 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBfParams p) {
 // groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table).  Next step: explicit read-ahead of the fragments and an XOR-swizzled
 // unpadded image; not a bigger tile.)
 
+
+// =====================================================================================================================
+// Ring kernel (round 3, second half): 256 x 128 x 64 tiles, 8 waves of 64 x 64, ONE workgroup per CU, bf16 operands in HBM.
+//
+// The kernel above is a register-staged pipeline: its stage timers put a k tile at ~3 000 cycles for 512 cycles of MFMA (issue
+// of the loads and reads, the reads landing, the MFMAs, the wait for the next operands + their LDS stores, the barrier: every
+// phase waits for the one before it).  This one is the f32 GEMM's recipe (gemm.hip::gemm_dma_body) on bf16 tiles:
+//   * operands go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write, the k advance in
+//     the instruction's SCALAR offset, rows / columns outside the operand get an offset beyond num_records and arrive as zeros);
+//   * a ring of three stages (3 x 48 KB): tile t + 2 is requested while tile t is multiplied, `s_waitcnt vmcnt(6)` (the six
+//     DMA instructions of the younger tile stay in flight), one raw `s_barrier` per k tile;
+//   * the DMA fixes where a lane's 16 bytes land (base + 16 lane), so the LDS images are unpadded and the SOURCE addresses carry
+//     the swizzle that keeps the operand reads conflict-free under the hardware's lane groups (MI355X_MICROARCH.md, LDS table):
+//       [row][64 k]  (k-contiguous, 128-byte rows): 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7) -- the 16 lanes
+//                    of a ds_read_b128 group (rows 0-3, 12-15 at chunk g, rows 4-11 at chunk g + 1) cover 16 different 16-byte
+//                    slots of the 256-byte bank row;
+//       [64 k][rows] (k-major, 512- or 256-byte lines): 32-byte segment s of line k sits at s ^ h(k), h = (k & 3) | ((k >> 3) & 1) << 2
+//                    -- the 32 lanes of a ds_read_b64_tr_b16 pass read 32-byte pieces of 8 lines (k = 8 g + q, g in {0,1} or {2,3}):
+//                    8 different h.
+// K must be a multiple of 64 (the caller falls back to the kernel above otherwise); M and N are free (zeros / guarded stores).
+namespace ring {
+
+constexpr int RBM = 256, RBN = 128, RBK = 64, RST = 3;
+constexpr int A_BYTES = RBM * RBK * 2, B_BYTES = RBN * RBK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+constexpr int LDS_BYTES = RST * STAGE_BYTES;  // 144 KB
+constexpr int LDC = RBN + 4;                  // f32 staging image of the output tile (plain stores): 256 x 132 x 4 = 132 KB
+static_assert(RBM * LDC * 4 <= LDS_BYTES, "the output tile is staged in the ring");
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// 64 lanes x 16 bytes from buffer offsets voff (per lane) + soff (scalar) to LDS bytes [lds_addr, lds_addr + 1024), lane l at
+// lds_addr + 16 l.  Inline asm on purpose (ss_common.h::ss_dma16): hipcc does not count it, so no barrier drains it; the
+// consumer waits with a counted s_waitcnt vmcnt in front of its barrier.
+__device__ __forceinline__ void buf_dma16(i32x4 rs, unsigned voff, int soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vmcnt_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void raw_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// One operand's share of a k tile for one wave: NL pieces of 1 KB (piece j = wave + 8 n of the tile's ROWS / 8).
+//   KC = 1: piece j = rows 8 j .. 8 j + 7 (128 bytes each); lane l -> row 8 j + (l >> 3), position l & 7.
+//   KC = 0: piece j = KL = 512 / ROWS k lines; lane l -> line KL j + l / (64 / KL), position l % (64 / KL).
+template <int ROWS, int KC>
+struct Operand {
+  static constexpr int NL = ROWS / 64;
+  static constexpr int KL = 512 / ROWS;      // KC = 0: k lines per piece (A: 2, B: 4)
+  static constexpr int LPL = 64 / KL;        // KC = 0: lanes (16-byte chunks) per k line
+  i32x4 rs;
+  unsigned voff[NL];   // identity map: complete per-lane offset; remapped k lines: the column part only
+  int quo[NL], rem[NL];
+  int soff, step, ld, group, gstride, off, dq, dm;
+  bool ident;
+  __device__ __forceinline__ void init(const bf16_t* src, int ld_, int group_, int gstride_, int off_, int row0, int rows, int k0, int wv,
+                                       int lane) {
+    ld = ld_; group = group_; gstride = gstride_; off = off_;
+    const uintptr_t sa_ = reinterpret_cast<uintptr_t>(src);  // raw buffer: base, stride 0, num_records 2^31 - 1 bytes
+    rs = i32x4{(int)(unsigned)sa_, (int)((sa_ >> 32) & 0xffffu), 0x7FFFFFFF, 0x00020000};
+    ident = KC || (group == 0x7FFFFFFF && off == 0);
+    dq = RBK / group; dm = RBK % group;
+#pragma unroll
+    for (int n = 0; n < NL; ++n) {
+      const int j = wv + 8 * n;
+      if (KC) {
+        const int r = row0 + 8 * j + (lane >> 3), c = (lane & 7) ^ ((4 * j + (lane >> 4)) & 7);
+        voff[n] = r < rows ? (unsigned)((remap_row(r, group, gstride, off) * ld + 8 * c) * 2) : OOB;
+        quo[n] = rem[n] = 0;
+      } else {
+        const int kk = KL * j + lane / LPL, h = (kk & 3) | (((kk >> 3) & 1) << 2);
+        const int c = (lane % LPL) ^ (2 * h), col = row0 + 8 * c;
+        voff[n] = col < rows ? (unsigned)(2 * col) + (ident ? (unsigned)(2 * kk * ld) : 0u) : OOB;
+        quo[n] = (k0 + kk) / group; rem[n] = (k0 + kk) % group;
+      }
+    }
+    soff = __builtin_amdgcn_readfirstlane(KC ? 2 * k0 : (ident ? 2 * k0 * ld : 0));
+    step = __builtin_amdgcn_readfirstlane(KC ? 2 * RBK : 2 * RBK * ld);
+  }
+  // request piece n of the current k tile into the operand's image at LDS byte address `img` (wave-uniform); next(): step to the
+  // following tile once all NL pieces are out
+  __device__ __forceinline__ void piece(int n, unsigned img, int wv) {
+    unsigned o = voff[n];
+    if (!KC && !ident) {  // wave-uniform
+      if (o != OOB) o += 2u * (unsigned)(((long)quo[n] * gstride + rem[n] + off) * ld);
+      quo[n] += dq; rem[n] += dm;
+      if (rem[n] >= group) { rem[n] -= group; ++quo[n]; }
+    }
+    buf_dma16(rs, o, soff, __builtin_amdgcn_readfirstlane(img + (unsigned)(wv + 8 * n) * 1024u));
+  }
+  __device__ __forceinline__ void next() {
+    if (ident) soff += step;
+  }
+  __device__ __forceinline__ void issue(unsigned img, int wv) {
+#pragma unroll
+    for (int n = 0; n < NL; ++n) piece(n, img, wv);
+    next();
+  }
+};
+
+// this lane's operand read offsets (bytes inside the operand's image); everything else of an address is an immediate
+template <int ROWS, int KC>
+struct Frag {
+  unsigned o[4];  // KC = 1: o[k2] (k2 = 0, 1) for row tile 0; KC = 0: o[t] for row tile t at k2 = 0, low half
+  static constexpr int LINE = ROWS * 2;
+  __device__ __forceinline__ void init(int wbase, int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    if (KC) {
+      const int f = (li >> 1) & 7;
+      o[0] = (unsigned)((wbase + li) * 128 + 16 * (g ^ f));
+      o[1] = (unsigned)((wbase + li) * 128 + 16 * ((4 + g) ^ f));
+      o[2] = o[3] = 0;
+    } else {
+      const int q = (lane >> 2) & 3, pp = lane & 3, h = q | ((g & 1) << 2), s0 = (wbase >> 4) ^ (h & 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[t] = (unsigned)((8 * g + q) * LINE + 32 * (s0 + (t ^ (h & 3))) + 8 * pp);
+    }
+  }
+  __device__ __forceinline__ s16x8 read(const char* img, int t, int k2) const {
+    if (KC) return *reinterpret_cast<const s16x8*>(img + o[k2] + 2048 * t);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const char* a0 = img + o[t] + 32 * k2 * LINE;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * LINE));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+};
+
+// The k loop of one output tile: acc += A[m0.., k tiles kt0 .. kt0 + nk) * B[.., n0..] of the operand pair p.A + ea * sa, p.B + eb * sb.
+// Called by all 512 threads; returns behind a barrier that follows the last LDS read (the ring can be refilled at once).
+//
+// Ping-pong: waves 0-3 (`early`) and 4-7 (`late`) -- one of each per SIMD -- run the SAME program one barrier apart.  A tile
+// is two phases with a barrier after each: [read tile t's fragments, request tile t + 2, wait for the own share of tile t + 1]
+// and [multiply tile t]; while one group multiplies, the other reads and requests.  (First version: all eight waves read,
+// requested and multiplied in lockstep -- the barrier starts them together -- and the three costs simply added up: 120 tiles
+// of a d W_ih slice 62 us with neither DMA nor MFMA, +25 us of DMA issue, +41 us of MFMA = 129 us.  In-process A/B of the
+// stagger, tools/gemm_bf16_bench.py diag: input projection 60 against 70 - 85 us, d layer_in 52 / 59, weight gradient 131 / 133.)
+// Hazards: tile t is read by the early group in phase A(t) and by the late group in phase B(t); tile t + 2 goes into the
+// stage of tile t - 1 (last read in phase B(t - 1)) and is requested in A(t) / B(t); a wave waits for its share of tile
+// t + 1 (requested a whole tile earlier) before the barrier that ends its read phase, i.e. before A(t + 1) starts.
+template <int AKC, int BKC>
+__device__ __forceinline__ void ring_mainloop(const GemmBfParams& p, long ea, int m0, int n0, int kt0, int nk, char* rlds, unsigned lds0,
+                                              f32x4 (&acc)[4][4]) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+  Operand<RBM, AKC> da;
+  Operand<RBN, BKC> db;
+  Frag<RBM, AKC> fa_;
+  Frag<RBN, BKC> fb_;
+  fa_.init(wm, lane);
+  fb_.init(wn, lane);
+  constexpr int LPW = Operand<RBM, AKC>::NL + Operand<RBN, BKC>::NL;  // DMA instructions per wave and k tile (6)
+  auto issue = [&](int buf) {
+    da.issue(lds0 + (unsigned)(buf * STAGE_BYTES), wv);
+    db.issue(lds0 + (unsigned)(buf * STAGE_BYTES + A_BYTES), wv);
+  };
+  s16x8 fa[2][4], fb[2][4];
+  const bool late = wv >= 4 && !(p.flags & 1024);  // wave-uniform (1024: diagnostic, no stagger)
+  // the six DMA requests of a wave are spread between its fragment reads: a request holds the wave's issue for as long as the
+  // CU's address path is busy with the other waves' requests (48 KB per tile at 64 B/clk), the reads issued before it land meanwhile
+  auto load = [&](const char* st, int refill) {
+    const char* As = st;
+    const char* Bs = st + A_BYTES;
+    const bool dma = refill >= 0 && !(p.flags & 256);
+    const unsigned ia = lds0 + (unsigned)(refill * STAGE_BYTES), ib = ia + A_BYTES;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k2 = u >> 2, t = u & 3;
+      fa[k2][t] = fa_.read(As, t, k2);
+      fb[k2][t] = fb_.read(Bs, t, k2);
+      if (dma) {
+        if (u == 0) da.piece(0, ia, wv);
+        if (u == 1) da.piece(1, ia, wv);
+        if (u == 2) db.piece(0, ib, wv);
+        if (u == 3) da.piece(2, ia, wv);
+        if (u == 4) da.piece(3, ia, wv);
+        if (u == 5) db.piece(1, ib, wv);
+      }
+    }
+    if (dma) {
+      da.next();
+      db.next();
+    }
+  };
+  auto mult = [&]() {
+    if (p.flags & 512) {  // diagnostic: no MFMAs
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) asm volatile("" ::"v"(fa[k2][a]), "v"(fb[k2][a]));
+      return;
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[k2][a], fb[k2][b], acc[a][b]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto phase_barrier = [&]() {  // (register-only MFMAs would move across a bare barrier)
+    __builtin_amdgcn_sched_barrier(0);
+    raw_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  da.init(static_cast<const bf16_t*>(p.A) + ea * p.sa, p.lda, p.a_group, p.a_gstride, p.a_off, m0, p.M, kt0 * RBK, wv, lane);
+  db.init(static_cast<const bf16_t*>(p.B) + ea * p.sb, p.ldb, p.b_group, p.b_gstride, p.b_off, n0, p.N, kt0 * RBK, wv, lane);
+  if (nk > 0) issue(0);
+  if (nk > 1) {
+    issue(1);
+    vmcnt_wait<LPW>();
+  } else {
+    vmcnt_wait<0>();
+  }
+  phase_barrier();  // tile 0 is in LDS
+  if (late) phase_barrier();
+  for (int t0 = 0; t0 < nk; t0 += RST) {
+#pragma unroll
+    for (int s_ = 0; s_ < RST; ++s_) {
+      const int t = t0 + s_;
+      if (t < nk) {
+        load(rlds + s_ * STAGE_BYTES, t + 2 < nk ? (s_ + 2) % RST : -1);
+        if (t + 2 < nk) vmcnt_wait<LPW>();  // tile t + 1: at most tile t + 2's LPW instructions of this wave stay in flight
+        else vmcnt_wait<0>();
+        phase_barrier();
+        mult();
+        phase_barrier();
+      }
+    }
+  }
+  if (!late) phase_barrier();
+}
+
+// workgroups are dealt to the 8 XCDs round-robin: give every XCD a contiguous range of work (neighbours share operand panels in
+// its L2); bijective for any grid size
+__device__ __forceinline__ int xcd_contiguous_id() {
+  const int nwg = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+
+template <int AKC, int BKC>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(GemmBfParams p, int gx, int gy, int kcat) {
+  extern __shared__ __attribute__((aligned(16))) char rlds[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)rlds;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int wg = xcd_contiguous_id();
+  const int bx = wg % gx, by = (wg / gx) % gy, bz = wg / (gx * gy);
+  const int batch = bz / p.splits, split = bz % p.splits;
+  const int m0 = by * RBM, n0 = bx * RBN;
+  const int nkt = p.K / RBK;
+  const int per = (nkt + p.splits - 1) / p.splits;
+  const int kt0 = split * per, kt1 = min(nkt, kt0 + per), nk = max(0, kt1 - kt0);
+  const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // kcat > 1: that many (A, B) pairs, strides sa / sb apart, are multiplied into ONE C (d layer_in = dG_f W_f + dG_r W_r
+  // without atomics or a cleared C); otherwise the pair of this batch entry
+  for (int kc = 0; kc < kcat; ++kc) ring_mainloop<AKC, BKC>(p, kcat > 1 ? kc : batch, m0, n0, kt0, nk, rlds, lds0, acc);
+
+  // ---- epilogue: D row = 4 g + r, column = li
+  float* C = p.C + (kcat > 1 ? 0 : batch * p.sc);
+  const bool accumulate = p.flags & 1, atomic = (p.flags & 4) || p.splits > 1;
+  const float* bias = p.bias ? p.bias + batch * p.sbias : nullptr;
+  if (!atomic && n0 + RBN <= p.N && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+    // plain stores of a tile whose 128 columns are all there: through LDS, so that a row leaves as one 512-byte run
+    // (the last k tile has been read by everybody and no DMA is in flight: the loop ended on vmcnt(0) and a barrier)
+    float* stage = reinterpret_cast<float*>(rlds);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = wn + 16 * b + li;
+      const float bv = (bias && split == 0) ? bias[n0 + col] : 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(wm + 16 * a + 4 * g + r) * LDC + col] = acc[a][b][r] + bv;
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+#pragma unroll 4
+    for (int it = 0; it < RBM / 16; ++it) {
+      const int row = r0 + 16 * it;
+      if (m0 + row < p.M) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * LDC + c4]);
+        f32x4* dst = reinterpret_cast<f32x4*>(C + (long)(m0 + row) * p.ldc + n0 + c4);
+        if (accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int n = n0 + wn + 16 * b + li;
+    if (n >= p.N) continue;
+    const float bv = (bias && split == 0) ? bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + 16 * a + 4 * g + r;
+        if (m >= p.M) continue;
+        float* dst = C + (long)m * p.ldc + n;
+        const float v = acc[a][b][r] + bv;
+        if (atomic) atomicAdd(dst, v);
+        else if (accumulate) *dst += v;
+        else *dst = v;
+      }
+  }
+}
+
+template <int AKC, int BKC>
+int launch_ring(const GemmBfParams& p, int batch, int kcat, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ring_kernel<AKC, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess)
+      return SS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int gx = ceil_div(p.N, RBN), gy = ceil_div(p.M, RBM);
+  const int nz = (kcat > 1 ? 1 : batch) * p.splits;
+  hipLaunchKernelGGL((gemm_bf16_ring_kernel<AKC, BKC>), dim3((unsigned)(gx * gy * nz)), dim3(512), LDS_BYTES, s, p, gx, gy, kcat);
+  return ss_launch_status();
+}
+
+// ---- Weight gradients: several k-major problems (tiny outputs, K = B T) in ONE launch, K spread evenly over the chip.
+// The work of the group is the list of its (problem, batch entry, output tile, k tile) units in that order; workgroup w takes
+// units [w U, (w + 1) U), U = ceil(units / workgroups): a contiguous run of k tiles of one output tile, crossing into the next
+// tile at most a few times ("stream-K").  Every run leaves its raw accumulators (16 x 16 bytes per lane, coalesced) in a slab of
+// the workspace -- slot (tile, w - first workgroup of the tile) -- and a second launch adds each tile's slabs into the gradient.
+// Why not K slices + float atomics (the form the register-staged kernel keeps): the atomic epilogue of a 256 x 128 tile took
+// 27 us per workgroup, as long as 30 k tiles (device-scope float atomics are performed beyond the XCD's L2), and whole slices
+// per workgroup quantise badly over 256 CUs (144 tiles x 120 k tiles: 1, 2 or 3 slices all end near 80 - 120 tile times for
+// an ideal of 67.5).
+constexpr int GROUP_MAX = 4;
+constexpr int SLAB_FLOATS = RBM * RBN;
+struct RingGroup {
+  GemmBfParams p[GROUP_MAX];
+  int gx[GROUP_MAX], gy[GROUP_MAX], batch[GROUP_MAX], nkt[GROUP_MAX];
+  int ubase[GROUP_MAX + 1];  // first unit of problem j
+  int tbase[GROUP_MAX + 1];  // first tile of problem j
+  int n, U, maxc;            // units per workgroup; slots per tile
+  float* ws;
+};
+
+__global__ __launch_bounds__(512, 1) void gemm_bf16_ring_group_kernel(RingGroup gg) {
+  extern __shared__ __attribute__((aligned(16))) char rlds[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)rlds;
+  const int tid = threadIdx.x;
+  const int w = xcd_contiguous_id();
+  int u = w * gg.U;
+  const int u1 = min(gg.ubase[gg.n], u + gg.U);
+  while (u < u1) {  // wave-uniform
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < GROUP_MAX; ++q)
+      if (q < gg.n && u >= gg.ubase[q]) j = q;
+    // (a dynamically indexed kernel-argument struct would go through scratch: select the problem's fields one by one)
+    GemmBfParams p = gg.p[0];
+    int gx = gg.gx[0], gy = gg.gy[0], nkt = gg.nkt[0], ub = gg.ubase[0], tb = gg.tbase[0];
+#pragma unroll
+    for (int q = 1; q < GROUP_MAX; ++q)
+      if (q == j) { p = gg.p[q]; gx = gg.gx[q]; gy = gg.gy[q]; nkt = gg.nkt[q]; ub = gg.ubase[q]; tb = gg.tbase[q]; }
+    const int local = u - ub, tile = local / nkt, kt0 = local - tile * nkt;
+    const int nk = min(nkt - kt0, u1 - u);
+    const int bx = tile % gx, by = (tile / gx) % gy, bi = tile / (gx * gy);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ring_mainloop<0, 0>(p, bi, by * RBM, bx * RBN, kt0, nk, rlds, lds0, acc);
+    const int w_lo = (ub + tile * nkt) / gg.U;  // first workgroup with a unit of this tile
+    f32x4* slab = reinterpret_cast<f32x4*>(gg.ws + ((long)(tb + tile) * gg.maxc + (w - w_lo)) * SLAB_FLOATS) + tid;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) slab[(a * 4 + b) * 512] = acc[a][b];
+    u += nk;
+  }
+}
+
+// C[tile] += the tile's slabs.  One thread owns one accumulator quad (a, b, lane) of one output tile.
+__global__ __launch_bounds__(512) void gemm_bf16_ring_group_reduce_kernel(RingGroup gg) {
+  const int q = blockIdx.x & 15, gt = blockIdx.x >> 4;
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k)
+    if (k < gg.n && gt >= gg.tbase[k]) j = k;
+  const GemmBfParams& p = gg.p[j];
+  const int tile = gt - gg.tbase[j], gx = gg.gx[j], gy = gg.gy[j], nkt = gg.nkt[j];
+  const int bx = tile % gx, by = (tile / gx) % gy, bi = tile / (gx * gy);
+  const int ustart = gg.ubase[j] + tile * nkt;
+  const int cnt = (ustart + nkt - 1) / gg.U - ustart / gg.U + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
+  const f32x4* src = reinterpret_cast<const f32x4*>(gg.ws + (long)gt * gg.maxc * SLAB_FLOATS) + q * 512 + tid;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < cnt; ++c) sum += src[(long)c * (SLAB_FLOATS / 4)];
+  const int a = q >> 2, b = q & 3;
+  const int col = bx * RBN + (wv & 1) * 64 + 16 * b + li;
+  if (col >= p.N) return;
+  float* C = p.C + bi * p.sc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = by * RBM + (wv >> 1) * 64 + 16 * a + 4 * g + r;
+    if (row < p.M) C[(long)row * p.ldc + col] += sum[r];
+  }
+}
+
+}  // namespace ring
+
 template <int AKC, int BKC, int SRC16>
 int launch_one(const GemmBfParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t lds = 4 * Tile<SRC16 ? 64 : 32>::ELEMS * sizeof(bf16_t);
@@ -333,13 +760,92 @@ int launch_gemm_bf16(int a_kcontig, int b_kcontig, const GemmBfParams& p, dim3 g
 
 }  // namespace
 
+// ---- grouped weight-gradient GEMMs (ring kernel, stream-K over the group; see gemm_bf16_ring_group_kernel)
+static int ring_group_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+static int ring_group_prepare(const ss_gemm_problem* pr, int n, float* ws, ring::RingGroup* out, int* wgs, long* floats) {
+  SS_REQUIRE(pr && n >= 1 && n <= ring::GROUP_MAX, SS_ERR_ARG);
+  ring::RingGroup& gg = *out;
+  gg.n = n;
+  gg.ws = ws;
+  gg.ubase[0] = gg.tbase[0] = 0;
+  int nkt_max = 1;
+  for (int j = 0; j < n; ++j) {
+    const ss_gemm_problem& q = pr[j];
+    SS_REQUIRE(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0 && q.batch > 0 && q.a_group > 0 && q.b_group > 0, SS_ERR_ARG);
+    SS_REQUIRE(!q.a_kcontig && !q.b_kcontig && q.K % ring::RBK == 0, SS_ERR_UNSUPPORTED);
+    SS_REQUIRE(q.lda % 8 == 0 && q.ldb % 8 == 0 && q.stride_a % 8 == 0 && q.stride_b % 8 == 0 && q.M <= q.lda && q.N <= q.ldb, SS_ERR_ARG);
+    SS_REQUIRE((reinterpret_cast<uintptr_t>(q.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.B) & 15) == 0 && q.ldc >= q.N, SS_ERR_ARG);
+    GemmBfParams& p = gg.p[j];
+    p.M = q.M; p.N = q.N; p.K = q.K;
+    p.A = q.A; p.lda = q.lda; p.a_group = q.a_group; p.a_gstride = q.a_gstride; p.a_off = q.a_off;
+    p.B = q.B; p.ldb = q.ldb; p.b_group = q.b_group; p.b_gstride = q.b_gstride; p.b_off = q.b_off;
+    p.C = q.C; p.ldc = q.ldc; p.bias = nullptr; p.flags = 8 | 1; p.splits = 1;
+    p.sa = q.stride_a; p.sb = q.stride_b; p.sc = q.stride_c; p.sbias = 0;
+    gg.gx[j] = ceil_div(q.N, ring::RBN); gg.gy[j] = ceil_div(q.M, ring::RBM); gg.batch[j] = q.batch; gg.nkt[j] = q.K / ring::RBK;
+    const int tiles = gg.gx[j] * gg.gy[j] * q.batch;
+    gg.tbase[j + 1] = gg.tbase[j] + tiles;
+    gg.ubase[j + 1] = gg.ubase[j] + tiles * gg.nkt[j];
+    if (gg.nkt[j] > nkt_max) nkt_max = gg.nkt[j];
+  }
+  for (int j = n; j < ring::GROUP_MAX; ++j) { gg.ubase[j + 1] = gg.ubase[n]; gg.tbase[j + 1] = gg.tbase[n]; gg.gx[j] = gg.gy[j] = gg.nkt[j] = 1; }
+  const int units = gg.ubase[n];
+  const int W = units < ring_group_cus() ? units : ring_group_cus();
+  gg.U = ceil_div(units, W);
+  gg.maxc = (nkt_max - 1) / gg.U + 2;
+  *wgs = ceil_div(units, gg.U);
+  *floats = (long)gg.tbase[n] * gg.maxc * ring::SLAB_FLOATS;
+  return SS_OK;
+}
+
+extern "C" int ss_gemm_bf16_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats) {
+  SS_REQUIRE(floats, SS_ERR_ARG);
+  ring::RingGroup gg;
+  int wgs = 0;
+  return ring_group_prepare(problems, n, nullptr, &gg, &wgs, floats);
+}
+
+extern "C" int ss_gemm_bf16_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream) {
+  SS_REQUIRE(ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, SS_ERR_ARG);
+  ring::RingGroup gg;
+  int wgs = 0;
+  long floats = 0;
+  const int st = ring_group_prepare(problems, n, ws, &gg, &wgs, &floats);
+  if (st != SS_OK) return st;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ring::gemm_bf16_ring_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            ring::LDS_BYTES) != hipSuccess)
+      return SS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(ring::gemm_bf16_ring_group_kernel, dim3((unsigned)wgs), dim3(512), ring::LDS_BYTES, s, gg);
+  if (ss_launch_status() != SS_OK) return SS_ERR_LAUNCH;
+  hipLaunchKernelGGL(ring::gemm_bf16_ring_group_reduce_kernel, dim3((unsigned)(gg.tbase[n] * 16)), dim3(512), 0, s, gg);
+  return ss_launch_status();
+}
+
+static const bool ss_gemm_bf16_no_ring = getenv("SS_GEMM_BF16_NO_RING") != nullptr;
+
 extern "C" int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, const void* A, int lda, int a_group,
                                     int a_gstride, int a_off, const void* B, int ldb, int b_group, int b_gstride, int b_off,
                                     float* C, int ldc, const float* bias, int flags, int splits, int batch, long stride_a,
                                     long stride_b, long stride_c, long stride_bias, ss_stream_t stream) {
   SS_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && splits > 0, SS_ERR_ARG);
   SS_REQUIRE(a_group > 0 && b_group > 0, SS_ERR_ARG);
-  SS_REQUIRE(!(flags & ~13), SS_ERR_UNSUPPORTED);                // bit0 accumulate, bit2 atomics, bit3 operands are bf16 in HBM
+  // bit0 accumulate, bit2 atomics, bit3 operands are bf16 in HBM, bit4 the `batch` (A, B) pairs are summed into ONE C (K concatenated)
+  SS_REQUIRE(!(flags & ~(29 | 768 | 1024)), SS_ERR_UNSUPPORTED);  // (256 / 512: diagnostic)
+  SS_REQUIRE(!(flags & 16) || ((flags & 8) && K % 64 == 0 && splits == 1 && !(flags & 4)), SS_ERR_UNSUPPORTED);
   SS_REQUIRE(splits == 1 || (flags & 1), SS_ERR_ARG);            // K slices add into a C the caller initialised
   SS_REQUIRE(!(flags & 4) || (flags & 1), SS_ERR_ARG);
   const bool src16 = flags & 8;
@@ -362,5 +868,13 @@ extern "C" int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, 
   p.sa = stride_a; p.sb = stride_b; p.sc = stride_c; p.sbias = stride_bias;
   dim3 grid(ceil_div(N, BN), ceil_div(M, BM), batch * p.splits);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // bf16 operands, whole 64-deep k tiles, an output worth a 256 x 128 tile: the ring kernel (SS_GEMM_BF16_NO_RING: diagnostic)
+  if (src16 && K % 64 == 0 && (M >= 128 || (flags & 16)) && !ss_gemm_bf16_no_ring) {
+    const int kcat = (flags & 16) ? batch : 1;
+    if (a_kcontig && b_kcontig) return ring::launch_ring<1, 1>(p, batch, kcat, s);
+    if (a_kcontig) return ring::launch_ring<1, 0>(p, batch, kcat, s);
+    if (b_kcontig) return ring::launch_ring<0, 1>(p, batch, kcat, s);
+    return ring::launch_ring<0, 0>(p, batch, kcat, s);
+  }
   return src16 ? launch_gemm_bf16<1>(a_kcontig, b_kcontig, p, grid, s) : launch_gemm_bf16<0>(a_kcontig, b_kcontig, p, grid, s);
 }

@@ -52,6 +52,35 @@ def split_k(M, N, K, batch, target_wgs=None):
     return max(1, min(-(-K // 64), target_wgs // tiles))
 
 
+# The weight-gradient GEMMs of a GRU layer as ONE launch of the LDS-DMA ring kernel, K dealt evenly over the CUs, + one reduce
+# launch (ss_gemm_bf16_splitk_group) when every K is a whole number of 64-deep tiles (B a multiple of 64); otherwise three
+# launches with K slices and float atomics.  SS_C5_DW_GROUP=0: always the latter (the form of the first half of round 3).
+USE_DW_GROUP = os.environ.get("SS_C5_DW_GROUP", "1") != "0"
+# d layer_in = dGi_f W_ih_f + dGi_r W_ih_r as one product with K concatenated (plain stores, no cleared destination, no atomics)
+USE_DX_KCAT = os.environ.get("SS_C5_DX_KCAT", "1") != "0"
+
+
+def dw_problems(cfg, B, T, l, Kp, dg=16, lin=16, hp=16, g_ih=(16, 0), g_hh=(16, 0)):
+    """ss_gemm_problem records of layer ``l``'s weight gradients (both directions each; bf16 operands): d W_ih = dGi^T . layer_in;
+    d W_hh = dGh^T . h_prev in two pieces (rows r|z from columns [0, 2H) of dG, rows n from columns [3H, 4H)).  Rows (b,t) of dG
+    pair with out rows (b,t-1) (forward) / (b,t+1) (reverse): the same pairing seen from one row earlier in dG and one row later
+    in out (two pointer shifts = the batch strides).  Pointer defaults: shape-only records for the workspace-size query."""
+    H, N = cfg.hidden, B * T
+    K = cfg.in_dim if l == 0 else 2 * H
+    out = [L.GemmProblem(0, 0, 3 * H, K, N, dg, 4 * H, INT_MAX, 0, 0, lin, Kp, INT_MAX, 0, 0, g_ih[0], K, 1, 2, N * 4 * H, 0, g_ih[1])]
+    if T > 1:
+        Kh = B * (T - 1)
+        sa, sb = N * 4 * H - 4 * H, H + 2 * H
+        out.append(L.GemmProblem(0, 0, 2 * H, H, Kh, dg, 4 * H, T - 1, T, 1, hp, 2 * H, T - 1, T, 0, g_hh[0], H, 1, 2, sa, sb, g_hh[1]))
+        out.append(L.GemmProblem(0, 0, H, H, Kh, dg + 3 * H * 2, 4 * H, T - 1, T, 1, hp, 2 * H, T - 1, T, 0, g_hh[0] + 2 * H * H * 4, H,
+                                 1, 2, sa, sb, g_hh[1]))
+    return out
+
+
+def dw_group_ok(problems) -> bool:
+    return USE_DW_GROUP and all(q.K % 64 == 0 for q in problems)
+
+
 def _pstride(P, a: str, b: str) -> int:
     return (P[b].data_ptr() - P[a].data_ptr()) // 4
 
@@ -136,6 +165,12 @@ class WorkspaceBf16:
             self.dG = [torch.empty(2, N, 4, H, **f32) if self.gru_sync is None else None for _ in range(cfg.gru_layers)]
             self.dG_bf = [torch.empty(2, N, 4, H, **i16) for _ in range(cfg.gru_layers)]
             self.d_out = torch.empty(N, 2 * H, **f32)
+            need = 0
+            for l in range(cfg.gru_layers):
+                pr = dw_problems(cfg, B, T, l, self.kp[l])
+                if dw_group_ok(pr):
+                    need = max(need, L.gemm_group_ws_floats(pr, bf16=True))
+            self.dw_ws = torch.empty(need, **f32) if need else None
             self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
             self.xhat = torch.empty(B, 2 * H, **f32)
             self.rstd = torch.empty(B, **f32)
@@ -265,6 +300,13 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
 
         def param_grads(l=l, K=K, Kp=Kp, lin=lin, dg=dg, wi=wi, wir=wir):
             # (the bias gradients are by-products of the BPTT kernel)
+            wh_, whr_ = f"gru.weight_hh_l{l}", f"gru.weight_hh_l{l}_reverse"
+            pr = dw_problems(cfg, B, T, l, Kp, dg, lin, ws.out_bf[l].data_ptr(), (G[wi].data_ptr(), _pstride(G, wi, wir)),
+                             (G[wh_].data_ptr(), _pstride(G, wh_, whr_)))
+            if ws.dw_ws is not None and dw_group_ok(pr):
+                arr, n = L.gemm_group(pr)
+                L.call("ss_gemm_bf16_splitk_group", arr, n, ws.dw_ws.data_ptr(), L.stream(), tag="gemm_bf16_dW")
+                return
             # ---- weight gradients: d W_ih = dGi^T . layer_in;  d W_hh = dGh^T . h_prev (rows r|z from columns [0,2H), rows n from [3H,4H))
             gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, Kp, G[wi].data_ptr(), K, accumulate=True, atomic=True,
                  splits=split_k(3 * H, K, N, 2), batch=2, strides=(N * 4 * H, 0, _pstride(G, wi, wir), 0), tag="gemm_bf16_dW")
@@ -297,8 +339,12 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
             if USE_SIDE_STREAM and not zero_waited:  # once per backward pass: every cleared buffer is behind the same event
                 torch.cuda.current_stream().wait_event(ws.ev_zero)
                 zero_waited = True
-            gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(ws.wih[l], c0), Kp, dst, ld_dst, accumulate=True, atomic=True, batch=2,
-                 strides=(N * 4 * H, 3 * H * Kp, 0, 0), tag="gemm_bf16_dX")
+            if USE_DX_KCAT and (3 * H) % 64 == 0:
+                L.call("ss_gemm_bf16_batched", 1, 0, N, K - c0, 3 * H, dg, 4 * H, *_IDENT, _addr(ws.wih[l], c0), Kp, *_IDENT, dst, ld_dst,
+                       None, 8 | 16, 1, 2, N * 4 * H, 3 * H * Kp, 0, 0, L.stream(), tag="gemm_bf16_dX")
+            else:
+                gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(ws.wih[l], c0), Kp, dst, ld_dst, accumulate=True, atomic=True, batch=2,
+                     strides=(N * 4 * H, 3 * H * Kp, 0, 0), tag="gemm_bf16_dX")
         if USE_SIDE_STREAM:
             ws.ev_fork.record()
             with torch.cuda.stream(ws.side):

@@ -88,6 +88,118 @@ def test_gemm_bf16_batch_splitk_remap(L, src16):
     assert float((C.cpu() - ref).abs().max()) < 3e-4 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K,mode", [(256, 128, 64, "store"), (300, 200, 192, "store"), (512, 136, 128, "accumulate"),
+                                        (132, 64, 256, "store"), (776, 384, 640, "splitk"), (1024, 256, 1024, "store"),
+                                        (384, 72, 320, "splitk")])
+def test_gemm_bf16_ring(L, akc, bkc, M, N, K, mode):
+    """The LDS-DMA ring kernel (bf16 operands, K a multiple of 64, M >= 128): every operand layout, ragged M and N (zeros
+    arrive for rows / columns outside the operand, stores are guarded), plain / accumulating stores through the LDS staging
+    image, K slices with float atomics; two problems per launch.  Run twice: the three-stage ring must leave nothing behind."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + akc * 2 + bkc)
+    A = torch.randn(2, M, K, generator=g)
+    B = torch.randn(2, K, N, generator=g)
+    bias = torch.randn(2, N, generator=g)
+    C0 = torch.randn(2, M, N, generator=g)
+    ref = torch.stack([(bf(A[d]).double() @ bf(B[d]).double()).float() for d in range(2)])
+    A_st = (A if akc else A.transpose(1, 2)).contiguous().cuda()
+    B_st = (B.transpose(1, 2) if bkc else B).contiguous().cuda()
+    ra, rb = A_st.shape[1], B_st.shape[1]
+    A16 = to_bf16_rows(L, A_st.view(2 * ra, -1))
+    B16 = to_bf16_rows(L, B_st.view(2 * rb, -1))
+    lda, ldb = A16.shape[1], B16.shape[1]
+    for rep in range(2):
+        C = C0.clone().cuda()
+        if mode == "store":
+            flags, splits, want, bias_p = 8, 1, ref + bias[:, None, :], bias.cuda()
+        elif mode == "accumulate":
+            flags, splits, want, bias_p = 8 | 1, 1, ref + C0, None
+        else:
+            flags, splits, want, bias_p = 8 | 1, 3, ref + C0, None
+        L.call("ss_gemm_bf16_batched", akc, bkc, M, N, K, A16.data_ptr(), lda, INT_MAX, 0, 0, B16.data_ptr(), ldb, INT_MAX, 0, 0,
+               C.data_ptr(), N, L.ptr(bias_p), flags, splits, 2, ra * lda, rb * ldb, M * N, N, L.stream())
+        torch.cuda.synchronize()
+        err = float((C.cpu() - want).abs().max())
+        assert err < 3e-4 * max(1.0, float(want.abs().max())), (rep, err)
+
+
+def test_gemm_bf16_ring_remap_and_kcat(L):
+    """Ring kernel: the storage-row remap of k-major operands that pairs dG[b][t] with h[b][t-1] (K = B (T - 1) = 128 rows picked
+    out of B T), and the K-concatenated form (flags bit 4: the two directions' products summed into ONE C by plain stores)."""
+    g = torch.Generator().manual_seed(5)
+    Bc, T, Mm, Nn = 16, 9, 192, 136
+    rows = Bc * T
+    dG = torch.randn(2, rows, Mm, generator=g)
+    Hs = torch.randn(2, rows, Nn, generator=g)
+    C0 = torch.randn(2, Mm, Nn, generator=g)
+    K = Bc * (T - 1)
+    ref = C0.clone()
+    for d in range(2):
+        a = dG[d].view(Bc, T, Mm)[:, 1:].reshape(K, Mm)
+        h = Hs[d].view(Bc, T, Nn)[:, :-1].reshape(K, Nn)
+        ref[d] += (bf(a).double().t() @ bf(h).double()).float()
+    C = C0.clone().cuda()
+    dGd, Hd = to_bf16_rows(L, dG.cuda().view(2 * rows, Mm)), to_bf16_rows(L, Hs.cuda().view(2 * rows, Nn))
+    L.call("ss_gemm_bf16_batched", 0, 0, Mm, Nn, K, dGd.data_ptr(), Mm, T - 1, T, 1, Hd.data_ptr(), Nn, T - 1, T, 0,
+           C.data_ptr(), Nn, None, 1 + 8, 2, 2, rows * Mm, rows * Nn, Mm * Nn, 0, L.stream())
+    torch.cuda.synchronize()
+    assert float((C.cpu() - ref).abs().max()) < 3e-4 * float(ref.abs().max())
+    # K concatenation: d layer_in = dG_f W_f + dG_r W_r
+    M, N, K = 400, 256, 192
+    A = torch.randn(2, M, K, generator=g)      # [row][k]
+    W = torch.randn(2, K, N, generator=g)      # [k][n]
+    want = sum((bf(A[d]).double() @ bf(W[d]).double()).float() for d in range(2))
+    A16, W16 = to_bf16_rows(L, A.cuda().view(2 * M, K)), to_bf16_rows(L, W.cuda().view(2 * K, N))
+    C = torch.full((M, N), 3.0, device="cuda")
+    L.call("ss_gemm_bf16_batched", 1, 0, M, N, K, A16.data_ptr(), K, INT_MAX, 0, 0, W16.data_ptr(), N, INT_MAX, 0, 0,
+           C.data_ptr(), N, None, 8 | 16, 1, 2, M * K, K * N, 0, 0, L.stream())
+    torch.cuda.synchronize()
+    assert float((C.cpu() - want).abs().max()) < 3e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("Bc,T,H,Kin", [(64, 5, 128, 136), (128, 3, 256, 512)])
+def test_gemm_bf16_splitk_group(L, Bc, T, H, Kin):
+    """The weight gradients of one GRU layer as ONE grouped launch (ss_gemm_bf16_splitk_group): d W_ih and the two pieces of
+    d W_hh, both directions each, K = B T resp. B (T - 1) with the row remap; the K tiles of the whole group are dealt evenly
+    over the CUs, so workgroups cross tile and problem boundaries.  C is accumulated into; run twice."""
+    g = torch.Generator().manual_seed(Bc + T)
+    N = Bc * T
+    dG = torch.randn(2, N, 4 * H, generator=g)
+    X = torch.randn(N, Kin, generator=g)
+    out = torch.randn(N, 2 * H, generator=g)
+    G_ih0 = torch.randn(2, 3 * H, Kin, generator=g)
+    G_hh0 = torch.randn(2, 3 * H, H, generator=g)
+    want_ih, want_hh = G_ih0.clone(), G_hh0.clone()
+    for d in range(2):
+        want_ih[d] += (bf(dG[d][:, :3 * H]).double().t() @ bf(X).double()).float()
+        dg3 = dG[d].view(Bc, T, 4 * H)
+        o3 = out.view(Bc, T, 2, H)[:, :, d]
+        a = (dg3[:, 1:] if d == 0 else dg3[:, :-1]).reshape(-1, 4 * H)
+        h = (o3[:, :-1] if d == 0 else o3[:, 1:]).reshape(-1, H)
+        want_hh[d][:2 * H] += (bf(a[:, :2 * H]).double().t() @ bf(h).double()).float()
+        want_hh[d][2 * H:] += (bf(a[:, 3 * H:]).double().t() @ bf(h).double()).float()
+    dG16 = to_bf16_rows(L, dG.cuda().view(2 * N, 4 * H))
+    X16 = to_bf16_rows(L, X.cuda())
+    out16 = to_bf16_rows(L, out.cuda())
+    Kp = X16.shape[1]
+    Kh = Bc * (T - 1)
+    for rep in range(2):
+        G_ih, G_hh = G_ih0.clone().cuda(), G_hh0.clone().cuda()
+        dg, hp = dG16.data_ptr(), out16.data_ptr()
+        sa, sb = N * 4 * H - 4 * H, 3 * H
+        pr = [L.GemmProblem(0, 0, 3 * H, Kin, N, dg, 4 * H, INT_MAX, 0, 0, X16.data_ptr(), Kp, INT_MAX, 0, 0, G_ih.data_ptr(), Kin, 1, 2,
+                            N * 4 * H, 0, 3 * H * Kin),
+              L.GemmProblem(0, 0, 2 * H, H, Kh, dg, 4 * H, T - 1, T, 1, hp, 2 * H, T - 1, T, 0, G_hh.data_ptr(), H, 1, 2, sa, sb, 3 * H * H),
+              L.GemmProblem(0, 0, H, H, Kh, dg + 3 * H * 2, 4 * H, T - 1, T, 1, hp, 2 * H, T - 1, T, 0, G_hh.data_ptr() + 2 * H * H * 4, H,
+                            1, 2, sa, sb, 3 * H * H)]
+        ws = torch.full((L.gemm_group_ws_floats(pr, bf16=True),), float("nan"), device="cuda")
+        arr, n = L.gemm_group(pr)
+        L.call("ss_gemm_bf16_splitk_group", arr, n, ws.data_ptr(), L.stream())
+        torch.cuda.synchronize()
+        for got, want in ((G_ih, want_ih), (G_hh, want_hh)):
+            assert float((got.cpu() - want).abs().max()) < 3e-4 * float(want.abs().max()), rep
+
+
 def _gru_emulated(gi, whh, bhh, lengths, T, H, reverse):
     """One direction with the kernel's roundings: bf16 W_hh and bf16 previous state inside the matmul, f32 elsewhere."""
     B = gi.shape[0]
