@@ -331,6 +331,13 @@ int ss_c5_conv2_dgrad_conv1_wgrad(const uint16_t* da2, const uint8_t* i2, int N,
  *   ss_c5_conv1_wgrad     with i1 == NULL recomputes conv1's pool winners from R (needs w1, b1) */
 int ss_c5_conv12_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, const float* w2, const float* b2,
                      uint16_t* a2, uint8_t* i2, float* st, ss_stream_t stream);
+/* The same two with conv1's pool winners i1 (N,48,48,16) u8 left in HBM by the forward kernel and read back by the fused backward
+ * kernel instead of being recomputed from the frame (37 KB per frame each way; i1 = NULL: the forms above). */
+int ss_c5_conv12_fwd_i1(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, const float* w2, const float* b2,
+                        uint16_t* a2, uint8_t* i2, float* st, uint8_t* i1, ss_stream_t stream);
+int ss_c5_conv2_dgrad_conv1_wgrad_i1(const uint16_t* da2, const uint8_t* i2, int N, const float* w2, const uint8_t* R, const float* st,
+                                     int standardize, const float* w1, const float* b1, uint16_t* da1, float* g_w1, float* g_b1,
+                                     const uint8_t* i1, ss_stream_t stream);
 int ss_c5_conv2_wgrad_rc(const uint8_t* R, const float* st, int standardize, const float* w1, const float* b1,
                          const uint16_t* da_out, const uint8_t* idx, int N, float* g_w, float* g_b, ss_stream_t stream);
 

@@ -382,6 +382,8 @@ struct Conv12Params {
   bf16_t* a2;         // (N, 24, 24, 32)
   uint8_t* i2;        // (N, 24, 24, 32)
   float* st;          // (N, 2) mean, std or null
+  uint8_t* i1;        // (N, 48, 48, 16) conv1's pool winners, or null: 37 KB per frame for the fused conv2-dgrad / conv1-wgrad kernel,
+                      // which spent 9.9 k of its 55 k cycles per frame recomputing them from the frame (stage timers, round 3)
 };
 
 __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
@@ -496,7 +498,10 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
     STAMP(0);
     if (n + (int)gridDim.x < p.N) load_px(n + gridDim.x);  // the next frame's bytes, under both convolutions
     // ---- conv1 -> conv2's haloed input image
-    conv1_rows(img, [&](int q) { return bq[q]; }, bias1, 0, 48, 0, a1, IM::at(0, 0), IM::RS, IM::PS, nullptr, wv, g, li);
+    if (p.i1)  // (wave-uniform; the winner bytes of a lane's four channels leave as one 4-byte global store)
+      conv1_rows(img, [&](int q) { return bq[q]; }, bias1, 0, 48, 0, a1, IM::at(0, 0), IM::RS, IM::PS, p.i1 + (long)n * 48 * 48 * C1, wv, g, li);
+    else
+      conv1_rows(img, [&](int q) { return bq[q]; }, bias1, 0, 48, 0, a1, IM::at(0, 0), IM::RS, IM::PS, nullptr, wv, g, li);
     STAMP(1);
     __syncthreads();
     STAMP(2);
@@ -565,11 +570,16 @@ constexpr int CONV12_LDS = round_up(98 * RS0 * 2, 16) + (256 + 64) * 4 + Img<C1,
 
 }  // namespace
 
+extern "C" int ss_c5_conv12_fwd_i1(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, const float* w2,
+                                   const float* b2, uint16_t* a2, uint8_t* i2, float* st, uint8_t* i1, ss_stream_t stream) {
+  SS_REQUIRE(R && w1 && b1 && w2 && b2 && a2 && i2 && N > 0, SS_ERR_ARG);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(i1) & 15) == 0, SS_ERR_ARG);
+  Conv12Params p{R, N, standardize, w1, b1, w2, b2, a2, i2, st, i1};
+  return launch_persistent(conv12_fwd_kernel, p, CONV12_LDS, N, static_cast<hipStream_t>(stream));
+}
 extern "C" int ss_c5_conv12_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, const float* w2,
                                 const float* b2, uint16_t* a2, uint8_t* i2, float* st, ss_stream_t stream) {
-  SS_REQUIRE(R && w1 && b1 && w2 && b2 && a2 && i2 && N > 0, SS_ERR_ARG);
-  Conv12Params p{R, N, standardize, w1, b1, w2, b2, a2, i2, st};
-  return launch_persistent(conv12_fwd_kernel, p, CONV12_LDS, N, static_cast<hipStream_t>(stream));
+  return ss_c5_conv12_fwd_i1(R, N, standardize, w1, b1, w2, b2, a2, i2, st, nullptr, stream);
 }
 
 extern "C" int ss_c5_conv1_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, uint16_t* a1,

@@ -714,6 +714,7 @@ struct Conv2DgradW1Params {
   const float *w1, *b1;  // conv1 (to recompute its pool winners)
   bf16_t* da1;           // (N, 48, 48, 16) or null
   float *g_w1, *g_b1;
+  const uint8_t* i1;     // (N, 48, 48, 16) conv1's pool winners from the forward pass (ss_c5_conv12_fwd_i1), or null: recomputed
 };
 
 constexpr int F_BH = 8;                                             // rows of d a1 per band
@@ -764,7 +765,13 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
     px[1] = (tid + NT < HW0 * HW0 / 16) ? src[tid + NT] : uint4{0u, 0u, 0u, 0u};
   };
   ExpandLoad<C2, H, W, F_BH + 2> pe;
-  auto issue = [&](int n, int y0) { pe.issue(p.da2 + (long)n * 24 * 24 * C2, p.i2 + (long)n * 24 * 24 * C2, y0 - 1, tid); };
+  // the band's pool winners (8 rows x 48 pixels x 16 channels = 384 x 16 bytes) ride with the band's other loads when the forward
+  // pass left them in HBM
+  uint4 iw = {0u, 0u, 0u, 0u};
+  auto issue = [&](int n, int y0) {
+    pe.issue(p.da2 + (long)n * 24 * 24 * C2, p.i2 + (long)n * 24 * 24 * C2, y0 - 1, tid);
+    if (p.i1 && tid < F_BH * 48) iw = reinterpret_cast<const uint4*>(p.i1 + ((long)n * HP + y0) * HP * C1)[tid];
+  };
   if ((int)blockIdx.x < p.N) {
     load_px(blockIdx.x);
     issue(blockIdx.x, 0);
@@ -821,7 +828,11 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
       // 8 row pairs (one per wave) -- both write what only the phase behind the barrier reads.
       pe.commit(dyi, F_ID::at(-1, 0), F_ID::RS, F_ID::PS, y0 - 1, tid);
       STAMP(1);
-      conv1_winners(imgE, [&](int q) { return bq[q]; }, bias_li, y0, y0 + F_BH, y0, ibl, wv, g, li);
+      if (p.i1) {  // wave-uniform
+        if (tid < F_BH * 48) reinterpret_cast<uint4*>(ibl)[tid] = iw;
+      } else {
+        conv1_winners(imgE, [&](int q) { return bq[q]; }, bias_li, y0, y0 + F_BH, y0, ibl, wv, g, li);
+      }
       STAMP(4);
       __syncthreads();
       STAMP(2);
@@ -955,12 +966,19 @@ extern "C" int ss_c5_conv2_wgrad_rc(const uint8_t* R, const float* st, int stand
 
 // conv2's data gradient and conv1's weight gradient in one kernel: d a1 never reaches HBM (da1 = NULL; a non-NULL da1 also gets the
 // map, for tests).  da2 / i2 (N,24,24,32), R (N,96,96), st (N,2) from the forward, w2 (32,16,3,3), w1 / b1 conv1.
+// i1 (N,48,48,16): conv1's pool winners as ss_c5_conv12_fwd_i1 left them, or NULL (recomputed from R, w1, b1).
+extern "C" int ss_c5_conv2_dgrad_conv1_wgrad_i1(const uint16_t* da2, const uint8_t* i2, int N, const float* w2, const uint8_t* R,
+                                                const float* st, int standardize, const float* w1, const float* b1, uint16_t* da1,
+                                                float* g_w1, float* g_b1, const uint8_t* i1, ss_stream_t stream) {
+  SS_REQUIRE(da2 && i2 && w2 && R && st && w1 && b1 && g_w1 && g_b1 && N > 0, SS_ERR_ARG);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(i1) & 15) == 0, SS_ERR_ARG);
+  Conv2DgradW1Params p{N, da2, i2, w2, R, st, standardize, w1, b1, da1, g_w1, g_b1, i1};
+  return launch_persistent(conv2_dgrad_w1_kernel, p, CONV2_DGRAD_W1_LDS, N, static_cast<hipStream_t>(stream));
+}
 extern "C" int ss_c5_conv2_dgrad_conv1_wgrad(const uint16_t* da2, const uint8_t* i2, int N, const float* w2, const uint8_t* R,
                                              const float* st, int standardize, const float* w1, const float* b1, uint16_t* da1,
                                              float* g_w1, float* g_b1, ss_stream_t stream) {
-  SS_REQUIRE(da2 && i2 && w2 && R && st && w1 && b1 && g_w1 && g_b1 && N > 0, SS_ERR_ARG);
-  Conv2DgradW1Params p{N, da2, i2, w2, R, st, standardize, w1, b1, da1, g_w1, g_b1};
-  return launch_persistent(conv2_dgrad_w1_kernel, p, CONV2_DGRAD_W1_LDS, N, static_cast<hipStream_t>(stream));
+  return ss_c5_conv2_dgrad_conv1_wgrad_i1(da2, i2, N, w2, R, st, standardize, w1, b1, da1, g_w1, g_b1, nullptr, stream);
 }
 
 extern "C" int ss_c5_conv_dgrad(int layer, const uint16_t* da_out, const uint8_t* idx, int N, const float* w, uint16_t* da_in,

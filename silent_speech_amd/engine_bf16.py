@@ -55,6 +55,8 @@ def split_k(M, N, K, batch, target_wgs=None):
 # The weight-gradient GEMMs of a GRU layer as ONE launch of the LDS-DMA ring kernel, K dealt evenly over the CUs, + one reduce
 # launch (ss_gemm_bf16_splitk_group) when every K is a whole number of 64-deep tiles (B a multiple of 64); otherwise three
 # launches with K slices and float atomics.  SS_C5_DW_GROUP=0: always the latter (the form of the first half of round 3).
+# conv1's pool winners (37 KB per frame) stashed by the forward kernel for the fused conv2-dgrad / conv1-wgrad kernel (0: recomputed there)
+STASH_I1 = os.environ.get("SS_C5_STASH_I1", "1") != "0"
 USE_DW_GROUP = os.environ.get("SS_C5_DW_GROUP", "1") != "0"
 # d layer_in = dGi_f W_ih_f + dGi_r W_ih_r as one product with K concatenated (plain stores, no cleared destination, no atomics)
 USE_DX_KCAT = os.environ.get("SS_C5_DX_KCAT", "1") != "0"
@@ -181,6 +183,7 @@ class WorkspaceBf16:
             if cfg.use_roi:
                 c1, c2, c3, c4 = CNN_CHANNELS
                 self.st = torch.empty(N, 2, **f32)
+                self.i1 = torch.empty(N, 48, 48, c1, **u8) if (STASH_I1 and FUSE_DGRAD2_WGRAD1) else None
                 self.m4 = torch.empty(N, 144, c4, **u8)
                 self.feat = torch.empty(N, c4, **f32)
                 self.da1 = torch.empty(N, 48, 48, c1, **i16) if not FUSE_DGRAD2_WGRAD1 else None
@@ -202,8 +205,8 @@ def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
             L.call("ss_copy_rows_f32", X.data_ptr(), cfg.x_dim, ws.Z.data_ptr(), cfg.in_dim, N, cfg.x_dim, s)
         w = [P[k + ".weight"].data_ptr() for k in _CONV]
         b = [P[k + ".bias"].data_ptr() for k in _CONV]
-        L.call("ss_c5_conv12_fwd", R.data_ptr(), N, int(cfg.roi_standardize), w[0], b[0], w[1], b[1], ws.a2.data_ptr(), ws.i2.data_ptr(),
-               ws.st.data_ptr() if stash else None, s)
+        L.call("ss_c5_conv12_fwd_i1", R.data_ptr(), N, int(cfg.roi_standardize), w[0], b[0], w[1], b[1], ws.a2.data_ptr(), ws.i2.data_ptr(),
+               ws.st.data_ptr() if stash else None, L.ptr(ws.i1) if stash else None, s, tag="ss_c5_conv12_fwd")
         L.call("ss_c5_conv_fwd", 3, ws.a2.data_ptr(), N, w[2], b[2], ws.a3.data_ptr(), ws.i3.data_ptr(), s, tag="ss_c5_conv3_fwd")
         L.call("ss_c5_conv_last_fwd", ws.a3.data_ptr(), N, w[3], b[3], P["roi_cnn.fc.weight"].data_ptr(), P["roi_cnn.fc.bias"].data_ptr(),
                cfg.roi_emb, _addr(ws.Z, cfg.x_dim), cfg.in_dim, ws.m4.data_ptr() if stash else None,
@@ -339,12 +342,13 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
             if USE_SIDE_STREAM and not zero_waited:  # once per backward pass: every cleared buffer is behind the same event
                 torch.cuda.current_stream().wait_event(ws.ev_zero)
                 zero_waited = True
-            if USE_DX_KCAT and (3 * H) % 64 == 0:
+            # (layer 0 with the ROI branch: 68 output columns = 30 tiles of the ring kernel -- K slices and atomics fill more CUs)
+            if USE_DX_KCAT and (3 * H) % 64 == 0 and K - c0 >= 128:
                 L.call("ss_gemm_bf16_batched", 1, 0, N, K - c0, 3 * H, dg, 4 * H, *_IDENT, _addr(ws.wih[l], c0), Kp, *_IDENT, dst, ld_dst,
                        None, 8 | 16, 1, 2, N * 4 * H, 3 * H * Kp, 0, 0, L.stream(), tag="gemm_bf16_dX")
             else:
                 gemm(1, 0, N, K - c0, 3 * H, dg, 4 * H, _addr(ws.wih[l], c0), Kp, dst, ld_dst, accumulate=True, atomic=True, batch=2,
-                     strides=(N * 4 * H, 3 * H * Kp, 0, 0), tag="gemm_bf16_dX")
+                     splits=2 if K - c0 < 128 else 1, strides=(N * 4 * H, 3 * H * Kp, 0, 0), tag="gemm_bf16_dX")
         if USE_SIDE_STREAM:
             ws.ev_fork.record()
             with torch.cuda.stream(ws.side):
@@ -369,8 +373,8 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         L.call("ss_c5_conv2_wgrad_rc", R.data_ptr(), ws.st.data_ptr(), int(cfg.roi_standardize), w[0], bb[0], ws.da2.data_ptr(),
                ws.i2.data_ptr(), N, gw[1], gb[1], s)
         if FUSE_DGRAD2_WGRAD1:  # d a1 (the largest gradient map) is born and consumed in LDS: 1.13 GB per step less through HBM
-            L.call("ss_c5_conv2_dgrad_conv1_wgrad", ws.da2.data_ptr(), ws.i2.data_ptr(), N, w[1], R.data_ptr(), ws.st.data_ptr(),
-                   int(cfg.roi_standardize), w[0], bb[0], None, gw[0], gb[0], s)
+            L.call("ss_c5_conv2_dgrad_conv1_wgrad_i1", ws.da2.data_ptr(), ws.i2.data_ptr(), N, w[1], R.data_ptr(), ws.st.data_ptr(),
+                   int(cfg.roi_standardize), w[0], bb[0], None, gw[0], gb[0], L.ptr(ws.i1), s, tag="ss_c5_conv2_dgrad_conv1_wgrad")
         else:
             L.call("ss_c5_conv_dgrad", 2, ws.da2.data_ptr(), ws.i2.data_ptr(), N, w[1], ws.da1.data_ptr(), s, tag="ss_c5_conv2_dgrad")
             L.call("ss_c5_conv1_wgrad", R.data_ptr(), N, int(cfg.roi_standardize), ws.st.data_ptr(), ws.da1.data_ptr(), None, w[0],

@@ -680,3 +680,21 @@ def test_c5_conv12_fused_forward_and_recomputing_backward(L, N, wg_cap):
     for got_w, got_b in ((g1f, gb1f), (g1n, gb1n)):
         assert float((got_w - g1a).abs().max()) < 1e-4 * float(g1a.abs().max())
         assert float((got_b - gb1a).abs().max()) < 1e-4 * float(gb1a.abs().max())
+
+    # ---- the pool winners stashed by the forward kernel (ss_c5_conv12_fwd_i1) instead of recomputed by the fused backward kernel:
+    # the same bytes as the unfused conv1 kernel writes, the same a2 / i2, the same conv1 gradient
+    a1_u = torch.empty(N, 48, 48, 16, device="cuda", dtype=torch.int16)
+    i1_u = torch.empty(N, 48, 48, 16, device="cuda", dtype=torch.uint8)
+    L.call("ss_c5_conv1_fwd", R_d.data_ptr(), N, 1, w1_d.data_ptr(), b1_d.data_ptr(), a1_u.data_ptr(), i1_u.data_ptr(), None, L.stream())
+    a2_s, i2_s = torch.empty_like(a2_d), torch.empty_like(i2_d)
+    i1_s = torch.full((N, 48, 48, 16), 9, device="cuda", dtype=torch.uint8)
+    L.call("ss_c5_conv12_fwd_i1", R_d.data_ptr(), N, 1, w1_d.data_ptr(), b1_d.data_ptr(), w2_d.data_ptr(), b2_d.data_ptr(), a2_s.data_ptr(),
+           i2_s.data_ptr(), st.data_ptr(), i1_s.data_ptr(), L.stream())
+    g1s, gb1s = torch.zeros(16, 1, 3, 3, device="cuda"), torch.zeros(16, device="cuda")
+    L.call("ss_c5_conv2_dgrad_conv1_wgrad_i1", da2_d.data_ptr(), idx2_d.data_ptr(), N, w2_d.data_ptr(), R_d.data_ptr(), st.data_ptr(), 1,
+           w1_d.data_ptr(), b1_d.data_ptr(), None, g1s.data_ptr(), gb1s.data_ptr(), i1_s.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a2_s, a2_d) and torch.equal(i2_s, i2_d)
+    assert float((i1_s != i1_u).float().mean()) < 1e-5, "stashed conv1 pool winners differ from the unfused kernel's"
+    assert float((g1s - g1a).abs().max()) < 1e-4 * float(g1a.abs().max())
+    assert float((gb1s - gb1a).abs().max()) < 1e-4 * float(gb1a.abs().max())
