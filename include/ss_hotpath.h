@@ -331,6 +331,15 @@ int ss_c5_conv2_dgrad_conv1_wgrad(const uint16_t* da2, const uint8_t* i2, int N,
  *   ss_c5_conv1_wgrad     with i1 == NULL recomputes conv1's pool winners from R (needs w1, b1) */
 int ss_c5_conv12_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, const float* w2, const float* b2,
                      uint16_t* a2, uint8_t* i2, float* st, ss_stream_t stream);
+/* Layer 4 with its Linear and the Linear's gradients as the caller's GEMMs over all frames (three small f32 GEMMs instead of a
+ * per-frame walk over W_fc inside the persistent kernels):
+ *   ss_c5_conv_last_fwd_feat  a3 -> feat (N,96) f32 (+ mask (N,144,96) u8 when training); z = feat . W_fc^T + b_fc is the caller's
+ *   ss_c5_conv_last_wgrad_df / _dgrad_df  take dfeat (N,96) f32 = d z . W_fc (unscaled: the kernels divide by 144);
+ *                             g_wfc += d z^T . feat and g_bfc += column sums of d z are the caller's */
+int ss_c5_conv_last_fwd_feat(const uint16_t* in, int N, const float* w, const float* b, uint8_t* mask, float* feat, ss_stream_t stream);
+int ss_c5_conv_last_wgrad_df(const uint16_t* a_in, const float* dfeat, const uint8_t* mask, int N, float* g_w, float* g_b,
+                             ss_stream_t stream);
+int ss_c5_conv_last_dgrad_df(const float* dfeat, const uint8_t* mask, int N, const float* w, uint16_t* da_in, ss_stream_t stream);
 /* The same two with conv1's pool winners i1 (N,48,48,16) u8 left in HBM by the forward kernel and read back by the fused backward
  * kernel instead of being recomputed from the frame (37 KB per frame each way; i1 = NULL: the forms above). */
 int ss_c5_conv12_fwd_i1(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, const float* w2, const float* b2,

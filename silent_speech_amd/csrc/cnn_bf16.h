@@ -245,16 +245,18 @@ template <int COUT, int NPIX>
 struct MaskLoad {
   static constexpr int CH = COUT / 8, ITEMS = NPIX * CH, NV = (ITEMS + NT - 1) / NT;
   uint2 m[NV];
-  float dz, ft;
+  float dz, ft, df;
+  // dfrow: this frame's row of d feat * (H*W) = d z . W_fc made by a GEMM over all frames (or null: the kernel makes it from dzrow)
   __device__ __forceinline__ void issue(const uint8_t* __restrict__ mask, const float* __restrict__ dzrow, int E,
-                                        const float* __restrict__ featrow, int tid) {
+                                        const float* __restrict__ featrow, int tid, const float* __restrict__ dfrow = nullptr) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int q = tid + k * NT;
       m[k] = q < ITEMS ? *reinterpret_cast<const uint2*>(mask + (long)(q / CH) * COUT + 8 * (q % CH)) : uint2{0u, 0u};
     }
-    dz = tid < E ? dzrow[tid] : 0.f;
+    dz = (dzrow && tid < E) ? dzrow[tid] : 0.f;
     ft = (featrow && tid < COUT) ? featrow[tid] : 0.f;
+    df = (dfrow && tid < COUT) ? dfrow[tid] : 0.f;
   }
   // dy[P][co] = mask ? dfeat[co] : 0
   __device__ __forceinline__ void commit(const float* s_dfeat, bf16_t* img, int off0, int RS, int PS, int W, int tid) const {

@@ -337,12 +337,15 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
         if (p.feat) p.feat[(long)n * COUT + q] = f;
       }
       __syncthreads();
-      for (int e = tid; e < p.E; e += NT) {
-        float o = p.bfc[e];
-        for (int c = 0; c < COUT; ++c) o += s_feat[c] * p.wfc[e * COUT + c];
-        p.z[(long)n * p.ld_z + e] = o;
+      if (p.z) {  // (null: Linear(96 -> E) over all frames is the caller's GEMM on `feat` -- 64 threads walking a row of W_fc each,
+                  // per frame, was a chain of global loads with the other 448 threads waiting at the barrier)
+        for (int e = tid; e < p.E; e += NT) {
+          float o = p.bfc[e];
+          for (int c = 0; c < COUT; ++c) o += s_feat[c] * p.wfc[e * COUT + c];
+          p.z[(long)n * p.ld_z + e] = o;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     } else {
       uint4* da = reinterpret_cast<uint4*>(p.out + (long)n * HO * WO * COUT);
       for (int q = tid; q < HO * WO * COUT * 2 / 16; q += NT) da[q] = reinterpret_cast<const uint4*>(oa)[q];
@@ -580,6 +583,16 @@ extern "C" int ss_c5_conv12_fwd_i1(const uint8_t* R, int N, int standardize, con
 extern "C" int ss_c5_conv12_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, const float* w2,
                                 const float* b2, uint16_t* a2, uint8_t* i2, float* st, ss_stream_t stream) {
   return ss_c5_conv12_fwd_i1(R, N, standardize, w1, b1, w2, b2, a2, i2, st, nullptr, stream);
+}
+
+// layer 4 without the Linear: feat (N, 96) f32 = global average of ReLU(conv4), mask (N,144,96) u8 or null
+extern "C" int ss_c5_conv_last_fwd_feat(const uint16_t* in, int N, const float* w, const float* b, uint8_t* mask, float* feat,
+                                        ss_stream_t stream) {
+  SS_REQUIRE(in && w && b && feat && N > 0, SS_ERR_ARG);
+  ConvFwdParams p{};
+  p.in = in; p.N = N; p.w = w; p.b = b; p.mask = mask; p.feat = feat;
+  return launch_persistent(conv_fwd_kernel<C3, C4, 12, 12, true, 3, 3>, p, conv_fwd_lds<C3, C4, 12, 12, true>(), N,
+                           static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ss_c5_conv1_fwd(const uint8_t* R, int N, int standardize, const float* w1, const float* b1, uint16_t* a1,

@@ -46,6 +46,7 @@ struct ConvBwdParams {
   const float* wfc;
   const uint8_t* mask;    // (N, H*W, COUT)
   const float* feat;      // (N, COUT)
+  const float* dfeat;     // (N, COUT) d z . W_fc of every frame (a GEMM in front of the kernels), or null: made per frame from dz, wfc
   const float* w;         // (COUT, CIN, 3, 3) f32 (dgrad)
   float *g_w, *g_b;       // gradient accumulators (wgrad), +=
   float *g_wfc, *g_bfc;   // (E, COUT), (E)  (last layer's wgrad)
@@ -141,7 +142,11 @@ __device__ __forceinline__ void last_dfeat(const ConvBwdParams& p, int n, float*
 // RC (layer 2 only): the layer's input a1 = pool(ReLU(conv1(frame))) is not read from HBM but recomputed per band from the 9 KB
 // uint8 frame (conv1 patch GEMM of cnn_bf16.hip: 12 MFMAs per row pair) -- it was the largest tensor of the net.
 // MINW: waves per SIMD the register allocation must allow (2 = one workgroup per CU, 4 = two)
-template <int CIN, int COUT, int H, int W, bool LAST, int BH, int WCO, int WCI, int WK, bool RC = false, int MINW = 2>
+// FCX (last layer): d feat arrives ready-made (p.dfeat) and the fc gradients are somebody else's GEMMs.  The stage timers put
+// the per-frame "d z -> d feat (96 threads walking 64 rows of W_fc in global memory), fc gradients, dy image" stage at 19.9 k of
+// the kernel's 30.4 k cycles per frame: as three small GEMMs over all frames that work leaves the kernel (and its 12 registers
+// of fc partial sums leave an instantiation that sat at 256 registers and spilled).
+template <int CIN, int COUT, int H, int W, bool LAST, int BH, int WCO, int WCI, int WK, bool RC = false, int MINW = 2, bool FCX = false>
 __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   static_assert(WCO * WCI * WK == NW && H % BH == 0, "wave split");
   static_assert(!RC || (CIN == C1 && H == 48 && W == 48 && !LAST), "recompute form: layer 2");
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   }
   const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   // fc gradients of the last layer: thread-private partial sums over the frames
-  constexpr int FCN = LAST ? (64 * COUT + NT - 1) / NT : 1;
+  constexpr int FCN = (LAST && !FCX) ? (64 * COUT + NT - 1) / NT : 1;
   float fcw[FCN];
   float fcb = 0.f;
 #pragma unroll
@@ -235,8 +240,12 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   MaskLoad<COUT, H * W> pm;
   BandLoad<IA, H, BH + 2> pa;
   auto issue = [&](int n, int y0) {
-    if (LAST) pm.issue(p.mask + (long)n * H * W * COUT, p.dz + (long)n * p.ld_dz, p.E, p.feat + (long)n * COUT, tid);
-    else pe.issue(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, y0, tid);
+    if (LAST) {
+      if (FCX) pm.issue(p.mask + (long)n * H * W * COUT, nullptr, 0, nullptr, tid, p.dfeat + (long)n * COUT);
+      else pm.issue(p.mask + (long)n * H * W * COUT, p.dz + (long)n * p.ld_dz, p.E, p.feat + (long)n * COUT, tid);
+    } else {
+      pe.issue(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, y0, tid);
+    }
     if (!RC) pa.issue(p.a_in + (long)n * H * W * CIN, y0 - 1, tid);
   };
   if ((int)blockIdx.x < p.N) issue(blockIdx.x, 0);
@@ -267,7 +276,11 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
     }
     STAMP(0);
     for (int y0 = 0; y0 < H; y0 += BH) {
-      if (LAST) {
+      if (LAST && FCX) {
+        if (tid < COUT) s_dfeat[tid] = pm.df * (1.0f / (float)(H * W));
+        __syncthreads();
+        pm.commit(s_dfeat, dyi, 0, RSD, PSD, W, tid);
+      } else if (LAST) {
         if (tid < p.E) s_dz[tid] = pm.dz;
         if (tid < COUT) s_feat[tid] = pm.ft;
         __syncthreads();
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
     __syncthreads();
     for (int q = tid; q < COUT; q += NT) atomicAdd(p.g_b + q, redw[q]);
   }
-  if (LAST) {
+  if (LAST && !FCX) {
 #pragma unroll
     for (int k = 0; k < FCN; ++k) {
       const int q = tid + k * NT;
@@ -446,19 +459,27 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
   ExpandLoad<COUT, H, W, BH + 2> pe;
   MaskLoad<COUT, H * W> pm;
   auto issue = [&](int n, int y0) {
-    if (LAST) pm.issue(p.mask + (long)n * H * W * COUT, p.dz + (long)n * p.ld_dz, p.E, nullptr, tid);
-    else pe.issue(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, y0 - 1, tid);
+    if (LAST) {
+      if (p.dfeat) pm.issue(p.mask + (long)n * H * W * COUT, nullptr, 0, nullptr, tid, p.dfeat + (long)n * COUT);
+      else pm.issue(p.mask + (long)n * H * W * COUT, p.dz + (long)n * p.ld_dz, p.E, nullptr, tid);
+    } else {
+      pe.issue(p.da_out + (long)n * (H / 2) * (W / 2) * COUT, p.idx + (long)n * (H / 2) * (W / 2) * COUT, y0 - 1, tid);
+    }
   };
   if ((int)blockIdx.x < p.N) issue(blockIdx.x, 0);
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     for (int y0 = 0; y0 < H; y0 += BH) {
       if (LAST) {
-        if (tid < p.E) s_dz[tid] = pm.dz;
-        __syncthreads();
-        for (int c = tid; c < COUT; c += NT) {
-          float s = 0.f;
-          for (int e = 0; e < p.E; ++e) s += s_dz[e] * p.wfc[e * COUT + c];
-          s_dfeat[c] = s * (1.0f / (float)(H * W));
+        if (p.dfeat) {  // wave-uniform: d z . W_fc of every frame was made by a GEMM (see conv_wgrad_kernel, FCX)
+          if (tid < COUT) s_dfeat[tid] = pm.df * (1.0f / (float)(H * W));
+        } else {
+          if (tid < p.E) s_dz[tid] = pm.dz;
+          __syncthreads();
+          for (int c = tid; c < COUT; c += NT) {
+            float s = 0.f;
+            for (int e = 0; e < p.E; ++e) s += s_dz[e] * p.wfc[e * COUT + c];
+            s_dfeat[c] = s * (1.0f / (float)(H * W));
+          }
         }
         __syncthreads();
         pm.commit(s_dfeat, dyi, ID::at(0, 0), ID::RS, ID::PS, W, tid);
@@ -1002,6 +1023,25 @@ extern "C" int ss_c5_conv_last_wgrad(const uint16_t* a_in, const float* dz, int 
   p.N = N; p.a_in = a_in; p.dz = dz; p.ld_dz = ld_dz; p.E = E; p.wfc = wfc; p.mask = mask; p.feat = feat;
   p.g_w = g_w; p.g_b = g_b; p.g_wfc = g_wfc; p.g_bfc = g_bfc;
   return launch_persistent(conv_wgrad_kernel<C3, C4, 12, 12, true, 12, 2, 4, 1>, p, wgrad_lds<C3, C4, 12, 12>(), N,
+                           static_cast<hipStream_t>(stream));
+}
+
+// The same two with d feat * 144 = d z . W_fc of every frame ready-made (dfeat (N, 96) f32: one small GEMM in front of them); the fc
+// gradients (g_wfc = d z^T . feat, g_bfc = column sums of d z) are then the caller's GEMMs as well.
+extern "C" int ss_c5_conv_last_wgrad_df(const uint16_t* a_in, const float* dfeat, const uint8_t* mask, int N, float* g_w, float* g_b,
+                                        ss_stream_t stream) {
+  SS_REQUIRE(a_in && dfeat && mask && g_w && g_b && N > 0, SS_ERR_ARG);
+  ConvBwdParams p{};
+  p.N = N; p.a_in = a_in; p.dfeat = dfeat; p.mask = mask; p.g_w = g_w; p.g_b = g_b;
+  return launch_persistent(conv_wgrad_kernel<C3, C4, 12, 12, true, 12, 2, 4, 1, false, 2, true>, p, wgrad_lds<C3, C4, 12, 12>(), N,
+                           static_cast<hipStream_t>(stream));
+}
+extern "C" int ss_c5_conv_last_dgrad_df(const float* dfeat, const uint8_t* mask, int N, const float* w, uint16_t* da_in,
+                                        ss_stream_t stream) {
+  SS_REQUIRE(dfeat && mask && w && da_in && N > 0, SS_ERR_ARG);
+  ConvBwdParams p{};
+  p.N = N; p.dfeat = dfeat; p.mask = mask; p.w = w; p.da_in = da_in;
+  return launch_persistent(conv_dgrad_kernel<C3, C4, 12, 12, true, 12, 3, false>, p, dgrad_lds<C3, C4, 12, 12, false>(), N,
                            static_cast<hipStream_t>(stream));
 }
 

@@ -57,6 +57,9 @@ def split_k(M, N, K, batch, target_wgs=None):
 # launches with K slices and float atomics.  SS_C5_DW_GROUP=0: always the latter (the form of the first half of round 3).
 # conv1's pool winners (37 KB per frame) stashed by the forward kernel for the fused conv2-dgrad / conv1-wgrad kernel (0: recomputed there)
 STASH_I1 = os.environ.get("SS_C5_STASH_I1", "1") != "0"
+# Linear(96 -> roi_emb) behind the CNN and its gradients as GEMMs over all frames instead of per-frame loops inside the last layer's
+# persistent kernels (0: inside the kernels, the form of the first half of round 3)
+FC_AS_GEMM = os.environ.get("SS_C5_FC_GEMM", "1") != "0"
 USE_DW_GROUP = os.environ.get("SS_C5_DW_GROUP", "1") != "0"
 # d layer_in = dGi_f W_ih_f + dGi_r W_ih_r as one product with K concatenated (plain stores, no cleared destination, no atomics)
 USE_DX_KCAT = os.environ.get("SS_C5_DX_KCAT", "1") != "0"
@@ -156,6 +159,7 @@ class WorkspaceBf16:
         self.mid = torch.empty(B, cfg.head_mid, **f32)
         if cfg.use_roi:
             c1, c2, c3, c4 = CNN_CHANNELS
+            self.feat = torch.empty(N, c4, **f32)
             # (the pooled conv1 map never reaches HBM: conv1 lands in conv2's LDS image and is recomputed in the backward pass)
             self.a2 = torch.empty(N, 24, 24, c2, **i16)
             self.i2 = torch.empty(N, 24, 24, c2, **u8)
@@ -185,7 +189,7 @@ class WorkspaceBf16:
                 self.st = torch.empty(N, 2, **f32)
                 self.i1 = torch.empty(N, 48, 48, c1, **u8) if (STASH_I1 and FUSE_DGRAD2_WGRAD1) else None
                 self.m4 = torch.empty(N, 144, c4, **u8)
-                self.feat = torch.empty(N, c4, **f32)
+                self.dfeat = torch.empty(N, c4, **f32)
                 self.da1 = torch.empty(N, 48, 48, c1, **i16) if not FUSE_DGRAD2_WGRAD1 else None
                 self.da2 = torch.empty(N, 24, 24, c2, **i16)
                 self.da3 = torch.empty(N, 12, 12, c3, **i16)
@@ -208,9 +212,18 @@ def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
         L.call("ss_c5_conv12_fwd_i1", R.data_ptr(), N, int(cfg.roi_standardize), w[0], b[0], w[1], b[1], ws.a2.data_ptr(), ws.i2.data_ptr(),
                ws.st.data_ptr() if stash else None, L.ptr(ws.i1) if stash else None, s, tag="ss_c5_conv12_fwd")
         L.call("ss_c5_conv_fwd", 3, ws.a2.data_ptr(), N, w[2], b[2], ws.a3.data_ptr(), ws.i3.data_ptr(), s, tag="ss_c5_conv3_fwd")
-        L.call("ss_c5_conv_last_fwd", ws.a3.data_ptr(), N, w[3], b[3], P["roi_cnn.fc.weight"].data_ptr(), P["roi_cnn.fc.bias"].data_ptr(),
-               cfg.roi_emb, _addr(ws.Z, cfg.x_dim), cfg.in_dim, ws.m4.data_ptr() if stash else None,
-               ws.feat.data_ptr() if stash else None, s)
+        if FC_AS_GEMM:
+            from .engine import gemm as gemm_f32
+
+            c4 = CNN_CHANNELS[3]
+            L.call("ss_c5_conv_last_fwd_feat", ws.a3.data_ptr(), N, w[3], b[3], ws.m4.data_ptr() if stash else None, ws.feat.data_ptr(), s,
+                   tag="ss_c5_conv_last_fwd")
+            gemm_f32(1, 1, N, cfg.roi_emb, c4, ws.feat.data_ptr(), c4, P["roi_cnn.fc.weight"].data_ptr(), c4, _addr(ws.Z, cfg.x_dim),
+                     cfg.in_dim, bias=P["roi_cnn.fc.bias"].data_ptr(), tag="gemm_fc")
+        else:
+            L.call("ss_c5_conv_last_fwd", ws.a3.data_ptr(), N, w[3], b[3], P["roi_cnn.fc.weight"].data_ptr(), P["roi_cnn.fc.bias"].data_ptr(),
+                   cfg.roi_emb, _addr(ws.Z, cfg.x_dim), cfg.in_dim, ws.m4.data_ptr() if stash else None,
+                   ws.feat.data_ptr() if stash else None, s)
         if ws.train and ws.stagger:  # only when another micro-batch waits for it (train.Trainer)
             ws.ev_cnn_fwd.record()
         layer_in, ld_in = ws.Z.data_ptr(), cfg.in_dim
@@ -364,9 +377,31 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         gb = [G[k + ".bias"].data_ptr() for k in _CONV]
         dz = _addr(ws.dZ, cfg.x_dim)
         wfc = P["roi_cnn.fc.weight"].data_ptr()
-        L.call("ss_c5_conv_last_wgrad", ws.a3.data_ptr(), dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), ws.feat.data_ptr(), N,
-               gw[3], gb[3], G["roi_cnn.fc.weight"].data_ptr(), G["roi_cnn.fc.bias"].data_ptr(), s)
-        L.call("ss_c5_conv_last_dgrad", dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), N, w[3], ws.da3.data_ptr(), s)
+        if FC_AS_GEMM:
+            from .engine import split_k as split_k_f32
+
+            c4, E = CNN_CHANNELS[3], cfg.roi_emb
+            gemm_f32(1, 0, N, c4, E, dz, cfg.in_dim, wfc, c4, ws.dfeat.data_ptr(), c4, tag="gemm_fc")  # d z . W_fc
+
+            def fc_grads():  # d W_fc += d z^T . feat, d b_fc += column sums of d z
+                gemm_f32(0, 0, E, c4, N, dz, cfg.in_dim, ws.feat.data_ptr(), c4, G["roi_cnn.fc.weight"].data_ptr(), c4, accumulate=True,
+                         atomic=True, splits=split_k_f32(E, c4, N), a_colsum=G["roi_cnn.fc.bias"].data_ptr(), tag="gemm_fc")
+
+            if USE_SIDE_STREAM:
+                ws.ev_fork.record()
+                with torch.cuda.stream(ws.side):
+                    ws.side.wait_event(ws.ev_fork)
+                    fc_grads()
+            else:
+                fc_grads()
+            L.call("ss_c5_conv_last_wgrad_df", ws.a3.data_ptr(), ws.dfeat.data_ptr(), ws.m4.data_ptr(), N, gw[3], gb[3], s,
+                   tag="ss_c5_conv_last_wgrad")
+            L.call("ss_c5_conv_last_dgrad_df", ws.dfeat.data_ptr(), ws.m4.data_ptr(), N, w[3], ws.da3.data_ptr(), s,
+                   tag="ss_c5_conv_last_dgrad")
+        else:
+            L.call("ss_c5_conv_last_wgrad", ws.a3.data_ptr(), dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), ws.feat.data_ptr(), N,
+                   gw[3], gb[3], G["roi_cnn.fc.weight"].data_ptr(), G["roi_cnn.fc.bias"].data_ptr(), s)
+            L.call("ss_c5_conv_last_dgrad", dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), N, w[3], ws.da3.data_ptr(), s)
         L.call("ss_c5_conv_wgrad", 3, ws.a2.data_ptr(), ws.da3.data_ptr(), ws.i3.data_ptr(), N, gw[2], gb[2], s, tag="ss_c5_conv3_wgrad")
         L.call("ss_c5_conv_dgrad", 3, ws.da3.data_ptr(), ws.i3.data_ptr(), N, w[2], ws.da2.data_ptr(), s, tag="ss_c5_conv3_dgrad")
         bb = [P[k + ".bias"].data_ptr() for k in _CONV]

@@ -506,6 +506,15 @@ def test_c5_conv_last_fwd(L, N, wg_cap):
            z2.data_ptr(), E, None, None, L.stream())
     torch.cuda.synchronize()
     assert float((z2.cpu() - z_ref).abs().max()) < 5e-5
+    # the form the engine runs: features only (the Linear is a GEMM over all frames), with and without the mask
+    for m_ptr in (mask, None):
+        fo2 = torch.zeros(N, 96, device="cuda")
+        m2 = torch.full_like(mask, 7)
+        L.call("ss_c5_conv_last_fwd_feat", a_d.data_ptr(), N, w_d.data_ptr(), b_d.data_ptr(), m2.data_ptr() if m_ptr is not None else None,
+               fo2.data_ptr(), L.stream())
+        torch.cuda.synchronize()
+        assert float((fo2 - fo).abs().max()) < 1e-6  # (the average is summed with LDS float atomics: order varies)
+        assert m_ptr is None or torch.equal(m2, mask)
 
 
 @pytest.mark.parametrize("layer,N", [(2, 2), (2, 270), (3, 3), (3, 300)])
@@ -571,6 +580,16 @@ def test_c5_conv_last_bwd(L, N, wg_cap):
     assert float((gwfc.cpu() - gwfc_ref).abs().max()) < 1e-4 * float(gwfc_ref.abs().max())
     assert float((gbfc.cpu() - gbfc_ref).abs().max()) < 1e-4 * float(gbfc_ref.abs().max())
     assert_bf16_close("da3", from_nhwc(din), din_ref, frac_exact=0.98)
+    # the form the engine runs: d z . W_fc ready-made for every frame (a GEMM), the fc gradients elsewhere
+    df_d = (dz[:, 84:] @ wfc).contiguous().cuda()
+    gw2, gb2 = torch.zeros_like(gw), torch.zeros_like(gb)
+    din2 = torch.empty_like(din)
+    L.call("ss_c5_conv_last_wgrad_df", a_d.data_ptr(), df_d.data_ptr(), m_d.data_ptr(), N, gw2.data_ptr(), gb2.data_ptr(), L.stream())
+    L.call("ss_c5_conv_last_dgrad_df", df_d.data_ptr(), m_d.data_ptr(), N, w_d.data_ptr(), din2.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert float((gw2.cpu() - gw_ref).abs().max()) < 3e-4 * float(gw_ref.abs().max())
+    assert float((gb2.cpu() - gb_ref).abs().max()) < 3e-4 * float(gb_ref.abs().max())
+    assert_bf16_close("da3", from_nhwc(din2), din_ref, frac_exact=0.98)
 
 
 @pytest.mark.parametrize("N", [2, 300])

@@ -65,6 +65,20 @@ def main():
     report("conv2_dgrad_conv1_wgrad", read(fbwd), {15: "frame top", 0: "frame images", 1: "dy expand commit", 2: "barrier", 3: "issue + d a1 MFMAs + oa stores",
                                                    4: "conv1 rows (pool winners)", 5: "barrier", 6: "slot-masked images of a half band", 7: "barrier",
                                                    8: "conv1-wgrad MFMAs of a half band", 9: "barrier"}, reps)
+    # ---- the last layer's weight gradient (12 x 12 x 64 -> 96): per-frame stages
+    a3 = torch.randint(-300, 300, (N, 12, 12, 64), device=dev, dtype=torch.int16)
+    dz = torch.randn(N, 64, device=dev)
+    wfc = torch.randn(64, 96, device=dev) / 10
+    m4 = torch.randint(0, 2, (N, 144, 96), device=dev, dtype=torch.uint8)
+    feat = torch.rand(N, 96, device=dev)
+    gw4, gb4 = torch.zeros(96, 64, 3, 3, device=dev), torch.zeros(96, device=dev)
+    gwf, gbf = torch.zeros(64, 96, device=dev), torch.zeros(64, device=dev)
+    read(fbwd)
+    for _ in range(reps):
+        L.call("ss_c5_conv_last_wgrad", a3.data_ptr(), dz.data_ptr(), 64, 64, wfc.data_ptr(), m4.data_ptr(), feat.data_ptr(), N, gw4.data_ptr(),
+               gb4.data_ptr(), gwf.data_ptr(), gbf.data_ptr(), L.stream())
+    report("conv_last_wgrad", read(fbwd), {15: "frame top", 0: "-", 1: "d feat, fc gradients, dy image from the sign mask", 2: "a_in commit", 3: "barrier",
+                                           4: "issue of the next frame's loads", 5: "MFMAs", 6: "barrier"}, reps)
 
 
 if __name__ == "__main__":
