@@ -12,6 +12,8 @@
 //                        straight into the (B,T,x_dim+E) GRU input (the torch.cat of train_model_official.py:297)
 //
 // Replaces /root/reference/train_model_official.py:286-291 (normalise) and :212-229 (CNN) for the wider model.
+#include <stdlib.h>
+
 #include "cnn_bf16.h"
 
 extern int ss_cnn_max_wgs;  // roi_cnn.hip: test hook, workgroups per launch (0 = one per CU)
@@ -240,12 +242,18 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
 
   BandLoad<IM, H, H> pre;  // the next frame, on its way while this one is computed
   if ((int)blockIdx.x < p.N) pre.issue(p.in + (long)blockIdx.x * H * W * CIN, 0, tid);
+  STAMP_ENTRY;
+  STAMP_DECL;
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+    STAMP(15);
     pre.commit(img, 0, tid);
     if (LAST)
       for (int q = tid; q < COUT; q += NT) s_feat[q] = 0.f;
+    STAMP(0);
     __syncthreads();
+    STAMP(1);
     if (n + (int)gridDim.x < p.N) pre.issue(p.in + (long)(n + gridDim.x) * H * W * CIN, 0, tid);
+    STAMP(2);
     for (int u = wv; u < UNITS; u += NW) {
       const int mg = u % (MTILES / MT), ng = u / (MTILES / MT);
       int base[MT];
@@ -325,7 +333,9 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
         }
       }
     }
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
     if (LAST) {
       if (p.mask) {
         uint4* dm = reinterpret_cast<uint4*>(p.mask + (long)n * H * W * COUT);
@@ -353,7 +363,191 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
       for (int q = tid; q < HO * WO * COUT / 16; q += NT) di[q] = reinterpret_cast<const uint4*>(oi)[q];
       // no barrier: the next frame's load writes img only, and its epilogue writes oa / oi behind the barrier after that load
     }
+    STAMP(5);
   }
+  STAMP_FLUSH();
+}
+
+// ------------------------------------------------------------------------------------------------ layer 4, weight-stationary
+// conv 64 -> 96 on the 12 x 12 map: 110 KB of bf16 weights for 18 KB of input per frame.  conv_fwd_kernel keeps the weights in LDS,
+// which leaves room for ONE frame: load, multiply, mask copy-out and average are phases of one workgroup with barriers between
+// them, six of eight waves multiply (11.9 k cycles per frame for 3.9 k cycles of MFMA, stage timers of round 3).  Here the weights
+// live in REGISTERS as the A operand of the transposed product D[co][pixel]: a consumer wave holds the 32 output channels of its
+// channel group = 2 x 18 fragments (144 registers) for the whole walk and multiplies them with some of the frame's nine pixel
+// tiles (16 consecutive pixels each: conv_fwd's A-fragment read as the B operand), 36 MFMAs and 18 fragment reads per tile.  Waves 6 and 7 are PRODUCERS: they write the next frame (loaded a whole frame time earlier) into the other
+// image, copy the previous frame's sign mask out and finish its average; one workgroup barrier per frame.
+struct ConvLastWsParams {
+  const bf16_t* in;   // (N, 12, 12, 64)
+  int N;
+  const float *w, *b; // (96, 64, 3, 3), (96)
+  uint8_t* mask;      // (N, 144, 96) or null
+  float* feat;        // (N, 96)
+};
+constexpr int L4_IMG = Img<C3, 12, 12>::BYTES, L4_MASK = 144 * C4;
+constexpr int L4_O_MASK = 2 * L4_IMG, L4_O_FEAT = L4_O_MASK + 2 * L4_MASK;
+constexpr int L4_O_BIAS = L4_O_FEAT + 2 * C4 * 4;
+constexpr int L4_LDS_RUN = L4_O_BIAS + C4 * 4;
+constexpr int CONV_LAST_WS_LDS = (Wmat<C3, C4>::BYTES > L4_LDS_RUN) ? Wmat<C3, C4>::BYTES : L4_LDS_RUN;
+
+__global__ __launch_bounds__(NT, 2) void conv_last_fwd_ws_kernel(ConvLastWsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using IM = Img<C3, 12, 12>;
+  using WM = Wmat<C3, C4>;
+  constexpr int NPIX = 144, NCONS = 6, NPT = (NW - NCONS) * 64;  // consumer waves; producer threads
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wv < NCONS;
+  // consumer roles.  Waves w and w + 4 of a workgroup share a SIMD (the hardware deals waves to SIMDs in a fixed cyclic order), so
+  // waves 0 / 4 and 1 / 5 sit together while 2 and 3 each share with a producer: three channel groups over four SIMDs balance as
+  //   wave:            0      1      2      3      4      5
+  //   channel group:   0      1      0      1      2      2
+  //   pixel tiles:   [0,2)  [0,2)  [2,9)  [2,9)  [0,4)  [4,9)      -> 6 / 7 / 7 / 7 tiles of 36 MFMAs per SIMD
+  // (halves of the frame per group, 5 + 4 tiles, put 9 tiles on two of the SIMDs: 8.0 k cycles per frame in the stage timers)
+  const int cg = wv < 4 ? (wv & 1) : 2;
+  const int t0 = wv < 2 ? 0 : wv < 4 ? 2 : wv == 4 ? 0 : 4;
+  const int ntile = wv < 2 ? 2 : wv < 4 ? 7 : wv == 4 ? 4 : 5;
+  constexpr int MAXT = 7;
+
+  // ---- the weights: staged through LDS once ([co][tap * 64 + ci] bf16), then this wave's 36 A fragments into registers
+  stage_weights<C3, C4>(p.w, reinterpret_cast<bf16_t*>(smem), tid);
+  __syncthreads();
+  s16x8 wf[2][WM::KSTEPS];
+  if (consumer) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < WM::KSTEPS; ++s)
+        wf[j][s] = lds_frag(reinterpret_cast<const bf16_t*>(smem) + (32 * cg + 16 * j + li) * WM::LD + 32 * s + 8 * g);
+  }
+  __syncthreads();
+  zero_lds(smem, L4_LDS_RUN, tid);
+  bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
+  uint8_t* msk0 = smem + L4_O_MASK;
+  float* sf0 = reinterpret_cast<float*>(smem + L4_O_FEAT);
+  float* s_bias = reinterpret_cast<float*>(smem + L4_O_BIAS);  // (an accumulator starts from its four channels' biases: one 16-byte read)
+  __syncthreads();
+  if (tid < C4) s_bias[tid] = p.b[tid];
+
+  // this lane's pixel of each of its (up to 5) tiles: B-fragment base = pixel (y - 1, x - 1), channel chunk g
+  int base[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int P = 16 * (t0 + t) + li, Pc = P < NPIX ? P : NPIX - 1;
+    base[t] = IM::at(Pc / 12 - 1, Pc % 12 - 1) + 8 * g;
+  }
+
+  // producers: a frame is 144 pixels x 8 pieces of 16 bytes = 1152 pieces, 9 per producer thread
+  // (in three rounds of three pieces: nine quads of staging registers beside the consumers' 144 weight registers spilled; the
+  // frame was touched a pass earlier -- below -- so a round costs an L2 hit, not an HBM miss)
+  constexpr int NLD = (NPIX * (C3 / 8) + NPT - 1) / NPT, NRD = 3;
+  static_assert(NLD % NRD == 0, "load rounds");
+  const int pt = tid - NCONS * 64;
+  auto copy_frame = [&](int n, bf16_t* img) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.in + (long)n * NPIX * C3);
+#pragma unroll
+    for (int rd = 0; rd < NLD / NRD; ++rd) {
+      uint4 fr[NRD];
+#pragma unroll
+      for (int k = 0; k < NRD; ++k) fr[k] = src[pt + (rd * NRD + k) * NPT];
+#pragma unroll
+      for (int k = 0; k < NRD; ++k) {
+        const int q = pt + (rd * NRD + k) * NPT, pix = q >> 3, c8 = q & 7;
+        *reinterpret_cast<uint4*>(img + IM::at(pix / 12, pix % 12) + 8 * c8) = fr[k];
+      }
+    }
+  };
+  static_assert(NLD * NPT == NPIX * (C3 / 8), "a frame is a whole number of pieces per producer thread");
+  __syncthreads();
+  // prologue: frame 0 into image 0
+  const int n0 = blockIdx.x, stride = gridDim.x;
+  if (!consumer && n0 < p.N) copy_frame(n0, img0);
+  __syncthreads();
+
+  int it = 0;
+  STAMP_ENTRY;
+  STAMP_DECL;
+  for (int n = n0; n < p.N + stride; n += stride, ++it) {  // one extra pass: the producers finish the last frame
+    STAMP(15);
+    const int cur = it & 1;
+    if (consumer) {
+      if (n < p.N) {
+        const bf16_t* img = img0 + cur * (L4_IMG / 2);
+        uint8_t* msk = msk0 + cur * L4_MASK;
+        float fs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          if (t < ntile) {  // wave-uniform
+            f32x4 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = *reinterpret_cast<const f32x4*>(s_bias + 32 * cg + 16 * j + 4 * g);
+            // the pixel fragments run RD k steps ahead of their MFMAs behind scheduling fences: left alone hipcc reads a fragment,
+            // waits lgkmcnt(0) and multiplies -- an LDS latency per pair of MFMAs, and a consumer wave has its SIMD (nearly) to itself
+            constexpr int RD = 4;
+            s16x8 fb[RD];
+#pragma unroll
+            for (int s = 0; s < RD; ++s) fb[s] = lds_frag(img + base[t] + koff<IM>(s, 0));
+#pragma unroll
+            for (int s = 0; s < WM::KSTEPS; ++s) {
+              SS_SCHED_FENCE();
+              acc[0] = mfma_bf16(wf[0][s], fb[s % RD], acc[0]);
+              acc[1] = mfma_bf16(wf[1][s], fb[s % RD], acc[1]);
+              SS_SCHED_FENCE();
+              if (s + RD < WM::KSTEPS) fb[s % RD] = lds_frag(img + base[t] + koff<IM>(s + RD, 0));
+            }
+            // D row 4 g + r = channel, column li = pixel: four consecutive channels of one pixel per lane
+            const int P = 16 * (t0 + t) + li;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              unsigned mb = 0;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float x = acc[j][r];
+                mb |= (x > 0.f ? 1u : 0u) << (8 * r);
+                fs[j][r] += fmaxf(x, 0.f);
+              }
+              *reinterpret_cast<unsigned*>(msk + P * C4 + 32 * cg + 16 * j + 4 * g) = mb;
+            }
+          }
+        }
+        // the average: sum over the 16 pixels of a lane row (DPP), the two pixel halves meet in LDS
+        float* sf = sf0 + cur * C4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = row_sum(fs[j][r]);
+            if (li == 0) atomicAdd(sf + 32 * cg + 16 * j + 4 * g + r, v);
+          }
+      }
+    } else {
+      // the frame after the next is TOUCHED (one dword per 128-byte line, two registers): the real loads of the next pass then
+      // find it in L2 instead of paying an HBM miss inside the pass
+      if (n + 2 * stride < p.N) {
+        const unsigned* t = reinterpret_cast<const unsigned*>(p.in + (long)(n + 2 * stride) * NPIX * C3);
+        const unsigned t0 = t[32 * pt], t1 = pt < NPIX - NPT ? t[32 * (pt + NPT)] : 0u;
+        asm volatile("" ::"v"(t0), "v"(t1));
+      }
+      // the previous frame's mask and average leave (its buffers are this pass's `cur ^ 1`)
+      if (it > 0) {
+        const long np = n - stride;
+        float* sf = sf0 + (cur ^ 1) * C4;
+        if (p.mask) {
+          const uint4* ms = reinterpret_cast<const uint4*>(msk0 + (cur ^ 1) * L4_MASK);
+          uint4* dm = reinterpret_cast<uint4*>(p.mask + np * L4_MASK);
+          for (int q = pt; q < L4_MASK / 16; q += NPT) dm[q] = ms[q];
+        }
+        if (pt < C4) {
+          p.feat[np * C4 + pt] = sf[pt] * (1.0f / (float)NPIX);
+          sf[pt] = 0.f;
+        }
+      }
+      if (n + stride < p.N) copy_frame(n + stride, img0 + (cur ^ 1) * (L4_IMG / 2));
+    }
+    STAMP(0);  // (thread 0 is a consumer: its multiply phase, then its wait for the producers)
+    __syncthreads();
+    STAMP(1);
+  }
+  STAMP_FLUSH();
 }
 
 template <int CIN, int COUT, int H, int W, bool LAST>
@@ -585,10 +779,16 @@ extern "C" int ss_c5_conv12_fwd(const uint8_t* R, int N, int standardize, const 
   return ss_c5_conv12_fwd_i1(R, N, standardize, w1, b1, w2, b2, a2, i2, st, nullptr, stream);
 }
 
+static const bool ss_c5_last_ws = !(getenv("SS_C5_LAST_WS") && getenv("SS_C5_LAST_WS")[0] == '0');
+
 // layer 4 without the Linear: feat (N, 96) f32 = global average of ReLU(conv4), mask (N,144,96) u8 or null
 extern "C" int ss_c5_conv_last_fwd_feat(const uint16_t* in, int N, const float* w, const float* b, uint8_t* mask, float* feat,
                                         ss_stream_t stream) {
   SS_REQUIRE(in && w && b && feat && N > 0, SS_ERR_ARG);
+  if (ss_c5_last_ws) {  // weight-stationary form (SS_C5_LAST_WS=0: the LDS-resident weights of conv_fwd_kernel)
+    ConvLastWsParams q{in, N, w, b, mask, feat};
+    return launch_persistent(conv_last_fwd_ws_kernel, q, CONV_LAST_WS_LDS, N, static_cast<hipStream_t>(stream));
+  }
   ConvFwdParams p{};
   p.in = in; p.N = N; p.w = w; p.b = b; p.mask = mask; p.feat = feat;
   return launch_persistent(conv_fwd_kernel<C3, C4, 12, 12, true, 3, 3>, p, conv_fwd_lds<C3, C4, 12, 12, true>(), N,

@@ -15,6 +15,8 @@
 // dy is rebuilt in LDS from the pooled-grid gradient + the argmax bytes (pooled layers) or from d feat + the sign mask
 // (last layer).  Large maps are processed in row bands so that dy (dense, bf16) fits beside the other operand.
 //   conv1 wgrad: 1 input channel -- a GEMM on the pooled grid against the 4 x 4 input patch under every pool window.
+#include <stdlib.h>
+
 #include "cnn_bf16.h"
 
 extern int ss_cnn_max_wgs;  // roi_cnn.hip: test hook, workgroups per launch (0 = one per CU)
@@ -467,8 +469,11 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
     }
   };
   if ((int)blockIdx.x < p.N) issue(blockIdx.x, 0);
+  STAMP_ENTRY;
+  STAMP_DECL;
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     for (int y0 = 0; y0 < H; y0 += BH) {
+      STAMP(15);
       if (LAST) {
         if (p.dfeat) {  // wave-uniform: d z . W_fc of every frame was made by a GEMM (see conv_wgrad_kernel, FCX)
           if (tid < COUT) s_dfeat[tid] = pm.df * (1.0f / (float)(H * W));
@@ -486,12 +491,15 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
       } else {
         pe.commit(dyi, ID::at(-1, 0), ID::RS, ID::PS, y0 - 1, tid);
       }
+      STAMP(0);
       __syncthreads();
+      STAMP(1);
       {
         const bool last_band = y0 + BH >= H;
         const int nn = last_band ? n + (int)gridDim.x : n;
         if (nn < p.N) issue(nn, last_band ? 0 : y0 + BH);
       }
+      STAMP(2);
       for (int u = wv; u < UNITS; u += NW) {
         const int mg = u % (MTILES / MT), nt = u / (MTILES / MT);
         int base[MT];
@@ -520,13 +528,129 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) od[(16 * (mg * MT + a) + 4 * g + r) * CIN + 16 * nt + li] = to_bf16(acc[a][r]);
       }
+      STAMP(3);
       __syncthreads();
+      STAMP(4);
       if (STAGE) {
         uint4* dst = reinterpret_cast<uint4*>(p.da_in + ((long)n * H + y0) * W * CIN);
         for (int q = tid; q < BH * W * CIN * 2 / 16; q += NT) dst[q] = reinterpret_cast<const uint4*>(oa)[q];
         // no barrier: the next band's commit rewrites dy only; its epilogue writes the staging area behind the barrier after that
       }
+      STAMP(5);
     }
+  }
+  STAMP_FLUSH();
+}
+
+// ------------------------------------------------------------------------------------------------ layer 4 dgrad, weight-stationary
+// d a3 = conv_transpose(dy4, W4) on the 12 x 12 map.  conv_dgrad_kernel keeps the 110 KB of flipped weights in LDS beside ONE dy
+// image: load, mask expansion, multiply and store are phases of one workgroup (13.4 k cycles per frame for 3.9 k of MFMA, stage
+// timers of round 3).  Here (as conv_last_fwd_ws_kernel, cnn_bf16.hip) the weights live in registers as the A operand of the
+// transposed product D[ci][pixel]: wave (c, h) holds input-channel tile c = 16 rows x 27 k steps (108 registers) for the whole walk
+// and multiplies it with the pixel tiles of half h of the frame (5 + 4 tiles: waves w and w + 4 share a SIMD, 243 MFMAs per SIMD
+// and frame); a lane ends up with four consecutive channels of one pixel = one 8-byte store.  The freed LDS holds TWO dy images:
+// every wave expands the next frame's sign mask (loaded at the top of the pass) into the other image behind its multiplications;
+// one barrier per frame.  d feat rows travel two passes ahead through a ring of three LDS rows.
+struct ConvLastDgradWsParams {
+  int N;
+  const float* dfeat;   // (N, 96) d z . W_fc (unscaled)
+  const uint8_t* mask;  // (N, 144, 96)
+  const float* w;       // (96, 64, 3, 3)
+  bf16_t* da_in;        // (N, 12, 12, 64)
+};
+constexpr int L4D_IMG = Img<C4, 12, 12>::BYTES;
+constexpr int L4D_O_DF = 2 * L4D_IMG;
+constexpr int L4D_LDS_RUN = L4D_O_DF + 3 * C4 * 4;
+constexpr int CONV_LAST_DGRAD_WS_LDS = (Wmat<C4, C3>::BYTES > L4D_LDS_RUN) ? Wmat<C4, C3>::BYTES : L4D_LDS_RUN;
+
+__global__ __launch_bounds__(NT, 2) void conv_last_dgrad_ws_kernel(ConvLastDgradWsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using ID = Img<C4, 12, 12>;
+  using WM = Wmat<C4, C3>;  // [ci][tap' * 96 + co], 27 k steps
+  constexpr int NPIX = 144, W = 12;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cit = wv & 3, ph = wv >> 2;
+  const int t0 = ph ? 5 : 0, ntile = ph ? 4 : 5;
+
+  // ---- flipped, transposed weights through LDS once (conv_dgrad_kernel's image), this wave's 27 A fragments into registers
+  {
+    bf16_t* wl = reinterpret_cast<bf16_t*>(smem);
+    for (int q = tid; q < C3 * WM::KP; q += NT) {
+      const int ci = q / WM::KP, kk = q % WM::KP, tap = kk / C4, co = kk % C4;
+      wl[ci * WM::LD + kk] = to_bf16(tap < 9 ? p.w[((long)co * C3 + ci) * 9 + (8 - tap)] : 0.f);
+    }
+  }
+  __syncthreads();
+  s16x8 wf[WM::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < WM::KSTEPS; ++s) wf[s] = lds_frag(reinterpret_cast<const bf16_t*>(smem) + (16 * cit + li) * WM::LD + 32 * s + 8 * g);
+  __syncthreads();
+  zero_lds(smem, L4D_LDS_RUN, tid);
+  bf16_t* dy0 = reinterpret_cast<bf16_t*>(smem);
+  float* sdf = reinterpret_cast<float*>(smem + L4D_O_DF);  // [3][96]: d feat / 144 of frames i, i + 1, i + 2
+  constexpr float inv_hw = 1.0f / (float)NPIX;
+
+  int base[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int P = 16 * (t0 + t) + li, Pc = P < NPIX ? P : NPIX - 1;
+    base[t] = ID::at(Pc / W - 1, Pc % W - 1) + 8 * g;
+  }
+  MaskLoad<C4, NPIX> pm;
+  const int n0 = blockIdx.x, stride = gridDim.x;
+  auto frame = [&](int k) { return n0 + (long)k * stride; };  // k-th frame of this workgroup
+  float dfreg = 0.f;
+  __syncthreads();
+  // prologue: d feat rows of frames 0 and 1 into the ring, frame 2's on its way, frame 0's dy image
+  if (tid < C4) {
+    if (frame(0) < p.N) sdf[tid] = p.dfeat[frame(0) * C4 + tid] * inv_hw;
+    if (frame(1) < p.N) sdf[C4 + tid] = p.dfeat[frame(1) * C4 + tid] * inv_hw;
+    if (frame(2) < p.N) dfreg = p.dfeat[frame(2) * C4 + tid];
+  }
+  if (frame(0) < p.N) pm.issue(p.mask + frame(0) * NPIX * C4, nullptr, 0, nullptr, tid);
+  __syncthreads();
+  if (frame(0) < p.N) pm.commit(sdf, dy0, ID::at(0, 0), ID::RS, ID::PS, W, tid);
+  __syncthreads();
+
+  for (int it = 0; frame(it) < p.N; ++it) {
+    const long n = frame(it);
+    const int cur = it & 1;
+    // top of the pass: frame it + 2's d feat row into the ring (read by the expansion of pass it + 1, a barrier later), frame
+    // it + 3's on its way; the next frame's sign mask on its way (expanded behind the multiplications below)
+    if (tid < C4) {
+      if (frame(it + 2) < p.N) sdf[((it + 2) % 3) * C4 + tid] = dfreg * inv_hw;
+      if (frame(it + 3) < p.N) dfreg = p.dfeat[frame(it + 3) * C4 + tid];
+    }
+    const bool more = frame(it + 1) < p.N;
+    if (more) pm.issue(p.mask + frame(it + 1) * NPIX * C4, nullptr, 0, nullptr, tid);
+    const bf16_t* dyi = dy0 + cur * (L4D_IMG / 2);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      if (t < ntile) {  // wave-uniform
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        constexpr int RD = 4;  // fragment reads RD k steps ahead of their MFMAs (see conv_last_fwd_ws_kernel)
+        s16x8 fb[RD];
+        auto koff = [&](int s) {
+          const int tap = (32 * s) / C4, c0 = (32 * s) % C4;
+          return (tap / 3) * ID::RS + (tap % 3) * ID::PS + c0;
+        };
+#pragma unroll
+        for (int s = 0; s < RD; ++s) fb[s] = lds_frag(dyi + base[t] + koff(s));
+#pragma unroll
+        for (int s = 0; s < WM::KSTEPS; ++s) {
+          SS_SCHED_FENCE();
+          acc = mfma_bf16(wf[s], fb[s % RD], acc);
+          SS_SCHED_FENCE();
+          if (s + RD < WM::KSTEPS) fb[s % RD] = lds_frag(dyi + base[t] + koff(s + RD));
+        }
+        // D row 4 g + r = input channel, column li = pixel: four consecutive channels of one pixel
+        const int P = 16 * (t0 + t) + li;
+        *reinterpret_cast<uint2*>(p.da_in + (n * NPIX + P) * C3 + 16 * cit + 4 * g) = pack_bf16x4(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+    if (more) pm.commit(sdf + ((it + 1) % 3) * C4, dy0 + (cur ^ 1) * (L4D_IMG / 2), ID::at(0, 0), ID::RS, ID::PS, W, tid);
+    __syncthreads();
   }
 }
 
@@ -847,6 +971,10 @@ __global__ __launch_bounds__(NT, 2) void conv2_dgrad_w1_kernel(Conv2DgradW1Param
       const bool last_band = y0 + F_BH >= H;
       // Two barriers per band.  Before the first: the dy band (from the prefetched registers) and conv1's pool winners of the band's
       // 8 row pairs (one per wave) -- both write what only the phase behind the barrier reads.
+#ifdef SS_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic build only: the wait for the band's loads apart from the expansion
+      STAMP(9);
+#endif
       pe.commit(dyi, F_ID::at(-1, 0), F_ID::RS, F_ID::PS, y0 - 1, tid);
       STAMP(1);
       if (p.i1) {  // wave-uniform
@@ -1026,6 +1154,8 @@ extern "C" int ss_c5_conv_last_wgrad(const uint16_t* a_in, const float* dz, int 
                            static_cast<hipStream_t>(stream));
 }
 
+static const bool ss_c5_last_ws = !(getenv("SS_C5_LAST_WS") && getenv("SS_C5_LAST_WS")[0] == '0');
+
 // The same two with d feat * 144 = d z . W_fc of every frame ready-made (dfeat (N, 96) f32: one small GEMM in front of them); the fc
 // gradients (g_wfc = d z^T . feat, g_bfc = column sums of d z) are then the caller's GEMMs as well.
 extern "C" int ss_c5_conv_last_wgrad_df(const uint16_t* a_in, const float* dfeat, const uint8_t* mask, int N, float* g_w, float* g_b,
@@ -1039,6 +1169,10 @@ extern "C" int ss_c5_conv_last_wgrad_df(const uint16_t* a_in, const float* dfeat
 extern "C" int ss_c5_conv_last_dgrad_df(const float* dfeat, const uint8_t* mask, int N, const float* w, uint16_t* da_in,
                                         ss_stream_t stream) {
   SS_REQUIRE(dfeat && mask && w && da_in && N > 0, SS_ERR_ARG);
+  if (ss_c5_last_ws) {  // weight-stationary form (SS_C5_LAST_WS=0: the LDS-resident weights of conv_dgrad_kernel)
+    ConvLastDgradWsParams q{N, dfeat, mask, w, da_in};
+    return launch_persistent(conv_last_dgrad_ws_kernel, q, CONV_LAST_DGRAD_WS_LDS, N, static_cast<hipStream_t>(stream));
+  }
   ConvBwdParams p{};
   p.N = N; p.dfeat = dfeat; p.mask = mask; p.w = w; p.da_in = da_in;
   return launch_persistent(conv_dgrad_kernel<C3, C4, 12, 12, true, 12, 3, false>, p, dgrad_lds<C3, C4, 12, 12, false>(), N,

@@ -513,8 +513,8 @@ def test_c5_conv_last_fwd(L, N, wg_cap):
         L.call("ss_c5_conv_last_fwd_feat", a_d.data_ptr(), N, w_d.data_ptr(), b_d.data_ptr(), m2.data_ptr() if m_ptr is not None else None,
                fo2.data_ptr(), L.stream())
         torch.cuda.synchronize()
-        assert float((fo2 - fo).abs().max()) < 1e-6  # (the average is summed with LDS float atomics: order varies)
-        assert m_ptr is None or torch.equal(m2, mask)
+        assert float((fo2.cpu() - feat).abs().max()) < 2e-5
+        assert m_ptr is None or torch.equal(m2.cpu().bool()[sure], m_ref[sure])
 
 
 @pytest.mark.parametrize("layer,N", [(2, 2), (2, 270), (3, 3), (3, 300)])

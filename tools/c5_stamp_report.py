@@ -62,7 +62,7 @@ def main():
     for _ in range(reps):
         L.call("ss_c5_conv2_dgrad_conv1_wgrad", da2.data_ptr(), i2.data_ptr(), N, w2.data_ptr(), R.data_ptr(), st.data_ptr(), 1, w1.data_ptr(),
                b1.data_ptr(), None, gw1.data_ptr(), gb1.data_ptr(), L.stream())
-    report("conv2_dgrad_conv1_wgrad", read(fbwd), {15: "frame top", 0: "frame images", 1: "dy expand commit", 2: "barrier", 3: "issue + d a1 MFMAs + oa stores",
+    report("conv2_dgrad_conv1_wgrad", read(fbwd), {15: "frame top", 0: "frame images", 9: "wait for the band's loads", 1: "dy expand commit", 2: "barrier", 3: "issue + d a1 MFMAs + oa stores",
                                                    4: "conv1 rows (pool winners)", 5: "barrier", 6: "slot-masked images of a half band", 7: "barrier",
                                                    8: "conv1-wgrad MFMAs of a half band", 9: "barrier"}, reps)
     # ---- the last layer's weight gradient (12 x 12 x 64 -> 96): per-frame stages
@@ -79,6 +79,42 @@ def main():
                gb4.data_ptr(), gwf.data_ptr(), gbf.data_ptr(), L.stream())
     report("conv_last_wgrad", read(fbwd), {15: "frame top", 0: "-", 1: "d feat, fc gradients, dy image from the sign mask", 2: "a_in commit", 3: "barrier",
                                            4: "issue of the next frame's loads", 5: "MFMAs", 6: "barrier"}, reps)
+    dfe = dz @ wfc
+    for _ in range(reps):
+        L.call("ss_c5_conv_last_wgrad_df", a3.data_ptr(), dfe.data_ptr(), m4.data_ptr(), N, gw4.data_ptr(), gb4.data_ptr(), L.stream())
+    report("conv_last_wgrad_df", read(fbwd), {15: "frame top", 0: "-", 1: "d feat, fc gradients, dy image from the sign mask", 2: "a_in commit", 3: "barrier",
+                                           4: "issue of the next frame's loads", 5: "MFMAs", 6: "barrier"}, reps)
+    # ---- generic forward / data-gradient kernels: layers 3 and 4
+    fnames = {15: "frame top", 0: "commit of the frame image", 1: "barrier", 2: "issue of the next frame", 3: "units: MFMAs + epilogue", 4: "barrier",
+              5: "copy-out / average"}
+    dnames = {15: "band top", 0: "dy image (expand / mask)", 1: "barrier", 2: "issue of the next band", 3: "units: MFMAs + stores", 4: "barrier",
+              5: "copy-out"}
+    a2 = torch.randint(-300, 300, (N, 24, 24, 32), device=dev, dtype=torch.int16)
+    w3, b3 = torch.randn(64, 32, 3, 3, device=dev) / 17, torch.randn(64, device=dev) * 0.1
+    w4, b4 = torch.randn(96, 64, 3, 3, device=dev) / 24, torch.randn(96, device=dev) * 0.1
+    a3o = torch.empty(N, 12, 12, 64, device=dev, dtype=torch.int16)
+    i3 = torch.empty(N, 12, 12, 64, device=dev, dtype=torch.uint8)
+    read(ffwd)
+    for _ in range(reps):
+        L.call("ss_c5_conv_fwd", 3, a2.data_ptr(), N, w3.data_ptr(), b3.data_ptr(), a3o.data_ptr(), i3.data_ptr(), L.stream())
+    report("conv3_fwd (2 workgroups per CU: x2)", read(ffwd), fnames, reps)
+    for _ in range(reps):
+        L.call("ss_c5_conv_last_fwd_feat", a3.data_ptr(), N, w4.data_ptr(), b4.data_ptr(), m4.data_ptr(), feat.data_ptr(), L.stream())
+    report("conv_last_fwd_feat (weight-stationary: consumer wave 0)", read(ffwd), {15: "pass top", 0: "multiply + epilogue", 1: "barrier (wait for the producers)"}, reps)
+    da3 = torch.randint(-300, 300, (N, 12, 12, 64), device=dev, dtype=torch.int16)
+    da2o = torch.empty(N, 24, 24, 32, device=dev, dtype=torch.int16)
+    read(fbwd)
+    for _ in range(reps):
+        L.call("ss_c5_conv_dgrad", 3, da3.data_ptr(), i3.data_ptr(), N, w3.data_ptr(), da2o.data_ptr(), L.stream())
+    report("conv3_dgrad (2 workgroups per CU: x2)", read(fbwd), dnames, reps)
+    for _ in range(reps):
+        L.call("ss_c5_conv_last_dgrad_df", dfe.data_ptr(), m4.data_ptr(), N, w4.data_ptr(), a3o.data_ptr(), L.stream())
+    report("conv_last_dgrad_df", read(fbwd), dnames, reps)
+    gw3, gb3 = torch.zeros(64, 32, 3, 3, device=dev), torch.zeros(64, device=dev)
+    for _ in range(reps):
+        L.call("ss_c5_conv_wgrad", 3, a2.data_ptr(), da3.data_ptr(), i3.data_ptr(), N, gw3.data_ptr(), gb3.data_ptr(), L.stream())
+    report("conv3_wgrad", read(fbwd), {15: "frame top", 0: "-", 1: "dy expand commit", 2: "a_in commit", 3: "barrier", 4: "issue of the next band's loads",
+                                       5: "MFMAs", 6: "barrier"}, reps)
 
 
 if __name__ == "__main__":
