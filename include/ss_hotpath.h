@@ -338,7 +338,15 @@ int ss_c5_conv12_fwd(const uint8_t* R, int N, int standardize, const float* w1, 
  *                             g_wfc += d z^T . feat and g_bfc += column sums of d z are the caller's */
 int ss_c5_conv_last_fwd_feat(const uint16_t* in, int N, const float* w, const float* b, uint8_t* mask, float* feat, ss_stream_t stream);
 int ss_c5_conv_last_wgrad_df(const uint16_t* a_in, const float* dfeat, const uint8_t* mask, int N, float* g_w, float* g_b,
-                             ss_stream_t stream);
+                             float* part, long part_floats, ss_stream_t stream);
+/* Weight gradients with the workgroups' partial sums through a scratch buffer instead of float atomics onto g_w:
+ * part = (min(N, CUs)) x (COUT * CIN * 9) floats, 16-byte aligned, contents irrelevant; NULL or too small: the atomics form.
+ * (256 workgroups adding 55 k floats each onto the same 55 k addresses was half of the last layer's launch.) */
+int ss_c5_conv_wgrad_ws(int layer, const uint16_t* a_in, const uint16_t* da_out, const uint8_t* idx, int N, float* g_w, float* g_b,
+                        float* part, long part_floats, ss_stream_t stream);
+int ss_c5_conv2_wgrad_rc_ws(const uint8_t* R, const float* st, int standardize, const float* w1, const float* b1,
+                            const uint16_t* da_out, const uint8_t* idx, int N, float* g_w, float* g_b, float* part, long part_floats,
+                            ss_stream_t stream);
 int ss_c5_conv_last_dgrad_df(const float* dfeat, const uint8_t* mask, int N, const float* w, uint16_t* da_in, ss_stream_t stream);
 /* The same two with conv1's pool winners i1 (N,48,48,16) u8 left in HBM by the forward kernel and read back by the fused backward
  * kernel instead of being recomputed from the frame (37 KB per frame each way; i1 = NULL: the forms above). */

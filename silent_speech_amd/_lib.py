@@ -48,7 +48,9 @@ SIGNATURES = {
     "ss_c5_conv2_dgrad_conv1_wgrad": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_c5_conv12_fwd": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_c5_conv_last_fwd_feat": [_vp, _i, _vp, _vp, _vp, _vp, _vp],
-    "ss_c5_conv_last_wgrad_df": [_vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "ss_c5_conv_last_wgrad_df": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _vp],
+    "ss_c5_conv_wgrad_ws": [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _vp],
+    "ss_c5_conv2_wgrad_rc_ws": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _vp],
     "ss_c5_conv_last_dgrad_df": [_vp, _vp, _i, _vp, _vp, _vp],
     "ss_c5_conv12_fwd_i1": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_c5_conv2_dgrad_conv1_wgrad_i1": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -52,6 +52,8 @@ struct ConvBwdParams {
   const float* w;         // (COUT, CIN, 3, 3) f32 (dgrad)
   float *g_w, *g_b;       // gradient accumulators (wgrad), +=
   float *g_wfc, *g_bfc;   // (E, COUT), (E)  (last layer's wgrad)
+  float* part;            // wgrad: null, or gridDim.x x (COUT*CIN*9) floats -- every workgroup leaves its weight-gradient sums there
+                          // with plain stores and ss_c5 wgrad_reduce folds them into g_w (instead of float atomics: below)
   bf16_t* da_in;          // (N, H, W, CIN) (dgrad)
   // recompute form of layer 2's weight gradient (RC): a_in is not stored, it is rebuilt from the frame
   const uint8_t* R;       // (N, 96, 96)
@@ -379,26 +381,44 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   static_assert(CO_H % 16 == 0 && CO_H * CIN * 9 * 4 <= 150 * 1024, "gradient image");
 #pragma unroll
   for (int hf = 0; hf < HALVES; ++hf) {
+    // The WK waves that share a tile set add their sums one after the other with plain read-modify-writes (an element has one owner
+    // lane per pass; the first pass stores, so nothing is cleared).  The first version cleared the image and used LDS float
+    // atomics: 110 k ds_add_f32 lane-operations per workgroup took 178 k cycles -- 80 us of the last layer's 228 us launch, found
+    // as the launch time at one frame per workgroup (tools/c5_last_bench.py) and placed by a stamp behind the flush.
     __syncthreads();
-    for (int q = tid; q < CO_H * CIN * 9; q += NT) redw[q] = 0.f;
-    __syncthreads();
 #pragma unroll
-    for (int a = 0; a < NCO; ++a) {
-      const int co0 = 16 * (wco * NCO + a) + 4 * g - hf * CO_H;  // first of this lane's 4 rows, relative to the half
-      if (co0 >= 0 && co0 < CO_H) {
+    for (int kp = 0; kp < WK; ++kp) {
+      if (wk == kp) {
 #pragma unroll
-        for (int b = 0; b < NCI; ++b) {
-          const int ci = 16 * (wci * NCI + b) + li;
+        for (int a = 0; a < NCO; ++a) {
+          const int co0 = 16 * (wco * NCO + a) + 4 * g - hf * CO_H;  // first of this lane's 4 rows, relative to the half
+          if (co0 >= 0 && co0 < CO_H) {
 #pragma unroll
-          for (int t = 0; t < 9; ++t)
+            for (int b = 0; b < NCI; ++b) {
+              const int ci = 16 * (wci * NCI + b) + li;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(redw + ((co0 + r) * CIN + ci) * 9 + t, acc[a][b][t][r]);
+              for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  float* d = redw + ((co0 + r) * CIN + ci) * 9 + t;
+                  *d = kp == 0 ? acc[a][b][t][r] : *d + acc[a][b][t][r];
+                }
+            }
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
-    for (int q = tid; q < CO_H * CIN * 9; q += NT) atomicAdd(p.g_w + (long)hf * CO_H * CIN * 9 + q, redw[q]);
+    if (p.part) {
+      // 256 workgroups x 55 k float atomics onto the same 55 k addresses took 113 us of the last layer's 228 us launch (launch
+      // time against the number of frames, tools/c5_last_bench.py): plain 16-byte stores + one small reduce launch instead
+      f32x4* dst = reinterpret_cast<f32x4*>(p.part + (long)blockIdx.x * (COUT * CIN * 9) + (long)hf * CO_H * CIN * 9);
+      for (int q = tid; q < CO_H * CIN * 9 / 4; q += NT) dst[q] = reinterpret_cast<const f32x4*>(redw)[q];
+    } else {
+      for (int q = tid; q < CO_H * CIN * 9; q += NT) atomicAdd(p.g_w + (long)hf * CO_H * CIN * 9 + q, redw[q]);
+    }
   }
+  STAMP(10);
   {  // bias gradients: every column of accb holds the same sum
     __syncthreads();
     for (int q = tid; q < COUT; q += NT) redw[q] = 0.f;
@@ -411,6 +431,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
     __syncthreads();
     for (int q = tid; q < COUT; q += NT) atomicAdd(p.g_b + q, redw[q]);
   }
+  STAMP(11);
   if (LAST && !FCX) {
 #pragma unroll
     for (int k = 0; k < FCN; ++k) {
@@ -419,6 +440,25 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
     }
     if (tid < p.E) atomicAdd(p.g_bfc + tid, fcb);
   }
+}
+
+// g_w[e] += sum over the workgroups' partial sums (ConvBwdParams::part); one thread per four elements
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nwg, int total, float* __restrict__ g_w) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (4 * q >= total) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(part) + q;
+  const long ws = total / 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+  int w = 0;
+  for (; w + 8 <= nwg; w += 8) {  // eight partials in flight: the sum must not become a chain of memory latencies
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(w + u) * ws];
+    s0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (; w < nwg; ++w) s0 += src[w * ws];
+  f32x4* dst = reinterpret_cast<f32x4*>(g_w) + q;
+  *dst += s0;
 }
 
 template <int CIN, int COUT, int W, int BH, bool RC = false>
@@ -1089,28 +1129,56 @@ int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s,
   return ss_launch_status();
 }
 
+// weight-gradient launch with the partial sums through `part` (may be null: float atomics) + the reduce launch
+template <class K>
+int launch_wgrad(K kernel, ConvBwdParams& p, int lds_bytes, int N, int total, float* part, long part_floats, hipStream_t s) {
+  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256;
+  const int grid = N < cap ? N : cap;
+  p.part = (part && part_floats >= (long)grid * total) ? part : nullptr;
+  const int st = launch_persistent(kernel, p, lds_bytes, N, s);
+  if (st != SS_OK || !p.part) return st;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, s, p.part, grid, total, p.g_w);
+  return ss_launch_status();
+}
+
 }  // namespace
 
 // layer 2: a_in (N,48,48,16), da_out / idx (N,24,24,32);  layer 3: a_in (N,24,24,32), da_out / idx (N,12,12,64)
-extern "C" int ss_c5_conv_wgrad(int layer, const uint16_t* a_in, const uint16_t* da_out, const uint8_t* idx, int N, float* g_w,
-                                float* g_b, ss_stream_t stream) {
+// part / part_floats (the _ws forms): scratch for the workgroups' partial weight-gradient sums, (workgroups = min(N, CUs)) x
+// (COUT * CIN * 9) floats, 16-byte aligned, contents irrelevant; the sums then leave with plain stores and a reduce launch adds them to
+// g_w.  Null or too small: float atomics straight onto g_w.
+extern "C" int ss_c5_conv_wgrad_ws(int layer, const uint16_t* a_in, const uint16_t* da_out, const uint8_t* idx, int N, float* g_w,
+                                   float* g_b, float* part, long part_floats, ss_stream_t stream) {
   SS_REQUIRE(a_in && da_out && idx && g_w && g_b && N > 0, SS_ERR_ARG);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(part) & 15) == 0 && (reinterpret_cast<uintptr_t>(g_w) & 15) == 0, SS_ERR_ARG);
   ConvBwdParams p{};
   p.N = N; p.a_in = a_in; p.da_out = da_out; p.idx = idx; p.g_w = g_w; p.g_b = g_b;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (layer == 2) return launch_persistent(conv_wgrad_kernel<C1, C2, 48, 48, false, 16, 1, 1, 8>, p, wgrad_lds<C1, C2, 48, 16>(), N, s);
-  if (layer == 3) return launch_persistent(conv_wgrad_kernel<C2, C3, 24, 24, false, 24, 2, 2, 2>, p, wgrad_lds<C2, C3, 24, 24>(), N, s);
+  if (layer == 2)
+    return launch_wgrad(conv_wgrad_kernel<C1, C2, 48, 48, false, 16, 1, 1, 8>, p, wgrad_lds<C1, C2, 48, 16>(), N, C2 * C1 * 9, part, part_floats, s);
+  if (layer == 3)
+    return launch_wgrad(conv_wgrad_kernel<C2, C3, 24, 24, false, 24, 2, 2, 2>, p, wgrad_lds<C2, C3, 24, 24>(), N, C3 * C2 * 9, part, part_floats, s);
   return SS_ERR_UNSUPPORTED;
+}
+extern "C" int ss_c5_conv_wgrad(int layer, const uint16_t* a_in, const uint16_t* da_out, const uint8_t* idx, int N, float* g_w,
+                                float* g_b, ss_stream_t stream) {
+  return ss_c5_conv_wgrad_ws(layer, a_in, da_out, idx, N, g_w, g_b, nullptr, 0, stream);
 }
 
 // layer 2's weight gradient with its input recomputed from the frame (no a1 in HBM): R (N,96,96) u8, st (N,2) from the forward
-extern "C" int ss_c5_conv2_wgrad_rc(const uint8_t* R, const float* st, int standardize, const float* w1, const float* b1,
-                                    const uint16_t* da_out, const uint8_t* idx, int N, float* g_w, float* g_b, ss_stream_t stream) {
+extern "C" int ss_c5_conv2_wgrad_rc_ws(const uint8_t* R, const float* st, int standardize, const float* w1, const float* b1,
+                                       const uint16_t* da_out, const uint8_t* idx, int N, float* g_w, float* g_b, float* part,
+                                       long part_floats, ss_stream_t stream) {
   SS_REQUIRE(R && st && w1 && b1 && da_out && idx && g_w && g_b && N > 0, SS_ERR_ARG);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(part) & 15) == 0 && (reinterpret_cast<uintptr_t>(g_w) & 15) == 0, SS_ERR_ARG);
   ConvBwdParams p{};
   p.N = N; p.da_out = da_out; p.idx = idx; p.g_w = g_w; p.g_b = g_b; p.R = R; p.st = st; p.standardize = standardize; p.w1 = w1; p.b1 = b1;
-  return launch_persistent(conv_wgrad_kernel<C1, C2, 48, 48, false, 16, 1, 1, 8, true>, p, wgrad_lds<C1, C2, 48, 16, true>(), N,
-                           static_cast<hipStream_t>(stream));
+  return launch_wgrad(conv_wgrad_kernel<C1, C2, 48, 48, false, 16, 1, 1, 8, true>, p, wgrad_lds<C1, C2, 48, 16, true>(), N, C2 * C1 * 9,
+                      part, part_floats, static_cast<hipStream_t>(stream));
+}
+extern "C" int ss_c5_conv2_wgrad_rc(const uint8_t* R, const float* st, int standardize, const float* w1, const float* b1,
+                                    const uint16_t* da_out, const uint8_t* idx, int N, float* g_w, float* g_b, ss_stream_t stream) {
+  return ss_c5_conv2_wgrad_rc_ws(R, st, standardize, w1, b1, da_out, idx, N, g_w, g_b, nullptr, 0, stream);
 }
 
 // conv2's data gradient and conv1's weight gradient in one kernel: d a1 never reaches HBM (da1 = NULL; a non-NULL da1 also gets the
@@ -1159,12 +1227,13 @@ static const bool ss_c5_last_ws = !(getenv("SS_C5_LAST_WS") && getenv("SS_C5_LAS
 // The same two with d feat * 144 = d z . W_fc of every frame ready-made (dfeat (N, 96) f32: one small GEMM in front of them); the fc
 // gradients (g_wfc = d z^T . feat, g_bfc = column sums of d z) are then the caller's GEMMs as well.
 extern "C" int ss_c5_conv_last_wgrad_df(const uint16_t* a_in, const float* dfeat, const uint8_t* mask, int N, float* g_w, float* g_b,
-                                        ss_stream_t stream) {
+                                        float* part, long part_floats, ss_stream_t stream) {
   SS_REQUIRE(a_in && dfeat && mask && g_w && g_b && N > 0, SS_ERR_ARG);
+  SS_REQUIRE((reinterpret_cast<uintptr_t>(part) & 15) == 0 && (reinterpret_cast<uintptr_t>(g_w) & 15) == 0, SS_ERR_ARG);
   ConvBwdParams p{};
   p.N = N; p.a_in = a_in; p.dfeat = dfeat; p.mask = mask; p.g_w = g_w; p.g_b = g_b;
-  return launch_persistent(conv_wgrad_kernel<C3, C4, 12, 12, true, 12, 2, 4, 1, false, 2, true>, p, wgrad_lds<C3, C4, 12, 12>(), N,
-                           static_cast<hipStream_t>(stream));
+  return launch_wgrad(conv_wgrad_kernel<C3, C4, 12, 12, true, 12, 2, 4, 1, false, 2, true>, p, wgrad_lds<C3, C4, 12, 12>(), N,
+                      C4 * C3 * 9, part, part_floats, static_cast<hipStream_t>(stream));
 }
 extern "C" int ss_c5_conv_last_dgrad_df(const float* dfeat, const uint8_t* mask, int N, const float* w, uint16_t* da_in,
                                         ss_stream_t stream) {

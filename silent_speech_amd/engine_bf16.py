@@ -190,6 +190,9 @@ class WorkspaceBf16:
                 self.i1 = torch.empty(N, 48, 48, c1, **u8) if (STASH_I1 and FUSE_DGRAD2_WGRAD1) else None
                 self.m4 = torch.empty(N, 144, c4, **u8)
                 self.dfeat = torch.empty(N, c4, **f32)
+                # partial weight-gradient sums of the conv layers' persistent workgroups (one per CU): plain stores + a reduce launch
+                cus = torch.cuda.get_device_properties(device).multi_processor_count
+                self.wg_part = torch.empty(min(N, cus) * c4 * c3 * 9, **f32)
                 self.da1 = torch.empty(N, 48, 48, c1, **i16) if not FUSE_DGRAD2_WGRAD1 else None
                 self.da2 = torch.empty(N, 24, 24, c2, **i16)
                 self.da3 = torch.empty(N, 12, 12, c3, **i16)
@@ -394,19 +397,20 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
                     fc_grads()
             else:
                 fc_grads()
-            L.call("ss_c5_conv_last_wgrad_df", ws.a3.data_ptr(), ws.dfeat.data_ptr(), ws.m4.data_ptr(), N, gw[3], gb[3], s,
-                   tag="ss_c5_conv_last_wgrad")
+            L.call("ss_c5_conv_last_wgrad_df", ws.a3.data_ptr(), ws.dfeat.data_ptr(), ws.m4.data_ptr(), N, gw[3], gb[3],
+                   ws.wg_part.data_ptr(), ws.wg_part.numel(), s, tag="ss_c5_conv_last_wgrad")
             L.call("ss_c5_conv_last_dgrad_df", ws.dfeat.data_ptr(), ws.m4.data_ptr(), N, w[3], ws.da3.data_ptr(), s,
                    tag="ss_c5_conv_last_dgrad")
         else:
             L.call("ss_c5_conv_last_wgrad", ws.a3.data_ptr(), dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), ws.feat.data_ptr(), N,
                    gw[3], gb[3], G["roi_cnn.fc.weight"].data_ptr(), G["roi_cnn.fc.bias"].data_ptr(), s)
             L.call("ss_c5_conv_last_dgrad", dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), N, w[3], ws.da3.data_ptr(), s)
-        L.call("ss_c5_conv_wgrad", 3, ws.a2.data_ptr(), ws.da3.data_ptr(), ws.i3.data_ptr(), N, gw[2], gb[2], s, tag="ss_c5_conv3_wgrad")
+        L.call("ss_c5_conv_wgrad_ws", 3, ws.a2.data_ptr(), ws.da3.data_ptr(), ws.i3.data_ptr(), N, gw[2], gb[2], ws.wg_part.data_ptr(),
+               ws.wg_part.numel(), s, tag="ss_c5_conv3_wgrad")
         L.call("ss_c5_conv_dgrad", 3, ws.da3.data_ptr(), ws.i3.data_ptr(), N, w[2], ws.da2.data_ptr(), s, tag="ss_c5_conv3_dgrad")
         bb = [P[k + ".bias"].data_ptr() for k in _CONV]
-        L.call("ss_c5_conv2_wgrad_rc", R.data_ptr(), ws.st.data_ptr(), int(cfg.roi_standardize), w[0], bb[0], ws.da2.data_ptr(),
-               ws.i2.data_ptr(), N, gw[1], gb[1], s)
+        L.call("ss_c5_conv2_wgrad_rc_ws", R.data_ptr(), ws.st.data_ptr(), int(cfg.roi_standardize), w[0], bb[0], ws.da2.data_ptr(),
+               ws.i2.data_ptr(), N, gw[1], gb[1], ws.wg_part.data_ptr(), ws.wg_part.numel(), s, tag="ss_c5_conv2_wgrad_rc")
         if FUSE_DGRAD2_WGRAD1:  # d a1 (the largest gradient map) is born and consumed in LDS: 1.13 GB per step less through HBM
             L.call("ss_c5_conv2_dgrad_conv1_wgrad_i1", ws.da2.data_ptr(), ws.i2.data_ptr(), N, w[1], R.data_ptr(), ws.st.data_ptr(),
                    int(cfg.roi_standardize), w[0], bb[0], None, gw[0], gb[0], L.ptr(ws.i1), s, tag="ss_c5_conv2_dgrad_conv1_wgrad")

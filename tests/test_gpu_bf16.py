@@ -542,6 +542,14 @@ def test_c5_conv_bwd(L, layer, N, wg_cap):
     assert float((gw.cpu() - 1.0 - gw_ref).abs().max()) < 2e-4 * float(gw_ref.abs().max())
     assert float((gb.cpu() - 1.0 - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
     assert_bf16_close(f"da{layer - 1}", from_nhwc(din), din_ref)
+    # the same through the scratch buffer of partial sums (plain stores + a reduce launch instead of float atomics onto g_w)
+    part = torch.full((min(N, 256) * cout * cin * 9,), float("nan"), device="cuda")
+    gw2, gb2 = torch.ones_like(gw), torch.ones_like(gb)
+    L.call("ss_c5_conv_wgrad_ws", layer, a_d.data_ptr(), da_d.data_ptr(), idx_d.data_ptr(), N, gw2.data_ptr(), gb2.data_ptr(), part.data_ptr(),
+           part.numel(), L.stream())
+    torch.cuda.synchronize()
+    assert float((gw2.cpu() - 1.0 - gw_ref).abs().max()) < 2e-4 * float(gw_ref.abs().max())
+    assert float((gb2.cpu() - 1.0 - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
 
 
 @pytest.mark.parametrize("N", [3, 300])
@@ -584,7 +592,9 @@ def test_c5_conv_last_bwd(L, N, wg_cap):
     df_d = (dz[:, 84:] @ wfc).contiguous().cuda()
     gw2, gb2 = torch.zeros_like(gw), torch.zeros_like(gb)
     din2 = torch.empty_like(din)
-    L.call("ss_c5_conv_last_wgrad_df", a_d.data_ptr(), df_d.data_ptr(), m_d.data_ptr(), N, gw2.data_ptr(), gb2.data_ptr(), L.stream())
+    part = torch.full((min(N, 256) * 96 * 64 * 9 + 4,), float("nan"), device="cuda")
+    L.call("ss_c5_conv_last_wgrad_df", a_d.data_ptr(), df_d.data_ptr(), m_d.data_ptr(), N, gw2.data_ptr(), gb2.data_ptr(), part.data_ptr(), part.numel(),
+           L.stream())
     L.call("ss_c5_conv_last_dgrad_df", df_d.data_ptr(), m_d.data_ptr(), N, w_d.data_ptr(), din2.data_ptr(), L.stream())
     torch.cuda.synchronize()
     assert float((gw2.cpu() - gw_ref).abs().max()) < 3e-4 * float(gw_ref.abs().max())
@@ -661,6 +671,13 @@ def test_c5_conv12_fused_forward_and_recomputing_backward(L, N, wg_cap):
     torch.cuda.synchronize()
     assert float((gw.cpu() - gw_ref).abs().max()) < 1e-3 * float(gw_ref.abs().max())
     assert float((gb.cpu() - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
+    part = torch.full((min(N, 256) * 32 * 16 * 9,), float("nan"), device="cuda")  # partial sums through scratch instead of atomics
+    gw_s, gb_s = torch.zeros_like(gw), torch.zeros_like(gb)
+    L.call("ss_c5_conv2_wgrad_rc_ws", R_d.data_ptr(), st.data_ptr(), 1, w1_d.data_ptr(), b1_d.data_ptr(), da2_d.data_ptr(), idx2_d.data_ptr(),
+           N, gw_s.data_ptr(), gb_s.data_ptr(), part.data_ptr(), part.numel(), L.stream())
+    torch.cuda.synchronize()
+    assert float((gw_s.cpu() - gw_ref).abs().max()) < 1e-3 * float(gw_ref.abs().max())
+    assert float((gb_s.cpu() - gb_ref).abs().max()) < 2e-4 * float(gb_ref.abs().max())
 
     # ---- conv1's weight gradient with recomputed pool winners
     da1 = bf(torch.randn(N, 16, 48, 48, generator=g))

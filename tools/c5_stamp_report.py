@@ -80,9 +80,14 @@ def main():
     report("conv_last_wgrad", read(fbwd), {15: "frame top", 0: "-", 1: "d feat, fc gradients, dy image from the sign mask", 2: "a_in commit", 3: "barrier",
                                            4: "issue of the next frame's loads", 5: "MFMAs", 6: "barrier"}, reps)
     dfe = dz @ wfc
+    part4 = torch.empty(256 * 96 * 64 * 9, device=dev)
     for _ in range(reps):
-        L.call("ss_c5_conv_last_wgrad_df", a3.data_ptr(), dfe.data_ptr(), m4.data_ptr(), N, gw4.data_ptr(), gb4.data_ptr(), L.stream())
-    report("conv_last_wgrad_df", read(fbwd), {15: "frame top", 0: "-", 1: "d feat, fc gradients, dy image from the sign mask", 2: "a_in commit", 3: "barrier",
+        L.call("ss_c5_conv_last_wgrad_df", a3.data_ptr(), dfe.data_ptr(), m4.data_ptr(), N, gw4.data_ptr(), gb4.data_ptr(), part4.data_ptr(), part4.numel(),
+               L.stream())
+    tt = read(fbwd)
+    print(f"   conv_last_wgrad_df per LAUNCH (cycles, mean over workgroups): before the frame loop {tt[:, 14].mean() / reps:.0f}, weight-gradient flush "
+          f"{tt[:, 10].mean() / reps:.0f}, bias flush {tt[:, 11].mean() / reps:.0f}")
+    report("conv_last_wgrad_df", tt, {15: "frame top", 0: "-", 1: "d feat, fc gradients, dy image from the sign mask", 2: "a_in commit", 3: "barrier",
                                            4: "issue of the next frame's loads", 5: "MFMAs", 6: "barrier"}, reps)
     # ---- generic forward / data-gradient kernels: layers 3 and 4
     fnames = {15: "frame top", 0: "commit of the frame image", 1: "barrier", 2: "issue of the next frame", 3: "units: MFMAs + epilogue", 4: "barrier",
