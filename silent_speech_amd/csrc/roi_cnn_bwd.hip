@@ -854,7 +854,23 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float* r_fc = r_b2 + 16;      // [E*24]
   const int rtot = 3456 + 1152 + 72 + 8 + 16 + E * 24;
   // (r_* overlay a1h and the phase area, both dead; s_gb3 in misc is untouched)
-  for (int q = tid; q < rtot; q += NT) lds[q] = 0.f;
+  // d W3 and d W2 -- 48 of a lane's 56 partial sums -- go through one LDS REGION PER WAVE with plain stores and are summed over the
+  // eight regions by the threads that then issue the global atomics.  The first version added all partials into one image with LDS
+  // float atomics: ds_add_f32 retires well under one lane-operation per clock (measured on the config-5 weight gradients: 110 k of
+  // them in 178 k cycles), 25 k of them here.  Shapes whose LDS image is too small for eight regions keep the atomics.
+  constexpr int RW = 3456 + 1152;
+  constexpr bool REGIONS = 8 * RW + 96 + 64 * 24 <= LL::o_misc;
+  float* r_w3w = REGIONS ? lds + wvu * RW : r_w3;  // this wave's region (d W3, then d W2)
+  float* r_w2w = r_w3w + 3456;
+  if (REGIONS) {
+    r_w1 = lds + 8 * RW;
+    r_b1 = r_w1 + 72;
+    r_b2 = r_b1 + 8;
+    r_fc = r_b2 + 16;
+    for (int q = tid; q < (8 * RW + 96) / 4; q += NT) reinterpret_cast<f32x4*>(lds)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    for (int q = tid; q < rtot; q += NT) lds[q] = 0.f;
+  }
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < 7; ++t)
@@ -866,7 +882,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       else if (t % 3 == 0) { nn = row; tap = t0; }
       else if (t % 3 == 1) { nn = row < 8 ? 16 + row : row - 8; tap = row < 8 ? t0 : t0 + 1; }
       else { nn = 8 + row; tap = t0 + 1; }
-      if (nn < 24) atomicAdd(&r_w3[nn * 144 + i * 9 + tap], acc3[t][r]);
+      if (nn < 24) {
+        if (REGIONS) r_w3w[nn * 144 + i * 9 + tap] = acc3[t][r];  // (a wave holds every element at most once)
+        else atomicAdd(&r_w3[nn * 144 + i * 9 + tap], acc3[t][r]);
+      }
     }
 #pragma unroll
   for (int nt = 0; nt < 5; ++nt) {
@@ -874,7 +893,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     if (idx < 72) {
       const int tap = idx >> 3, c = idx & 7;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&r_w2[(4 * g + r) * 72 + c * 9 + tap], acc2[nt][r]);
+      for (int r = 0; r < 4; ++r) {
+        if (REGIONS) r_w2w[(4 * g + r) * 72 + c * 9 + tap] = acc2[nt][r];
+        else atomicAdd(&r_w2[(4 * g + r) * 72 + c * 9 + tap], acc2[nt][r]);
+      }
     }
   }
   // S5 accumulators: row 16mt+4g+r = (c = row&7, window slot o = row>>3), column i = (ry, rx):
@@ -906,8 +928,18 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     if (idx < E * 24) r_fc[idx] = accfc[k];
   }
   __syncthreads();
-  for (int q = tid; q < 3456; q += NT) atomicAdd(&p.g_w3[q], r_w3[q]);
-  for (int q = tid; q < 1152; q += NT) atomicAdd(&p.g_w2[q], r_w2[q]);
+  if (REGIONS) {
+    for (int q = tid; q < RW; q += NT) {
+      float s8[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s8[w] = lds[w * RW + q];
+      const float sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+      atomicAdd(q < 3456 ? &p.g_w3[q] : &p.g_w2[q - 3456], sum);
+    }
+  } else {
+    for (int q = tid; q < 3456; q += NT) atomicAdd(&p.g_w3[q], r_w3[q]);
+    for (int q = tid; q < 1152; q += NT) atomicAdd(&p.g_w2[q], r_w2[q]);
+  }
   if (tid < 72) atomicAdd(&p.g_w1[tid], r_w1[tid]);
   if (tid < 8) atomicAdd(&p.g_b1[tid], r_b1[tid]);
   if (tid < 16) atomicAdd(&p.g_b2[tid], r_b2[tid]);
