@@ -179,9 +179,11 @@ typedef struct ss_gemm_problem {
 int ss_gemm_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats);
 int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream);
 /* The same for bf16 operands (config 5; csrc/gemm_bf16.hip): A and B point at bf16 data (k-major, a_kcontig = b_kcontig = 0; lda /
- * ldb / strides in bf16 elements, multiples of 8; K a multiple of 64), C[b] += A[b]^T B[b] in f32.  The K tiles of the whole group
- * are dealt evenly over the CUs ("stream-K": `splits` is ignored), every workgroup leaves raw accumulators in `ws`
- * (ss_gemm_bf16_splitk_group_ws_floats() floats, 16-byte aligned, contents irrelevant) and a second launch folds them into C. */
+ * ldb / strides in bf16 elements, multiples of 8; K a multiple of 64; n <= 8), C[b] += A[b]^T B[b] in f32.  A group with at least
+ * half a chip of 256 x 128 output tiles runs one workgroup per tile over all of K (neighbouring tiles share operand panels in L2);
+ * a smaller one has its K tiles dealt evenly over the CUs ("stream-K"), every workgroup leaves raw accumulators in `ws`
+ * (ss_gemm_bf16_splitk_group_ws_floats() floats, 16-byte aligned, contents irrelevant) and a second launch folds them into C.
+ * `splits` is ignored. */
 int ss_gemm_bf16_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats);
 int ss_gemm_bf16_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream);
 

@@ -559,43 +559,20 @@ __device__ __forceinline__ int xcd_contiguous_id() {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
 }
 
-template <int AKC, int BKC>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(GemmBfParams p, int gx, int gy, int kcat) {
-  extern __shared__ __attribute__((aligned(16))) char rlds[];
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)rlds;
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, li = lane & 15;
-  const int wg = xcd_contiguous_id();
-  const int bx = wg % gx, by = (wg / gx) % gy, bz = wg / (gx * gy);
-  const int batch = bz / p.splits, split = bz % p.splits;
-  const int m0 = by * RBM, n0 = bx * RBN;
-  const int nkt = p.K / RBK;
-  const int per = (nkt + p.splits - 1) / p.splits;
-  const int kt0 = split * per, kt1 = min(nkt, kt0 + per), nk = max(0, kt1 - kt0);
+// acc (D row = 4 g + r, column = li of the wave's 64 x 64 sub-tile) -> C.  Called behind the main loop (no DMA in flight, every LDS
+// read done): a tile whose 128 columns are all there goes through an LDS image so that a row leaves as one 512-byte run.
+__device__ __forceinline__ void ring_epilogue(const GemmBfParams& p, f32x4 (&acc)[4][4], float* C, const float* bias, int m0, int n0,
+                                              bool add_bias, bool atomic, char* rlds) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, li = lane & 15;
   const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // kcat > 1: that many (A, B) pairs, strides sa / sb apart, are multiplied into ONE C (d layer_in = dG_f W_f + dG_r W_r
-  // without atomics or a cleared C); otherwise the pair of this batch entry
-  for (int kc = 0; kc < kcat; ++kc) ring_mainloop<AKC, BKC>(p, kcat > 1 ? kc : batch, m0, n0, kt0, nk, rlds, lds0, acc);
-
-  // ---- epilogue: D row = 4 g + r, column = li
-  float* C = p.C + (kcat > 1 ? 0 : batch * p.sc);
-  const bool accumulate = p.flags & 1, atomic = (p.flags & 4) || p.splits > 1;
-  const float* bias = p.bias ? p.bias + batch * p.sbias : nullptr;
+  const bool accumulate = p.flags & 1;
+  if (!add_bias) bias = nullptr;
   if (!atomic && n0 + RBN <= p.N && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
-    // plain stores of a tile whose 128 columns are all there: through LDS, so that a row leaves as one 512-byte run
-    // (the last k tile has been read by everybody and no DMA is in flight: the loop ended on vmcnt(0) and a barrier)
     float* stage = reinterpret_cast<float*>(rlds);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int col = wn + 16 * b + li;
-      const float bv = (bias && split == 0) ? bias[n0 + col] : 0.f;
+      const float bv = bias ? bias[n0 + col] : 0.f;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -619,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(GemmBfParams p, 
   for (int b = 0; b < 4; ++b) {
     const int n = n0 + wn + 16 * b + li;
     if (n >= p.N) continue;
-    const float bv = (bias && split == 0) ? bias[n] : 0.f;
+    const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -633,6 +610,33 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(GemmBfParams p, 
         else *dst = v;
       }
   }
+}
+
+template <int AKC, int BKC>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(GemmBfParams p, int gx, int gy, int kcat) {
+  extern __shared__ __attribute__((aligned(16))) char rlds[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)rlds;
+  const int wg = xcd_contiguous_id();
+  const int bx = wg % gx, by = (wg / gx) % gy, bz = wg / (gx * gy);
+  const int batch = bz / p.splits, split = bz % p.splits;
+  const int m0 = by * RBM, n0 = bx * RBN;
+  const int nkt = p.K / RBK;
+  const int per = (nkt + p.splits - 1) / p.splits;
+  const int kt0 = split * per, kt1 = min(nkt, kt0 + per), nk = max(0, kt1 - kt0);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // kcat > 1: that many (A, B) pairs, strides sa / sb apart, are multiplied into ONE C (d layer_in = dG_f W_f + dG_r W_r
+  // without atomics or a cleared C); otherwise the pair of this batch entry
+  for (int kc = 0; kc < kcat; ++kc) ring_mainloop<AKC, BKC>(p, kcat > 1 ? kc : batch, m0, n0, kt0, nk, rlds, lds0, acc);
+
+  // ---- epilogue
+  ring_epilogue(p, acc, p.C + (kcat > 1 ? 0 : batch * p.sc), p.bias ? p.bias + batch * p.sbias : nullptr, m0, n0, split == 0,
+                (p.flags & 4) || p.splits > 1, rlds);
 }
 
 template <int AKC, int BKC>
@@ -659,7 +663,7 @@ int launch_ring(const GemmBfParams& p, int batch, int kcat, hipStream_t s) {
 // 27 us per workgroup, as long as 30 k tiles (device-scope float atomics are performed beyond the XCD's L2), and whole slices
 // per workgroup quantise badly over 256 CUs (144 tiles x 120 k tiles: 1, 2 or 3 slices all end near 80 - 120 tile times for
 // an ideal of 67.5).
-constexpr int GROUP_MAX = 4;
+constexpr int GROUP_MAX = 8;
 constexpr int SLAB_FLOATS = RBM * RBN;
 struct RingGroup {
   GemmBfParams p[GROUP_MAX];
@@ -667,6 +671,7 @@ struct RingGroup {
   int ubase[GROUP_MAX + 1];  // first unit of problem j
   int tbase[GROUP_MAX + 1];  // first tile of problem j
   int n, U, maxc;            // units per workgroup; slots per tile
+  int whole;                 // 1: one workgroup per output tile, all of K, C += straight from the registers (no slabs, no reduce)
   float* ws;
 };
 
@@ -675,6 +680,29 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_group_kernel(RingGroup 
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)rlds;
   const int tid = threadIdx.x;
   const int w = xcd_contiguous_id();
+  if (gg.whole) {
+    // Enough output tiles to fill the chip: workgroup w = tile w, whole K.  Neighbouring tiles (one XCD: xcd_contiguous_id) walk K
+    // together and share their operand panels in that XCD's L2 -- the K ranges of the stream-K form below are staggered, every
+    // workgroup then streams its own 3 MB from beyond L2 (845 MB per launch for 95 MB of operands: bound by exactly that).
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < GROUP_MAX; ++q)
+      if (q < gg.n && w >= gg.tbase[q]) j = q;
+    GemmBfParams p = gg.p[0];
+    int gx = gg.gx[0], gy = gg.gy[0], nkt = gg.nkt[0], tb = gg.tbase[0];
+#pragma unroll
+    for (int q = 1; q < GROUP_MAX; ++q)
+      if (q == j) { p = gg.p[q]; gx = gg.gx[q]; gy = gg.gy[q]; nkt = gg.nkt[q]; tb = gg.tbase[q]; }
+    const int tile = w - tb, bx = tile % gx, by = (tile / gx) % gy, bi = tile / (gx * gy);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ring_mainloop<0, 0>(p, bi, by * RBM, bx * RBN, 0, nkt, rlds, lds0, acc);
+    ring_epilogue(p, acc, p.C + bi * p.sc, nullptr, by * RBM, bx * RBN, false, false, rlds);
+    return;
+  }
   int u = w * gg.U;
   const int u1 = min(gg.ubase[gg.n], u + gg.U);
   while (u < u1) {  // wave-uniform
@@ -761,6 +789,7 @@ int launch_gemm_bf16(int a_kcontig, int b_kcontig, const GemmBfParams& p, dim3 g
 }  // namespace
 
 // ---- grouped weight-gradient GEMMs (ring kernel, stream-K over the group; see gemm_bf16_ring_group_kernel)
+static const bool ss_gemm_bf16_group_split = getenv("SS_GEMM_BF16_GROUP_SPLIT") != nullptr;  // diagnostic: always the stream-K form
 static int ring_group_cus() {
   static int cus = 0;
   if (!cus) {
@@ -804,6 +833,9 @@ static int ring_group_prepare(const ss_gemm_problem* pr, int n, float* ws, ring:
   gg.maxc = (nkt_max - 1) / gg.U + 2;
   *wgs = ceil_div(units, gg.U);
   *floats = (long)gg.tbase[n] * gg.maxc * ring::SLAB_FLOATS;
+  // at least half a chip of output tiles (and no more than a chip): one workgroup per tile, no K split
+  gg.whole = (2 * gg.tbase[n] >= ring_group_cus() && gg.tbase[n] <= ring_group_cus() && !ss_gemm_bf16_group_split) ? 1 : 0;
+  if (gg.whole) *wgs = gg.tbase[n];
   return SS_OK;
 }
 
@@ -831,6 +863,7 @@ extern "C" int ss_gemm_bf16_splitk_group(const ss_gemm_problem* problems, int n,
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(ring::gemm_bf16_ring_group_kernel, dim3((unsigned)wgs), dim3(512), ring::LDS_BYTES, s, gg);
   if (ss_launch_status() != SS_OK) return SS_ERR_LAUNCH;
+  if (gg.whole) return SS_OK;
   hipLaunchKernelGGL(ring::gemm_bf16_ring_group_reduce_kernel, dim3((unsigned)(gg.tbase[n] * 16)), dim3(512), 0, s, gg);
   return ss_launch_status();
 }

@@ -61,6 +61,7 @@ STASH_I1 = os.environ.get("SS_C5_STASH_I1", "1") != "0"
 # persistent kernels (0: inside the kernels, the form of the first half of round 3)
 FC_AS_GEMM = os.environ.get("SS_C5_FC_GEMM", "1") != "0"
 USE_DW_GROUP = os.environ.get("SS_C5_DW_GROUP", "1") != "0"
+DW_ALL_LAYERS = os.environ.get("SS_C5_DW_ALL_LAYERS", "1") != "0"  # 0: one grouped launch per layer
 # d layer_in = dGi_f W_ih_f + dGi_r W_ih_r as one product with K concatenated (plain stores, no cleared destination, no atomics)
 USE_DX_KCAT = os.environ.get("SS_C5_DX_KCAT", "1") != "0"
 
@@ -171,11 +172,14 @@ class WorkspaceBf16:
             self.dG = [torch.empty(2, N, 4, H, **f32) if self.gru_sync is None else None for _ in range(cfg.gru_layers)]
             self.dG_bf = [torch.empty(2, N, 4, H, **i16) for _ in range(cfg.gru_layers)]
             self.d_out = torch.empty(N, 2 * H, **f32)
-            need = 0
+            need, allp = 0, []
             for l in range(cfg.gru_layers):
                 pr = dw_problems(cfg, B, T, l, self.kp[l])
                 if dw_group_ok(pr):
                     need = max(need, L.gemm_group_ws_floats(pr, bf16=True))
+                    allp += pr
+            if allp and DW_ALL_LAYERS and len(allp) <= 8:
+                need = max(need, L.gemm_group_ws_floats(allp, bf16=True))
             self.dw_ws = torch.empty(need, **f32) if need else None
             self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
             self.xhat = torch.empty(B, 2 * H, **f32)
@@ -301,6 +305,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
     else:
         head_grads()
     zero_waited = False
+    dw_pending = []
     use_drop = train and cfg.gru_dropout > 0.0
     for l in range(cfg.gru_layers - 1, -1, -1):
         K = cfg.in_dim if l == 0 else 2 * H
@@ -323,8 +328,14 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
             pr = dw_problems(cfg, B, T, l, Kp, dg, lin, ws.out_bf[l].data_ptr(), (G[wi].data_ptr(), _pstride(G, wi, wir)),
                              (G[wh_].data_ptr(), _pstride(G, wh_, whr_)))
             if ws.dw_ws is not None and dw_group_ok(pr):
-                arr, n = L.gemm_group(pr)
-                L.call("ss_gemm_bf16_splitk_group", arr, n, ws.dw_ws.data_ptr(), L.stream(), tag="gemm_bf16_dW")
+                # ALL layers' weight gradients in ONE launch, behind the bottom layer's BPTT kernel: 216 output tiles at the
+                # config-5 shapes = one workgroup per tile and CU walking all of K (no K split, no slabs; neighbouring tiles share
+                # operand panels in L2) -- per layer (144 / 72 tiles) the K tiles had to be dealt over the CUs, 154 + 80 us
+                dw_pending.extend(pr)
+                if l == 0 or not DW_ALL_LAYERS or len(dw_pending) > 5:  # (a group holds at most 8 problems)
+                    arr, n = L.gemm_group(dw_pending)
+                    L.call("ss_gemm_bf16_splitk_group", arr, n, ws.dw_ws.data_ptr(), L.stream(), tag="gemm_bf16_dW")
+                    dw_pending.clear()
                 return
             # ---- weight gradients: d W_ih = dGi^T . layer_in;  d W_hh = dGh^T . h_prev (rows r|z from columns [0,2H), rows n from [3H,4H))
             gemm(0, 0, 3 * H, K, N, dg, 4 * H, lin, Kp, G[wi].data_ptr(), K, accumulate=True, atomic=True,

@@ -157,11 +157,12 @@ def test_gemm_bf16_ring_remap_and_kcat(L):
     assert float((C.cpu() - want).abs().max()) < 3e-4 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("Bc,T,H,Kin", [(64, 5, 128, 136), (128, 3, 256, 512)])
+@pytest.mark.parametrize("Bc,T,H,Kin", [(64, 5, 128, 136), (128, 3, 256, 512), (64, 5, 512, 1024)])
 def test_gemm_bf16_splitk_group(L, Bc, T, H, Kin):
     """The weight gradients of one GRU layer as ONE grouped launch (ss_gemm_bf16_splitk_group): d W_ih and the two pieces of
     d W_hh, both directions each, K = B T resp. B (T - 1) with the row remap; the K tiles of the whole group are dealt evenly
-    over the CUs, so workgroups cross tile and problem boundaries.  C is accumulated into; run twice."""
+    over the CUs, so workgroups cross tile and problem boundaries.  C is accumulated into; run twice.  The last case has 144
+    output tiles (at least half a chip): one workgroup per tile over all of K, C += straight from the registers."""
     g = torch.Generator().manual_seed(Bc + T)
     N = Bc * T
     dG = torch.randn(2, N, 4 * H, generator=g)

@@ -25,7 +25,8 @@ def timed(fn, n=20):
 def main():
     dev = torch.device("cuda")
     H = 192
-    for B, T, split in ((256, 30, False), (256, 30, True), (128, 30, True), (16, 30, True), (256, 60, True)):
+    # (T = 1, 2, 4: the intercept of launch time against T is what a launch costs outside its steps)
+    for B, T, split in ((256, 30, False), (256, 1, True), (256, 2, True), (256, 4, True), (256, 30, True), (128, 30, True), (16, 30, True), (256, 60, True)):
         N = B * T
         nb = L.gru_sync_bytes(B, T, H) if split else 0
         sync_ws = torch.zeros(nb // 4, device=dev, dtype=torch.int32) if nb else None
