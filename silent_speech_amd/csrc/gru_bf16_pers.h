@@ -169,6 +169,16 @@ __global__ __launch_bounds__(256) void gru_pers_fwd_kernel(PersFwdParams p, unsi
       *reinterpret_cast<f32x4*>(sv + 3 * H) = st_q;
     }
   };
+  f32x4 ngr, ngz, ngn;  // input-projection gates of the NEXT step
+  auto load_gi = [&](int s) {
+    const int t = dir ? (T - 1 - s) : s;
+    const long rowl = (long)(clip_ok ? clip : p.c0) * T + (t < len ? t : 0);
+    const float* gp = p.gi + ((long)dir * N + rowl) * (3 * H) + u0;
+    ngr = *reinterpret_cast<const f32x4*>(gp);
+    ngz = *reinterpret_cast<const f32x4*>(gp + H);
+    ngn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+  };
+  load_gi(0);
   STAMP_ENTRY;
   STAMP_DECL;
   for (int s = 0; s < T; ++s) {
@@ -176,13 +186,14 @@ __global__ __launch_bounds__(256) void gru_pers_fwd_kernel(PersFwdParams p, unsi
     const int t = dir ? (T - 1 - s) : s;
     const long row = (long)clip * T + t;
     const bool valid = t < len;
-    f32x4 gr = z4, gz = z4, gn = z4;
-    if (valid) {  // in flight during the sweep
-      const float* gp = p.gi + ((long)dir * N + row) * (3 * H) + u0;
-      gr = *reinterpret_cast<const f32x4*>(gp);
-      gz = *reinterpret_cast<const f32x4*>(gp + H);
-      gn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
-    }
+    // In flight during the sweep -- and UNCONDITIONAL (a lane past its clip's end reads a row of a valid clip and never uses it):
+    // behind `if (valid)` the registers were cleared first, and a write to the destination of an older load makes hipcc wait for
+    // that load by COUNT -- it cannot count the younger stores issued under divergent branches, so it waited for (nearly) all of
+    // them, write-through granule stores included.  In the BPTT kernel below that wait was 3.3 k of 11.6 k cycles per step.
+    // ... and requested a step AHEAD, behind the previous step's sweep: loads return in order, so requested at the top of their own
+    // step (the first version) the sweep's L2 hits queued behind these three HBM misses.
+    const f32x4 gr = ngr, gz = ngz, gn = ngn;
+    if (s == 0 && T > 1) load_gi(1);
     f32x4 ar = br, az = bz, an = bn;
     if (s > 0) {
       // the full previous state of the slice: every thread sweeps NGP granule pairs (4 units of one clip each) into the panel
@@ -193,6 +204,7 @@ __global__ __launch_bounds__(256) void gru_pers_fwd_kernel(PersFwdParams p, unsi
       flush_stores();  // the previous step's, under the sweep's first pass
       if (!dead && !sweep_check<NGP>(raw, base + (unsigned)s, hv)) dead = !sweep_pairs<NGP>(hrs, pr, 256, base + (unsigned)s, hv, &sync[2], lane);
       STAMP(0);
+      if (s + 1 < T) load_gi(s + 1);  // behind the sweep: a whole step to arrive
 #pragma unroll
       for (int k = 0; k < NGP; ++k) {
         const int q = tid + 256 * k;  // clip = q / (H/4), units 4 (q % (H/4)) ..
@@ -310,24 +322,26 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
   f32x4 dh = z4;
   f32x4 sb_r = z4, sb_z = z4, sb_n = z4, sb_q = z4;  // bias-gradient sums of this lane's (clip, 4 units)
   f32x4 go, gsc, sr, sz, sn, sq, hprev;
+  // The loads of a step's inputs are UNCONDITIONAL (a lane past its clip's end, or without a previous state, reads a row of a valid
+  // clip; the step tests `valid` / `hp_ok` where it uses the values): see the forward kernel -- behind `if (t < len)` the registers
+  // were cleared first and hipcc waited for the step's granule stores before it touched them (3.3 k of 11.6 k cycles per step).
   auto load_inputs = [&](int s) {
     const int t = dir ? s : (T - 1 - s);
     const int tp = dir ? t + 1 : t - 1;
-    go = sr = sz = sn = sq = hprev = z4;
+    const bool in = t < len;
+    const long cl = clip_ok ? clip : p.c0;
+    const long row = cl * T + (in ? t : 0), rowp = cl * T + ((in && tp >= 0 && tp < len) ? tp : 0);
+    go = *reinterpret_cast<const f32x4*>(p.d_out + row * (2 * H) + dir * H + u0);
+    // the dropout scale stays beside the raw load: multiplying here made the wave sit through the load's whole latency in
+    // every step of a layer with dropout (2 700 of 12 200 cycles, stage timers)
     gsc = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (t < len) {
-      const long row = (long)clip * T + t;
-      go = *reinterpret_cast<const f32x4*>(p.d_out + row * (2 * H) + dir * H + u0);
-      // the dropout scale stays beside the raw load: multiplying here made the wave sit through the load's whole latency in
-      // every step of a layer with dropout (2 700 of 12 200 cycles, stage timers)
-      if (p.drop_p > 0.f) gsc = drop_scale4((row * (2 * H) + dir * H + u0) >> 2, p.drop_p, p.seed, p.offset);
-      const float* sv = p.save + ((long)dir * N + row) * (4 * H) + u0;
-      sr = *reinterpret_cast<const f32x4*>(sv);
-      sz = *reinterpret_cast<const f32x4*>(sv + H);
-      sn = *reinterpret_cast<const f32x4*>(sv + 2 * H);
-      sq = *reinterpret_cast<const f32x4*>(sv + 3 * H);
-      if (tp >= 0 && tp < len) hprev = *reinterpret_cast<const f32x4*>(p.out + ((long)clip * T + tp) * (2 * H) + dir * H + u0);
-    }
+    if (p.drop_p > 0.f) gsc = drop_scale4((row * (2 * H) + dir * H + u0) >> 2, p.drop_p, p.seed, p.offset);  // (wave-uniform branch)
+    const float* sv = p.save + ((long)dir * N + row) * (4 * H) + u0;
+    sr = *reinterpret_cast<const f32x4*>(sv);
+    sz = *reinterpret_cast<const f32x4*>(sv + H);
+    sn = *reinterpret_cast<const f32x4*>(sv + 2 * H);
+    sq = *reinterpret_cast<const f32x4*>(sv + 3 * H);
+    hprev = *reinterpret_cast<const f32x4*>(p.out + rowp * (2 * H) + dir * H + u0);
   };
   load_inputs(0);
   STAMP_ENTRY;
@@ -338,6 +352,8 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
     const long row = (long)clip * T + t;
     const bool valid = t < len;
     const bool last = s + 1 == T;  // nothing consumes the last d h_prev
+    const int tpc = dir ? t + 1 : t - 1;
+    const bool hp_ok = tpc >= 0 && tpc < len;
     f32x4 dcarry = dh;
     f32x4 dar = z4, daz = z4, dan = z4, dqn = z4;
     if (valid) {
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
       for (int e = 0; e < 4; ++e) {
         const float d = go[e] * gsc[e] + dh[e];
         const float dn = d * (1.0f - sz[e]);
-        const float dz = d * (hprev[e] - sn[e]);
+        const float dz = d * ((hp_ok ? hprev[e] : 0.f) - sn[e]);
         dan[e] = dn * (1.0f - sn[e] * sn[e]);
         dar[e] = dan[e] * sq[e] * sr[e] * (1.0f - sr[e]);
         daz[e] = dz * sz[e] * (1.0f - sz[e]);
@@ -354,6 +370,10 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
       }
     }
     if (dead) dar = daz = dan = dqn = f32x4{NAN_F, NAN_F, NAN_F, NAN_F};
+    // The next step's inputs are requested HERE, into the registers the gate gradients above have just finished with: loads return
+    // in order, so requested behind the publish (as the first version did) the sweep's L2 hits queued behind six HBM misses and
+    // every step paid max(miss, exchange) -- "next step's inputs" 3.3 k of 11.6 k cycles in the stage timers.
+    if (!last) load_inputs(s + 1);
     const uint2 br_ = pack_bf16x4(dar[0], dar[1], dar[2], dar[3]), bz_ = pack_bf16x4(daz[0], daz[1], daz[2], daz[3]),
                 bq_ = pack_bf16x4(dqn[0], dqn[1], dqn[2], dqn[3]);
     if (!last) {
@@ -405,7 +425,6 @@ __global__ __launch_bounds__(256) void gru_pers_bwd_kernel(PersBwdParams p, unsi
     }
     if (last) break;
     STAMP(8);
-    load_inputs(s + 1);
     STAMP(9);
     // sum the P partials of this part's units: thread -> granule pair tid of the [clip][64] tile (clip tid / 16, units
     // 4 (tid % 16) ..), one per source part

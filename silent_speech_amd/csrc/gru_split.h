@@ -120,6 +120,20 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   f32x4 hp = {0.f, 0.f, 0.f, 0.f};
   const long dir_off = (long)dir * p.B * T;
   const rsrc_t hrs = granule_rsrc(hx, 2L * pairs * SLICE * H);
+  // (unconditional for the owner waves: a lane past its clip's end reads its clip's first row and never uses the values -- behind
+  // `valid` the registers were cleared first, and hipcc waits for a step's younger stores before it overwrites the destination
+  // of an older load)
+  f32x4 ngr = {0.f, 0.f, 0.f, 0.f}, ngz = ngr, ngn = ngr;
+  auto load_gi = [&](int s) {
+    if (!owner) return;  // wave-uniform
+    const int t = dir ? (T - 1 - s) : s;
+    const long fl = (long)(clip_ok ? clip : b0) * T + (t < len ? t : 0);
+    const float* gp = p.gi + (dir_off + fl) * (3 * H) + j0;
+    ngr = *reinterpret_cast<const f32x4*>(gp);
+    ngz = *reinterpret_cast<const f32x4*>(gp + H);
+    ngn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+  };
+  load_gi(0);
   STAMP_ENTRY;
   STAMP_DECL;
   for (int s = 0; s < T; ++s) {
@@ -127,14 +141,11 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
     const int t = dir ? (T - 1 - s) : s;
     const long frame = (long)clip * T + t;
     const bool valid = t < len;
-    // input-projection gates of this step: independent of the recurrence, in flight during the sweep below
-    f32x4 gr = {0.f, 0.f, 0.f, 0.f}, gz = gr, gn = gr;
-    if (owner && valid) {
-      const float* gp = p.gi + (dir_off + frame) * (3 * H) + j0;
-      gr = *reinterpret_cast<const f32x4*>(gp);
-      gz = *reinterpret_cast<const f32x4*>(gp + H);
-      gn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
-    }
+    // input-projection gates of this step: independent of the recurrence, requested a step AHEAD behind the previous step's sweep
+    // (load_gi).  The first version requested them at the top of their own step, "in flight during the sweep": loads return in
+    // order, so the sweep's L2 hits queued behind these three HBM misses (found in the bf16 BPTT kernel's stage timers).
+    const f32x4 gr = ngr, gz = ngz, gn = ngn;
+    if (s == 0 && T > 1) load_gi(1);
     f32x4 ar = br, az = bz, an = bn;
     if (s > 0) {
       // the full previous state of the slice, swept ONCE per workgroup into an LDS panel (what a step publishes is
@@ -143,6 +154,7 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
       float hv[2 * C::NGP];
       const int hr = (((s - 1) & 1) * pairs + pair) * (SLICE * H / 2) + threadIdx.x;
       if (!dead) dead = !sweep_granules<C::NGP>(hrs, hr, base + (unsigned)s, hv, &sync[2], lane);
+      if (s + 1 < T) load_gi(s + 1);  // behind the sweep: a whole step to arrive
       STAMP(0);
 #pragma unroll
       for (int k = 0; k < C::NGP; ++k) {
@@ -282,11 +294,16 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   auto load_inputs = [&](int s) {
     const int t = dir ? s : (T - 1 - s);
     const int tp = dir ? t + 1 : t - 1;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    go = sr = sz = sn = sq = hprev = zero;
+    // UNCONDITIONAL loads (an owner lane past its clip's end, or without a previous state, reads a row of its clip's first step
+    // and the step tests `valid` / `hp_ok` where it uses the values): behind `if (t < len)` the registers were cleared first, and a
+    // write to the destination of an older load makes hipcc wait for that load by COUNT -- it cannot count the younger stores issued
+    // under divergent branches, so it waited for the step's granule stores as well (found in the bf16 kernel's stage timers:
+    // 3.3 k of 11.6 k cycles per step)
     gsc = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (owner && t < len) {
-      const long frame = (long)clip * T + t;
+    if (owner) {  // (the non-owner lanes of a wave hold no units: wave-uniform by construction of the lane map)
+      const bool in = t < len;
+      const long cl = clip_ok ? clip : b0;
+      const long frame = cl * T + (in ? t : 0), framep = cl * T + ((in && tp >= 0 && tp < len) ? tp : 0);
       go = *reinterpret_cast<const f32x4*>(p.d_out + frame * (2 * H) + dir * H + j0);
       // the dropout scale stays beside the raw load and is applied where the gradient is used, a step later: multiplying here
       // made the wave wait for the load it had just issued -- a memory latency in front of every sweep of a layer with dropout
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
       sz = *reinterpret_cast<const f32x4*>(sp + H);
       sn = *reinterpret_cast<const f32x4*>(sp + 2 * H);
       sq = *reinterpret_cast<const f32x4*>(sp + 3 * H);
-      if (tp >= 0 && tp < len) hprev = *reinterpret_cast<const f32x4*>(p.out + ((long)clip * T + tp) * (2 * H) + dir * H + j0);
+      hprev = *reinterpret_cast<const f32x4*>(p.out + framep * (2 * H) + dir * H + j0);
     }
   };
   load_inputs(0);
@@ -309,6 +326,8 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
     const long frame = (long)clip * T + t;
     const bool valid = t < len;
     const bool last = s + 1 == T;  // nothing consumes the last dh_prev
+    const int tpc = dir ? t + 1 : t - 1;
+    const bool hp_ok = tpc >= 0 && tpc < len;
     f32x4 dcarry = dh;
     f32x4 dar = {0.f, 0.f, 0.f, 0.f}, daz = dar, dan = dar, dqn = dar;
     if (owner) {
@@ -317,7 +336,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
         for (int e = 0; e < 4; ++e) {
           const float d = go[e] * gsc[e] + dh[e];
           const float dn = d * (1.0f - sz[e]);
-          const float dz = d * (hprev[e] - sn[e]);
+          const float dz = d * ((hp_ok ? hprev[e] : 0.f) - sn[e]);
           dan[e] = dn * (1.0f - sn[e] * sn[e]);
           dar[e] = dan[e] * sq[e] * sr[e] * (1.0f - sr[e]);
           daz[e] = dz * sz[e] * (1.0f - sz[e]);
@@ -333,6 +352,10 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
         *reinterpret_cast<f32x4*>(dp + 2 * C::UP) = dqn;
       }
     }
+    // The next step's inputs are requested here, into the registers the gate gradients above have just finished with: loads return
+    // in order, so requested behind the publish (the first version) the sweep's L2 hits queued behind six HBM misses
+    // (found in the bf16 kernel's stage timers: 3.3 k of 11.6 k cycles per step)
+    if (!last) load_inputs(s + 1);
     if (!last) {
       __syncthreads();
       STAMP(4);
@@ -368,7 +391,6 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
       *reinterpret_cast<f32x4*>(gp + 3 * H) = dqn;
     }
     if (last) break;
-    load_inputs(s + 1);
     // sum the P partials of this part's units: thread -> positions 2 tid, 2 tid + 1 of the [clip][UP] tile
     float xv[2 * NGP];
     const int xr = ((((s & 1) * pairs + pair) * P + part) * P * SLICE * C::UP) / 2 + threadIdx.x;
