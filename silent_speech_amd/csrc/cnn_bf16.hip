@@ -376,6 +376,9 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
 // channel group = 2 x 18 fragments (144 registers) for the whole walk and multiplies them with some of the frame's nine pixel
 // tiles (16 consecutive pixels each: conv_fwd's A-fragment read as the B operand), 36 MFMAs and 18 fragment reads per tile.  Waves 6 and 7 are PRODUCERS: they write the next frame (loaded a whole frame time earlier) into the other
 // image, copy the previous frame's sign mask out and finish its average; one workgroup barrier per frame.
+#ifndef SS_L4_NRD
+#define SS_L4_NRD 9
+#endif
 struct ConvLastWsParams {
   const bf16_t* in;   // (N, 12, 12, 64)
   int N;
@@ -437,9 +440,8 @@ __global__ __launch_bounds__(NT, 2) void conv_last_fwd_ws_kernel(ConvLastWsParam
   }
 
   // producers: a frame is 144 pixels x 8 pieces of 16 bytes = 1152 pieces, 9 per producer thread
-  // (in three rounds of three pieces: nine quads of staging registers beside the consumers' 144 weight registers spilled; the
-  // frame was touched a pass earlier -- below -- so a round costs an L2 hit, not an HBM miss)
-  constexpr int NLD = (NPIX * (C3 / 8) + NPT - 1) / NPT, NRD = 3;
+  // (in rounds of NRD pieces: nine quads of staging registers live across a pass beside the consumers' 144 weight registers spilled)
+  constexpr int NLD = (NPIX * (C3 / 8) + NPT - 1) / NPT, NRD = SS_L4_NRD;
   static_assert(NLD % NRD == 0, "load rounds");
   const int pt = tid - NCONS * 64;
   auto copy_frame = [&](int n, bf16_t* img) {
@@ -520,13 +522,6 @@ __global__ __launch_bounds__(NT, 2) void conv_last_fwd_ws_kernel(ConvLastWsParam
           }
       }
     } else {
-      // the frame after the next is TOUCHED (one dword per 128-byte line, two registers): the real loads of the next pass then
-      // find it in L2 instead of paying an HBM miss inside the pass
-      if (n + 2 * stride < p.N) {
-        const unsigned* t = reinterpret_cast<const unsigned*>(p.in + (long)(n + 2 * stride) * NPIX * C3);
-        const unsigned t0 = t[32 * pt], t1 = pt < NPIX - NPT ? t[32 * (pt + NPT)] : 0u;
-        asm volatile("" ::"v"(t0), "v"(t1));
-      }
       // the previous frame's mask and average leave (its buffers are this pass's `cur ^ 1`)
       if (it > 0) {
         const long np = n - stride;
