@@ -244,9 +244,21 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
   if ((int)blockIdx.x < p.N) pre.issue(p.in + (long)blockIdx.x * H * W * CIN, 0, tid);
   STAMP_ENTRY;
   STAMP_DECL;
+  // The pooled map of frame n leaves for HBM at the top of frame n + 1, BEHIND the commit of that frame's prefetched image: vector
+  // memory operations retire in order and hipcc cannot count stores issued in a loop, so the commit's wait for its (older) loads is
+  // vmcnt(0) -- with the copy-out in front of it that wait sat through the stores' round trip every frame.
+  auto copy_out = [&](int n) {
+    uint4* da = reinterpret_cast<uint4*>(p.out + (long)n * HO * WO * COUT);
+    for (int q = tid; q < HO * WO * COUT * 2 / 16; q += NT) da[q] = reinterpret_cast<const uint4*>(oa)[q];
+    uint4* di = reinterpret_cast<uint4*>(p.idx + (long)n * HO * WO * COUT);
+    for (int q = tid; q < HO * WO * COUT / 16; q += NT) di[q] = reinterpret_cast<const uint4*>(oi)[q];
+  };
+  int n_prev = -1;
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     STAMP(15);
     pre.commit(img, 0, tid);
+    if (!LAST && n_prev >= 0) copy_out(n_prev);  // (its staging area is rewritten behind the barrier below)
+    n_prev = n;
     if (LAST)
       for (int q = tid; q < COUT; q += NT) s_feat[q] = 0.f;
     STAMP(0);
@@ -356,15 +368,10 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(ConvFwdParams p) {
         }
         __syncthreads();
       }
-    } else {
-      uint4* da = reinterpret_cast<uint4*>(p.out + (long)n * HO * WO * COUT);
-      for (int q = tid; q < HO * WO * COUT * 2 / 16; q += NT) da[q] = reinterpret_cast<const uint4*>(oa)[q];
-      uint4* di = reinterpret_cast<uint4*>(p.idx + (long)n * HO * WO * COUT);
-      for (int q = tid; q < HO * WO * COUT / 16; q += NT) di[q] = reinterpret_cast<const uint4*>(oi)[q];
-      // no barrier: the next frame's load writes img only, and its epilogue writes oa / oi behind the barrier after that load
     }
     STAMP(5);
   }
+  if (!LAST && n_prev >= 0) copy_out(n_prev);
   STAMP_FLUSH();
 }
 
@@ -633,6 +640,16 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
   __syncthreads();
   STAMP_DECL;
 
+  // A half's pooled rows leave for HBM.  The second half's copy is deferred to the top of the NEXT frame, behind the first use of that
+  // frame's prefetched bytes: vector memory operations retire in order and hipcc cannot count stores issued in a loop, so the wait
+  // for the (older) prefetch is vmcnt(0) -- with the copy-out in front of it that wait sat through the stores' round trip.
+  auto copy_half = [&](int n, int half) {
+    uint4* da = reinterpret_cast<uint4*>(p.a2 + ((long)n * HO + half * HH) * WO * C2);
+    for (int q = tid; q < HH * WO * C2 * 2 / 16; q += NT) da[q] = reinterpret_cast<const uint4*>(oa)[q];
+    uint4* di = reinterpret_cast<uint4*>(p.i2 + ((long)n * HO + half * HH) * WO * C2);
+    for (int q = tid; q < HH * WO * C2 / 16; q += NT) di[q] = reinterpret_cast<const uint4*>(oi)[q];
+  };
+  int n_pending = -1;
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
     STAMP(15);
     // ---- statistics, table, bf16 image (as conv1_fwd_kernel)
@@ -652,6 +669,10 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
     su = wave_sum_u32(su);
     sq = wave_sum_u32(sq);
     if (lane == 0) { s_red[2 * wv] = su; s_red[2 * wv + 1] = sq; }
+    if (n_pending >= 0) {  // the previous frame's second half (its staging area is rewritten three barriers further on)
+      copy_half(n_pending, 1);
+      n_pending = -1;
+    }
     __syncthreads();
     if (tid == 0) {
       unsigned long long tsu = 0, tsq = 0;
@@ -745,15 +766,17 @@ __global__ __launch_bounds__(NT, 2) void conv12_fwd_kernel(Conv12Params p) {
       STAMP(3);
       __syncthreads();
       STAMP(4);
-      uint4* da = reinterpret_cast<uint4*>(p.a2 + ((long)n * HO + half * HH) * WO * C2);
-      for (int q = tid; q < HH * WO * C2 * 2 / 16; q += NT) da[q] = reinterpret_cast<const uint4*>(oa)[q];
-      uint4* di = reinterpret_cast<uint4*>(p.i2 + ((long)n * HO + half * HH) * WO * C2);
-      for (int q = tid; q < HH * WO * C2 / 16; q += NT) di[q] = reinterpret_cast<const uint4*>(oi)[q];
-      STAMP(5);
-      __syncthreads();  // the second half's (and the next frame's) epilogues rewrite the staging area
-      STAMP(6);
+      if (half == 0) {
+        copy_half(n, 0);
+        STAMP(5);
+        __syncthreads();  // the second half's epilogues rewrite the staging area
+        STAMP(6);
+      } else {
+        n_pending = n;  // leaves at the top of the next frame, behind the wait for that frame's prefetched bytes (see copy_half)
+      }
     }
   }
+  if (n_pending >= 0) copy_half(n_pending, 1);
   STAMP_FLUSH();
 }
 

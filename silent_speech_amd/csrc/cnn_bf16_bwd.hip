@@ -509,6 +509,8 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
     }
   };
   if ((int)blockIdx.x < p.N) issue(blockIdx.x, 0);
+  bool out_pending = false;
+  int out_n = 0, out_y0 = 0;
   STAMP_ENTRY;
   STAMP_DECL;
   for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
@@ -530,6 +532,14 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
         pm.commit(s_dfeat, dyi, ID::at(0, 0), ID::RS, ID::PS, W, tid);
       } else {
         pe.commit(dyi, ID::at(-1, 0), ID::RS, ID::PS, y0 - 1, tid);
+      }
+      // the previous band's result leaves HERE, behind the commit of this band's prefetched operands: vector memory operations
+      // retire in order and hipcc cannot count stores issued in a loop, so the commit's wait for its (older) loads is vmcnt(0) --
+      // with the copy-out in front of it that wait sat through the stores' round trip every band
+      if (STAGE && out_pending) {
+        uint4* dst = reinterpret_cast<uint4*>(p.da_in + ((long)out_n * H + out_y0) * W * CIN);
+        for (int q = tid; q < BH * W * CIN * 2 / 16; q += NT) dst[q] = reinterpret_cast<const uint4*>(oa)[q];
+        out_pending = false;
       }
       STAMP(0);
       __syncthreads();
@@ -571,13 +581,13 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_kernel(ConvBwdParams p) {
       STAMP(3);
       __syncthreads();
       STAMP(4);
-      if (STAGE) {
-        uint4* dst = reinterpret_cast<uint4*>(p.da_in + ((long)n * H + y0) * W * CIN);
-        for (int q = tid; q < BH * W * CIN * 2 / 16; q += NT) dst[q] = reinterpret_cast<const uint4*>(oa)[q];
-        // no barrier: the next band's commit rewrites dy only; its epilogue writes the staging area behind the barrier after that
-      }
+      if (STAGE) { out_pending = true; out_n = n; out_y0 = y0; }  // (the staging area is rewritten behind the next band's first barrier)
       STAMP(5);
     }
+  }
+  if (STAGE && out_pending) {
+    uint4* dst = reinterpret_cast<uint4*>(p.da_in + ((long)out_n * H + out_y0) * W * CIN);
+    for (int q = tid; q < BH * W * CIN * 2 / 16; q += NT) dst[q] = reinterpret_cast<const uint4*>(oa)[q];
   }
   STAMP_FLUSH();
 }
