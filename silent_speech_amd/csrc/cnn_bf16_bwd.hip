@@ -306,23 +306,16 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
       }
       STAMP(1);
       if (RC) {
-        // a1 rows y0-1 .. y0+BH of the band: recomputed inside the frame, zero outside it.  Rows y0-1 and y0 of a band that is not
-        // the frame's first ARE rows BH-1 and BH of the band before it: the two waves that are about to recompute those image rows
-        // (local rows 15 and 16: waves 6 and 7, second iteration) first move them to local rows -1 and 0 -- 16 rows = two per wave
-        // are left to compute instead of 18 (three for two of the waves: the stage ends with its slowest wave).
-        static_assert(!RC || BH == 2 * NW, "two recomputed rows per wave and band");
-        const int yp0 = y0 > 0 ? y0 + 1 : 0, yp1 = y0 + BH + 1 < H ? y0 + BH + 1 : H;
-        if (y0 > 0 && wv >= NW - 2) {  // wave-uniform
-          const int rs = wv == NW - 2 ? BH - 1 : BH, rd = rs - BH;
-          for (int q = lane; q < W * CIN / 8; q += 64)
-            *reinterpret_cast<uint4*>(ai + IA::at(rd, 0) + 8 * q) = *reinterpret_cast<const uint4*>(ai + IA::at(rs, 0) + 8 * q);
-        }
+        // a1 rows y0-1 .. y0+BH of the band: recomputed inside the frame, zero outside it
+        // (rows y0-1 and y0 ARE rows BH-1 and BH of the band before: moving them instead of recomputing them -- 16 rows = two per wave
+        // instead of 18 -- was built and measured: 377.5 -> 407.7 us per launch, the two waves that move rows hold the stage up)
+        const int yp0 = y0 > 0 ? y0 - 1 : 0, yp1 = y0 + BH + 1 < H ? y0 + BH + 1 : H;
         conv1_rows(ximg, [&](int q) { return lds_frag(bqs + (q * 64 + lane) * 8); }, bias1, yp0, yp1, y0, ai, IA::at(0, 0), IA::RS,
                    IA::PS, nullptr, wv, g, li);
         if (y0 == 0)
           for (int q = tid; q < W * CIN / 8; q += NT) *reinterpret_cast<uint4*>(ai + IA::at(-1, 0) + 8 * q) = uint4{0u, 0u, 0u, 0u};
-        if (y0 + BH == H && wv == NW - 1)  // (the wave that has just moved the old row BH away)
-          for (int q = lane; q < W * CIN / 8; q += 64) *reinterpret_cast<uint4*>(ai + IA::at(BH, 0) + 8 * q) = uint4{0u, 0u, 0u, 0u};
+        if (y0 + BH == H)
+          for (int q = tid; q < W * CIN / 8; q += NT) *reinterpret_cast<uint4*>(ai + IA::at(BH, 0) + 8 * q) = uint4{0u, 0u, 0u, 0u};
       } else {
         pa.commit(ai, -1, tid);
       }
