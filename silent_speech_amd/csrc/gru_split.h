@@ -123,29 +123,31 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   // (unconditional for the owner waves: a lane past its clip's end reads its clip's first row and never uses the values -- behind
   // `valid` the registers were cleared first, and hipcc waits for a step's younger stores before it overwrites the destination
   // of an older load)
-  f32x4 ngr = {0.f, 0.f, 0.f, 0.f}, ngz = ngr, ngn = ngr;
-  auto load_gi = [&](int s) {
+  // input-projection gates of a step: independent of the recurrence, requested a step AHEAD behind the previous step's sweep into
+  // the other of two register sets (the step loop runs two steps per turn).  The first version requested them at the top of their
+  // own step, "in flight during the sweep": loads return in order, so the sweep's L2 hits queued behind these three HBM misses
+  // (found in the bf16 kernels' stage timers); one set copied at the top of the step made the copy wait for them there.
+  struct Gi { f32x4 r, z, n; };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  Gi gA{zero4, zero4, zero4}, gB{zero4, zero4, zero4};
+  auto load_gi = [&](int s, Gi& d) {
     if (!owner) return;  // wave-uniform
     const int t = dir ? (T - 1 - s) : s;
     const long fl = (long)(clip_ok ? clip : b0) * T + (t < len ? t : 0);
     const float* gp = p.gi + (dir_off + fl) * (3 * H) + j0;
-    ngr = *reinterpret_cast<const f32x4*>(gp);
-    ngz = *reinterpret_cast<const f32x4*>(gp + H);
-    ngn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+    d.r = *reinterpret_cast<const f32x4*>(gp);
+    d.z = *reinterpret_cast<const f32x4*>(gp + H);
+    d.n = *reinterpret_cast<const f32x4*>(gp + 2 * H);
   };
-  load_gi(0);
+  load_gi(0, gA);
   STAMP_ENTRY;
   STAMP_DECL;
-  for (int s = 0; s < T; ++s) {
+  auto step = [&](int s, const Gi& gc, Gi& gnx) {
     STAMP(15);
     const int t = dir ? (T - 1 - s) : s;
     const long frame = (long)clip * T + t;
     const bool valid = t < len;
-    // input-projection gates of this step: independent of the recurrence, requested a step AHEAD behind the previous step's sweep
-    // (load_gi).  The first version requested them at the top of their own step, "in flight during the sweep": loads return in
-    // order, so the sweep's L2 hits queued behind these three HBM misses (found in the bf16 BPTT kernel's stage timers).
-    const f32x4 gr = ngr, gz = ngz, gn = ngn;
-    if (s == 0 && T > 1) load_gi(1);
+    if (s == 0 && T > 1) load_gi(1, gnx);
     f32x4 ar = br, az = bz, an = bn;
     if (s > 0) {
       // the full previous state of the slice, swept ONCE per workgroup into an LDS panel (what a step publishes is
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
       float hv[2 * C::NGP];
       const int hr = (((s - 1) & 1) * pairs + pair) * (SLICE * H / 2) + threadIdx.x;
       if (!dead) dead = !sweep_granules<C::NGP>(hrs, hr, base + (unsigned)s, hv, &sync[2], lane);
-      if (s + 1 < T) load_gi(s + 1);  // behind the sweep: a whole step to arrive
+      if (s + 1 < T) load_gi(s + 1, gnx);  // behind the sweep: a whole step to arrive
       STAMP(0);
 #pragma unroll
       for (int k = 0; k < C::NGP; ++k) {
@@ -195,9 +197,9 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
       f32x4 r, z, n, hn;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        r[e] = sigmoid_f(gr[e] + ar[e]);
-        z[e] = sigmoid_f(gz[e] + az[e]);
-        n[e] = tanh_f(gn[e] + r[e] * an[e]);
+        r[e] = sigmoid_f(gc.r[e] + ar[e]);
+        z[e] = sigmoid_f(gc.z[e] + az[e]);
+        n[e] = tanh_f(gc.n[e] + r[e] * an[e]);
         hn[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
       }
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -223,6 +225,10 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
         }
       }
     }
+  };
+  for (int s = 0; s < T; s += 2) {
+    step(s, gA, gB);
+    if (s + 1 < T) step(s + 1, gB, gA);
   }
   STAMP_FLUSH();
   finish_launch(sync, gen);
