@@ -100,8 +100,22 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
   const int i = lane & 15, g = lane >> 4;
   const bool stash = p.st_a1 != nullptr;
 
-  // ---- one-time: zero LDS (halos), load weights into MFMA B fragments
-  for (int q = tid; q < LL::total; q += NT) lds[q] = 0.f;
+  // ---- one-time: load weights into MFMA B fragments, zero LDS (halos).  W2 and W3 go through LDS (coalesced 16-byte loads, then
+  // 90 ds_read_b32 per lane): read straight from global memory the 90 strided 4-byte loads per lane were most of the 30 k cycles
+  // a workgroup spent in front of its frame loop (14 us of a 470 us launch, stage timers)
+  static_assert(LL::total >= 1152 + 3456, "weight staging area");
+  if (((reinterpret_cast<uintptr_t>(p.w2) | reinterpret_cast<uintptr_t>(p.w3)) & 15) == 0) {  // (views of a flat bucket need not be)
+    const f32x4* g2 = reinterpret_cast<const f32x4*>(p.w2);
+    const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3);
+    for (int q = tid; q < 1152 / 4; q += NT) reinterpret_cast<f32x4*>(lds)[q] = g2[q];
+    for (int q = tid; q < 3456 / 4; q += NT) reinterpret_cast<f32x4*>(lds + 1152)[q] = g3[q];
+  } else {
+    for (int q = tid; q < 1152; q += NT) lds[q] = p.w2[q];
+    for (int q = tid; q < 3456; q += NT) lds[1152 + q] = p.w3[q];
+  }
+  __syncthreads();
+  const float* w2s = lds;
+  const float* w3s = lds + 1152;
   // conv1: k = 4kk+g -> (ry = k/3, kx = k%3) over the 4x3 input window of output rows y, y+1;
   // column i = (c = i&7, s = i>>3): W1[c][ky = ry - s][kx], zero outside the 3x3 kernel
   float bw1[3];
@@ -114,14 +128,16 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
   }
   float bw2[18];  // conv2: k-step kk -> tap = kk/2, c = 4*(kk%2)+g ; n = i
 #pragma unroll
-  for (int kk = 0; kk < 18; ++kk) bw2[kk] = p.w2[i * 72 + (4 * (kk & 1) + g) * 9 + (kk >> 1)];
+  for (int kk = 0; kk < 18; ++kk) bw2[kk] = w2s[i * 72 + (4 * (kk & 1) + g) * 9 + (kk >> 1)];
   float bw3a[36], bw3b[36];  // conv3: tap = kk/4, c = 4*(kk%4)+g ; n = i and 16+i
 #pragma unroll
   for (int kk = 0; kk < 36; ++kk) {
     const int c = 4 * (kk & 3) + g, tap = kk >> 2;
-    bw3a[kk] = p.w3[i * 144 + c * 9 + tap];
-    bw3b[kk] = (i < 8) ? p.w3[(16 + i) * 144 + c * 9 + tap] : 0.f;
+    bw3a[kk] = w3s[i * 144 + c * 9 + tap];
+    bw3b[kk] = (i < 8) ? w3s[(16 + i) * 144 + c * 9 + tap] : 0.f;
   }
+  __syncthreads();
+  for (int q = tid; q < LL::total; q += NT) lds[q] = 0.f;
   __syncthreads();
   if (tid < 8) s_b1[tid] = p.b1[tid];
   if (tid < 16) s_b2[tid] = p.b2[tid];
