@@ -616,7 +616,7 @@ template <int AKC, int BKC>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_ring_kernel(GemmBfParams p, int gx, int gy, int kcat) {
   extern __shared__ __attribute__((aligned(16))) char rlds[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)rlds;
-  const int wg = xcd_contiguous_id();
+  const int wg = (p.flags & 2048) ? (int)blockIdx.x : xcd_contiguous_id();  // (2048: diagnostic, tiles as dispatched)
   const int bx = wg % gx, by = (wg / gx) % gy, bz = wg / (gx * gy);
   const int batch = bz / p.splits, split = bz % p.splits;
   const int m0 = by * RBM, n0 = bx * RBN;
@@ -877,7 +877,7 @@ extern "C" int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, 
   SS_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && splits > 0, SS_ERR_ARG);
   SS_REQUIRE(a_group > 0 && b_group > 0, SS_ERR_ARG);
   // bit0 accumulate, bit2 atomics, bit3 operands are bf16 in HBM, bit4 the `batch` (A, B) pairs are summed into ONE C (K concatenated)
-  SS_REQUIRE(!(flags & ~(29 | 768 | 1024)), SS_ERR_UNSUPPORTED);  // (256 / 512: diagnostic)
+  SS_REQUIRE(!(flags & ~(29 | 768 | 1024 | 2048)), SS_ERR_UNSUPPORTED);  // (256 / 512: diagnostic)
   SS_REQUIRE(!(flags & 16) || ((flags & 8) && K % 64 == 0 && splits == 1 && !(flags & 4)), SS_ERR_UNSUPPORTED);
   SS_REQUIRE(splits == 1 || (flags & 1), SS_ERR_ARG);            // K slices add into a C the caller initialised
   SS_REQUIRE(!(flags & 4) || (flags & 1), SS_ERR_ARG);

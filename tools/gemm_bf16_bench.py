@@ -73,6 +73,13 @@ def run_group(name, l, reps=20):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "xcd":  # tiles dealt to the XCDs in contiguous ranges (default) against as dispatched (flag 2048)
+        for rep in range(2):
+            for fl in (0, 2048):
+                run("ih l1 (store)", 1, 1, N, 3 * H, 2 * H, 2 * H, 2 * H, fl, 1, 2)
+                run("dX l1 (K-concatenated, store)", 1, 0, N, 2 * H, 3 * H, 4 * H, 2 * H, 16 | fl, 1, 2)
+                run("dW_ih l1 (2 slices, atomics)", 0, 0, 3 * H, 2 * H, N, 4 * H, 2 * H, 5 | fl, 2, 2)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "step":
         run_group("dW group l1", 1)
         run_group("dW group l0", 0)
