@@ -104,3 +104,25 @@ def test_host_side_size_queries_need_no_gpu():
     assert lib.ss_gru_bf16_sync_bytes(256, 2000, 512, C.byref(n)) == 0 and n.value == 0        # step tags are 10 bits
     assert lib.ss_gru_bf16_sync_bytes(0, 30, 512, C.byref(n)) != 0
     assert _lib.gru_sync_bytes(256, 30, 192) > 0 and _lib.gru_sync_bytes(4096, 60, 192) == 0   # f32: one CU per slice for big batches
+
+
+def test_bf16_weight_gradient_group_size_query_needs_no_gpu():
+    """The grouped bf16 weight-gradient GEMM (ss_gemm_bf16_splitk_group): shape-only problem records of the config-5 GRU layers, the
+    scratch size query (host code) and its argument checks -- K must be whole 64-deep tiles, at most eight problems per group."""
+    from types import SimpleNamespace
+
+    from silent_speech_amd import _lib
+    from silent_speech_amd import engine_bf16 as E
+
+    cfg = SimpleNamespace(hidden=512, in_dim=148)
+    l1 = E.dw_problems(cfg, 256, 30, 1, 1024)
+    l0 = E.dw_problems(cfg, 256, 30, 0, 152)
+    assert [(q.M, q.N, q.K) for q in l1] == [(1536, 1024, 7680), (1024, 512, 7424), (512, 512, 7424)]
+    assert E.dw_group_ok(l1) and E.dw_group_ok(l0)
+    assert _lib.gemm_group_ws_floats(l1, bf16=True) > 0 and _lib.gemm_group_ws_floats(l1 + l0, bf16=True) > 0
+    assert not E.dw_group_ok(E.dw_problems(cfg, 5, 7, 1, 1024))                 # K = 35 / 30: the per-problem launches take these
+    with pytest.raises(RuntimeError):
+        _lib.gemm_group_ws_floats(E.dw_problems(cfg, 5, 7, 1, 1024), bf16=True)  # ... and the entry point refuses them
+    with pytest.raises(RuntimeError):
+        _lib.gemm_group_ws_floats(l1 + l0 + l1, bf16=True)                      # nine problems
+
