@@ -416,12 +416,14 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
             L.call("ss_c5_conv_last_wgrad", ws.a3.data_ptr(), dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), ws.feat.data_ptr(), N,
                    gw[3], gb[3], G["roi_cnn.fc.weight"].data_ptr(), G["roi_cnn.fc.bias"].data_ptr(), s)
             L.call("ss_c5_conv_last_dgrad", dz, cfg.in_dim, cfg.roi_emb, wfc, ws.m4.data_ptr(), N, w[3], ws.da3.data_ptr(), s)
-        L.call("ss_c5_conv_wgrad_ws", 3, ws.a2.data_ptr(), ws.da3.data_ptr(), ws.i3.data_ptr(), N, gw[2], gb[2], ws.wg_part.data_ptr(),
-               ws.wg_part.numel(), s, tag="ss_c5_conv3_wgrad")
+        # (partial sums through scratch + a reduce launch pay for the last layer's 55 k elements only: launch time at B = 256, T = 30,
+        # tools/c5_fixed_cost.py / c5_last_bench.py with SS_NO_PART=1: layer 4 152 - 156 us against 172 - 174 with float atomics onto the
+        # gradient, layer 3 equal, layer 2 (4.6 k elements) 376 against 362)
+        L.call("ss_c5_conv_wgrad", 3, ws.a2.data_ptr(), ws.da3.data_ptr(), ws.i3.data_ptr(), N, gw[2], gb[2], s, tag="ss_c5_conv3_wgrad")
         L.call("ss_c5_conv_dgrad", 3, ws.da3.data_ptr(), ws.i3.data_ptr(), N, w[2], ws.da2.data_ptr(), s, tag="ss_c5_conv3_dgrad")
         bb = [P[k + ".bias"].data_ptr() for k in _CONV]
-        L.call("ss_c5_conv2_wgrad_rc_ws", R.data_ptr(), ws.st.data_ptr(), int(cfg.roi_standardize), w[0], bb[0], ws.da2.data_ptr(),
-               ws.i2.data_ptr(), N, gw[1], gb[1], ws.wg_part.data_ptr(), ws.wg_part.numel(), s, tag="ss_c5_conv2_wgrad_rc")
+        L.call("ss_c5_conv2_wgrad_rc", R.data_ptr(), ws.st.data_ptr(), int(cfg.roi_standardize), w[0], bb[0], ws.da2.data_ptr(),
+               ws.i2.data_ptr(), N, gw[1], gb[1], s)
         if FUSE_DGRAD2_WGRAD1:  # d a1 (the largest gradient map) is born and consumed in LDS: 1.13 GB per step less through HBM
             L.call("ss_c5_conv2_dgrad_conv1_wgrad_i1", ws.da2.data_ptr(), ws.i2.data_ptr(), N, w[1], R.data_ptr(), ws.st.data_ptr(),
                    int(cfg.roi_standardize), w[0], bb[0], None, gw[0], gb[0], L.ptr(ws.i1), s, tag="ss_c5_conv2_dgrad_conv1_wgrad")

@@ -40,15 +40,16 @@ def main():
     gw2, gb2 = torch.zeros(32, 16, 3, 3, device=dev), torch.zeros(32, device=dev)
     gw3, gb3 = torch.zeros(64, 32, 3, 3, device=dev), torch.zeros(64, device=dev)
     part = torch.empty(256 * 96 * 64 * 9, device=dev)
+    pn = 0 if os.environ.get("SS_NO_PART") else part.numel()  # SS_NO_PART=1: float atomics straight onto the gradients
     s = L.stream()
     P = lambda t: t.data_ptr()  # noqa: E731
     kernels = {
         "conv12_fwd (+i1)": lambda N: L.call("ss_c5_conv12_fwd_i1", P(R), N, 1, P(w1), P(b1), P(w2), P(b2), P(a2), P(i2), P(st), P(i1), s),
         "conv3_fwd": lambda N: L.call("ss_c5_conv_fwd", 3, P(a2), N, P(w3), P(b3), P(a3), P(i3), s),
-        "conv3_wgrad": lambda N: L.call("ss_c5_conv_wgrad_ws", 3, P(a2), P(da3), P(i3), N, P(gw3), P(gb3), P(part), part.numel(), s),
+        "conv3_wgrad": lambda N: L.call("ss_c5_conv_wgrad_ws", 3, P(a2), P(da3), P(i3), N, P(gw3), P(gb3), P(part), pn, s),
         "conv3_dgrad": lambda N: L.call("ss_c5_conv_dgrad", 3, P(da3), P(i3), N, P(w3), P(da2), s),
         "conv2_wgrad_rc": lambda N: L.call("ss_c5_conv2_wgrad_rc_ws", P(R), P(st), 1, P(w1), P(b1), P(da2), P(i2), N, P(gw2), P(gb2), P(part),
-                                           part.numel(), s),
+                                           pn, s),
         "conv2_dgrad_conv1_wgrad": lambda N: L.call("ss_c5_conv2_dgrad_conv1_wgrad_i1", P(da2), P(i2), N, P(w2), P(R), P(st), 1, P(w1), P(b1),
                                                     None, P(gw1), P(gb1), P(i1), s),
     }

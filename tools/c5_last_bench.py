@@ -38,7 +38,7 @@ def main():
     for N in (256, 512, 1024, 2560, 7680):
         tf = timeit(lambda: L.call("ss_c5_conv_last_fwd_feat", a3.data_ptr(), N, w4.data_ptr(), b4.data_ptr(), m4.data_ptr(), feat.data_ptr(), s))
         td = timeit(lambda: L.call("ss_c5_conv_last_dgrad_df", dfe.data_ptr(), m4.data_ptr(), N, w4.data_ptr(), da3.data_ptr(), s))
-        tw = timeit(lambda: L.call("ss_c5_conv_last_wgrad_df", a3.data_ptr(), dfe.data_ptr(), m4.data_ptr(), N, gw4.data_ptr(), gb4.data_ptr(), part.data_ptr(), part.numel(), s))
+        tw = timeit(lambda: L.call("ss_c5_conv_last_wgrad_df", a3.data_ptr(), dfe.data_ptr(), m4.data_ptr(), N, gw4.data_ptr(), gb4.data_ptr(), part.data_ptr(), 0 if os.environ.get("SS_NO_PART") else part.numel(), s))
         print(f"N={N:5d} ({N // 256:2d} frames per workgroup): fwd {tf:7.1f} us   dgrad {td:7.1f} us   wgrad {tw:7.1f} us", flush=True)
 
 
