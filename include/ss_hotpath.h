@@ -374,6 +374,13 @@ int ss_c5_conv2_wgrad_rc(const uint8_t* R, const float* st, int standardize, con
 int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
                const float* b_hh_r, const int32_t* lengths, int B, int T, int H, float* out, float* save,
                void* sync_ws, ss_stream_t stream);
+/* The same with nn.GRU's inter-layer dropout as a by-product: out_drop (B,T,2H) = out x the keep-scales of ss_dropout's Philox
+ * stream at (drop_seed, drop_offset) -- what the next layer's input projection multiplies (train_model_official.py:261-267,
+ * dropout=0.2 between the layers).  out_drop != NULL needs the multi-CU form (sync_ws given, ss_gru_sync_bytes(B,T,H) != 0);
+ * otherwise SS_ERR_UNSUPPORTED and the caller runs ss_dropout on `out`. */
+int ss_gru_fwd_drop(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f, const float* b_hh_r,
+                    const int32_t* lengths, int B, int T, int H, float* out, float* save, float* out_drop, float drop_p,
+                    uint64_t drop_seed, uint64_t drop_offset, void* sync_ws, ss_stream_t stream);
 
 /* bytes of sync_ws the multi-CU recurrence needs for this shape; 0 = the shape always takes the one-CU-per-slice
  * kernels (pass NULL). */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "ss_mouth_gate": [_vp, _i, _vp, _d, _d, _d, _vp, _vp, _vp],
     "ss_clip_gate": [_vp, _i, _vp, _vp, _d, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_gru_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "ss_gru_fwd_drop": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _u64, _u64, _vp, _vp],
     "ss_gru_sync_bytes": [_i, _i, _i, _vp],
     "ss_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_gru_bias_grad": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -39,6 +39,11 @@ struct GruFwdParams {
   float* out;           // [B][T][2H]   forward dir in cols [0,H), reverse in [H,2H)
   float* save;          // [2][B*T][4][H]  r, z, n, q=(W_hn h + b_hn); may be null (inference)
   int B, T;
+  // nn.GRU's inter-layer dropout as a by-product (multi-CU form only): out_drop = out * Philox keep-scale of ss_dropout's stream
+  // (seed, offset, element index = position in `out`), or null
+  float* out_drop;
+  float drop_p;
+  uint64_t drop_seed, drop_off;
 };
 
 template <int H>
@@ -320,17 +325,24 @@ extern "C" int ss_gru_sync_bytes(int B, int T, int H, long* bytes) {
   return SS_OK;
 }
 
-extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
-                          const float* b_hh_r, const int32_t* lengths, int B, int T, int H, float* out, float* save,
-                          void* sync_ws, ss_stream_t stream) {
+// out_drop != NULL: the dropped-out copy of `out` the next layer's input projection multiplies (nn.GRU's inter-layer dropout, the
+// stream of ss_dropout at (seed, offset)) is written by the recurrence kernel itself, behind each step's publish -- one launch and
+// one read of `out` less per training step.  Needs the multi-CU form (sync_ws given and the batch small enough for it:
+// ss_gru_sync_bytes() != 0); SS_ERR_UNSUPPORTED otherwise -- the caller then runs ss_dropout.
+extern "C" int ss_gru_fwd_drop(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
+                               const float* b_hh_r, const int32_t* lengths, int B, int T, int H, float* out, float* save,
+                               float* out_drop, float drop_p, uint64_t drop_seed, uint64_t drop_offset, void* sync_ws,
+                               ss_stream_t stream) {
   SS_REQUIRE(gi && w_hh_f && w_hh_r && b_hh_f && b_hh_r && lengths && out, SS_ERR_ARG);
-  SS_REQUIRE(B > 0 && T > 0, SS_ERR_ARG);
+  SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
   GruFwdParams p;
   p.gi = gi; p.w_hh[0] = w_hh_f; p.w_hh[1] = w_hh_r; p.b_hh[0] = b_hh_f; p.b_hh[1] = b_hh_r;
   p.lengths = lengths; p.out = out; p.save = save; p.B = B; p.T = T;
+  p.out_drop = out_drop; p.drop_p = drop_p; p.drop_seed = drop_seed; p.drop_off = drop_offset;
   dim3 grid(ceil_div(B, SLICE), 2);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int P = sync_ws ? gru_split_parts(B, T, H) : 0;
+  SS_REQUIRE(P || !out_drop, SS_ERR_UNSUPPORTED);
   if (P) {
     dim3 sgrid(2 * ceil_div(B, SLICE) * P);
     unsigned* sy = static_cast<unsigned*>(sync_ws);
@@ -344,6 +356,12 @@ extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_h
   else if (H == 64) hipLaunchKernelGGL(gru_fwd_kernel<64>, grid, dim3(256), 0, s, p);
   else return SS_ERR_UNSUPPORTED;
   return ss_launch_status();
+}
+
+extern "C" int ss_gru_fwd(const float* gi, const float* w_hh_f, const float* w_hh_r, const float* b_hh_f,
+                          const float* b_hh_r, const int32_t* lengths, int B, int T, int H, float* out, float* save,
+                          void* sync_ws, ss_stream_t stream) {
+  return ss_gru_fwd_drop(gi, w_hh_f, w_hh_r, b_hh_f, b_hh_r, lengths, B, T, H, out, save, nullptr, 0.f, 0, 0, sync_ws, stream);
 }
 
 extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* save, const float* w_hh_f,

@@ -216,6 +216,12 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
       STAMP(4);
       if (clip_ok) {
         *reinterpret_cast<f32x4*>(p.out + frame * (2 * H) + dir * H + j0) = o;
+        if (p.out_drop) {  // (wave-uniform) behind the publish: the Philox rounds run under the partners' exchange
+          const long e0 = frame * (2 * H) + dir * H + j0;
+          f32x4 od = o;
+          if (p.drop_p > 0.f) od *= drop_scale4(e0 >> 2, p.drop_p, p.drop_seed, p.drop_off);
+          *reinterpret_cast<f32x4*>(p.out_drop + e0) = od;
+        }
         if (p.save && valid) {
           float* sp = p.save + (dir_off + frame) * (4 * H) + j0;
           *reinterpret_cast<f32x4*>(sp) = r;

@@ -32,6 +32,7 @@ JOIN_BEFORE_CNN_BWD = True
 # (latency-bound) rather than beside that GEMM (MFMA-bound like them): 2.30 vs 2.32 ms/step
 SIDE_AFTER_DX = os.environ.get("SS_SIDE_AFTER_DX", "1") == "1"
 USE_SPLIT_GRU = True
+FUSE_GRU_DROPOUT = os.environ.get("SS_FUSE_GRU_DROPOUT", "1") != "0"  # 0: the inter-layer dropout as its own launch (ss_dropout)
 # K slices of the d W_hh GEMMs (18 / 12 output tiles): fewer, longer slices than for d W_ih halve the scratch traffic of
 # their reduce passes (measured 512: -0.3 % on the step against 768; 384 and 256: +0.4 %)
 _HH_TARGET = int(os.environ.get("SS_SPLITK_TARGET_HH", "512"))
@@ -275,14 +276,19 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
         gemm(1, 1, N, 3 * H, K, layer_in, ld_in, P[wf].data_ptr(), K, ws.gi[l].data_ptr(), 3 * H,
              bias=P[f"gru.bias_ih_l{l}"].data_ptr(), tag="gemm_gru_ih", batch=2,
              strides=(0, _pstride(P, wf, wr), N * 3 * H, _pstride(P, f"gru.bias_ih_l{l}", f"gru.bias_ih_l{l}_reverse"), 0))
-        L.call("ss_gru_fwd", ws.gi[l].data_ptr(), P[f"gru.weight_hh_l{l}"].data_ptr(),
+        drop = train and l < cfg.gru_layers - 1 and cfg.gru_dropout > 0.0
+        # nn.GRU's inter-layer dropout: a by-product of the multi-CU recurrence kernel (its own launch + read of `out` otherwise)
+        fused_drop = drop and ws.gru_sync is not None and FUSE_GRU_DROPOUT
+        L.call("ss_gru_fwd_drop", ws.gi[l].data_ptr(), P[f"gru.weight_hh_l{l}"].data_ptr(),
                P[f"gru.weight_hh_l{l}_reverse"].data_ptr(), P[f"gru.bias_hh_l{l}"].data_ptr(),
                P[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.lengths.data_ptr(), B, T, H, ws.out[l].data_ptr(),
-               ws.save[l].data_ptr() if stash else None, L.ptr(ws.gru_sync), s)
+               ws.save[l].data_ptr() if stash else None, ws.out_drop[l].data_ptr() if fused_drop else None,
+               cfg.gru_dropout if fused_drop else 0.0, seed, (l + 1) << 40, L.ptr(ws.gru_sync), s, tag="ss_gru_fwd")
         layer_in, ld_in = ws.out[l].data_ptr(), 2 * H
-        if train and l < cfg.gru_layers - 1 and cfg.gru_dropout > 0.0:
-            L.call("ss_dropout", ws.out[l].data_ptr(), ws.out_drop[l].data_ptr(), N * 2 * H, cfg.gru_dropout, seed,
-                   (l + 1) << 40, None, s)
+        if drop:
+            if not fused_drop:
+                L.call("ss_dropout", ws.out[l].data_ptr(), ws.out_drop[l].data_ptr(), N * 2 * H, cfg.gru_dropout, seed,
+                       (l + 1) << 40, None, s)
             layer_in = ws.out_drop[l].data_ptr()
     top = ws.out[cfg.gru_layers - 1]
     # ---- AttnPool + head (+ loss): one fused launch, a workgroup per clip

@@ -268,6 +268,21 @@ def test_gru_fwd_bwd(L, H, B, T, split):
            out2.data_ptr(), None, sw, L.stream())
     sync()
     assert torch.equal(out2, out_d)
+    # nn.GRU's inter-layer dropout as a by-product of the multi-CU kernel: the same bits as ss_dropout on the finished output;
+    # the one-CU form refuses (the caller then runs ss_dropout)
+    out3, od3 = torch.empty_like(out_d), torch.full_like(out_d, 7.0)
+    args = (gi_d.data_ptr(), P["gru.weight_hh_l0"].data_ptr(), P["gru.weight_hh_l0_reverse"].data_ptr(), P["gru.bias_hh_l0"].data_ptr(),
+            P["gru.bias_hh_l0_reverse"].data_ptr(), len_d.data_ptr(), B, T, H, out3.data_ptr(), None, od3.data_ptr(), 0.2, 1234, 5 << 40, sw,
+            L.stream())
+    if sw is None:
+        with pytest.raises(RuntimeError):
+            L.call("ss_gru_fwd_drop", *args)
+    else:
+        L.call("ss_gru_fwd_drop", *args)
+        od_ref = torch.empty_like(out_d)
+        L.call("ss_dropout", out_d.data_ptr(), od_ref.data_ptr(), N * 2 * H, 0.2, 1234, 5 << 40, None, L.stream())
+        sync()
+        assert torch.equal(out3, out_d) and torch.equal(od3, od_ref)
 
     dout_d = dev(wgt.reshape(N, 2 * H))
     dg_d = torch.full((2, N, 4, H), 5.0, device="cuda")
@@ -283,7 +298,7 @@ def test_gru_fwd_bwd(L, H, B, T, split):
                      (torch.cat([colsum[0], colsum[1], colsum[3]]) + 0.5).float(), atol=2e-4, rtol=1e-4)
     if split:
         assert int(sync_ws[2]) == 0, "a wait on a partner workgroup timed out"
-        assert int(sync_ws[0]) == 3 and int(sync_ws[1]) == 0  # three launches, each closed its generation
+        assert int(sync_ws[0]) == 4 and int(sync_ws[1]) == 0  # four launches (three forward, one backward), each closed its generation
     # inter-layer dropout fused into the read of d_out == ss_dropout on d_out first, bit for bit
     p_drop, seed, off = 0.25, 1234567, 3 << 40
     dmask = torch.empty_like(dout_d)
