@@ -33,7 +33,16 @@ extern "C" int ss_roi_cnn_set_max_workgroups(int n) {
 
 namespace {
 
-constexpr int NT = 256;  // threads per workgroup; TWO workgroups per CU (LDS image <= 80 KB): while one is in an epilogue, a
+#ifndef SS_FWD_NT
+#define SS_FWD_NT 256
+#endif
+// (Round 3: -DSS_FWD_NT=384 = two 6-wave workgroups per CU, a third wave per SIMD to fill the issue slots two leave empty -- MFMA
+// busy is 0.58 with each wave in MFMAs 29 % of its time.  168 registers per wave do not hold the 93 weight fragments plus a
+// stage's working set: 33 spilled, 719 us per launch against 459.  LDS (66 KB per frame image) rules out a third workgroup.
+// Also measured: the NEXT frame's pixel sums taken behind conv3, its mean / std by one thread of wave 1 beside the feature sums
+// and its grey-level table beside the fc -- three barriers and the serial f64 section out of a frame's front: 458.8 / 461.8 us
+// against 459.0 / 458.6.  A workgroup's own latency chain is not what bounds the CU's rate.)
+constexpr int NT = SS_FWD_NT;  // threads per workgroup; TWO workgroups per CU (LDS image <= 80 KB): while one is in an epilogue, a
                          // barrier or the statistics, the other's MFMAs keep the matrix pipes busy
 constexpr int NWV = NT / 64;
 
@@ -72,7 +81,7 @@ struct FwdLds {
 };
 
 template <class G>
-__global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnFwdParams p) {
   STAMP_ENTRY;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = FwdLds<G>;
@@ -246,8 +255,7 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
       constexpr int XT = W / 16;
       constexpr int UC = (XT % 4 == 0) ? 4 : (XT % 3 == 0) ? 3 : 2;
       static_assert(XT % UC == 0, "conv1 pass split");
-      constexpr int XP = XT / UC, passes = (H / 2) * XP, ppw = passes / NWV;
-      static_assert(ppw * NWV == passes && ppw % 2 == 0, "conv1 pass split");
+      constexpr int XP = XT / UC, passes = (H / 2) * XP;
       const int c = i & 7, s = i >> 3;
       const int wvu = __builtin_amdgcn_readfirstlane(wv);
       const float bias = s_b1[c];
@@ -304,13 +312,19 @@ __global__ __launch_bounds__(NT, 2) void roi_cnn_fwd_kernel(CnnFwdParams p) {
         }
       };
       f32x4 accA[UC], accB[UC];
-      mm(wvu, accA);
+      if (wvu < passes) {
+        mm(wvu, accA);
 #pragma unroll 1
-      for (int it = 0; it < ppw; it += 2) {
-        mm(wvu + NWV * (it + 1), accB);
-        epi(wvu + NWV * it, accA);
-        if (it + 2 < ppw) mm(wvu + NWV * (it + 2), accA);
-        epi(wvu + NWV * (it + 1), accB);
+        for (int ps = wvu;;) {  // (wave-uniform exits: a wave's share of the passes need not be even)
+          const int p1 = ps + NWV, p2 = p1 + NWV;
+          if (p1 < passes) mm(p1, accB);
+          epi(ps, accA);
+          if (p1 >= passes) break;
+          if (p2 < passes) mm(p2, accA);
+          epi(p1, accB);
+          if (p2 >= passes) break;
+          ps = p2;
+        }
       }
     }
     __syncthreads();
