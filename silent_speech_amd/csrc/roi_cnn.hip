@@ -41,7 +41,9 @@ namespace {
 // stage's working set: 33 spilled, 719 us per launch against 459.  LDS (66 KB per frame image) rules out a third workgroup.
 // Also measured: the NEXT frame's pixel sums taken behind conv3, its mean / std by one thread of wave 1 beside the feature sums
 // and its grey-level table beside the fc -- three barriers and the serial f64 section out of a frame's front: 458.8 / 461.8 us
-// against 459.0 / 458.6.  A workgroup's own latency chain is not what bounds the CU's rate.)
+// against 459.0 / 458.6.  And: conv2 / conv3 with two register sets of A values, the next nine k steps' ds_reads issued under the
+// current nine's MFMAs and the next unit's first nine under this unit's last (counted lgkmcnt waits in the ISA): 457.9 / 459.8
+// against 459.0 / 458.8.  A workgroup's own latency chain is not what bounds the CU's rate.)
 constexpr int NT = SS_FWD_NT;  // threads per workgroup; TWO workgroups per CU (LDS image <= 80 KB): while one is in an epilogue, a
                          // barrier or the statistics, the other's MFMAs keep the matrix pipes busy
 constexpr int NWV = NT / 64;
