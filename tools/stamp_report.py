@@ -34,6 +34,8 @@ def main():
     lengths = torch.full((B,), T, device=dev)
     y = torch.randint(0, 5, (B,), device=dev)
     lib = L.load()
+    if os.environ.get("SS_STAMP_MAX_WGS"):  # e.g. 128: one forward workgroup per CU (the cap counts CUs) -- a workgroup's solo time
+        L.call("ss_roi_cnn_set_max_workgroups", int(os.environ["SS_STAMP_MAX_WGS"]))
     for k in range(3):
         if k == 2:  # the tables accumulate over launches and a read clears them: measure the last step only
             for nm in ("ss_debug_stamps_fwd", "ss_debug_stamps_bwd"):
@@ -50,6 +52,8 @@ def main():
         assert fn(buf.ctypes.data) == 0
         t = buf.reshape(nwg, 24).astype(np.float64)
         used = 512 if which == 0 else 256   # forward: 512 workgroups of 256 threads (two per CU), backward: 256 of 512
+        if os.environ.get("SS_STAMP_MAX_WGS"):
+            used = int(os.environ["SS_STAMP_MAX_WGS"]) * (2 if which == 0 else 1)
         t = t[:used]
         stage = t[:, list(names)]
         tot = stage.sum(1).mean()
