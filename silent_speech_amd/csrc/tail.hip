@@ -64,7 +64,7 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
   // Linear(D -> MID) weights of this wave's rows, fetched NOW: the loop that consumed them straight from memory (one L2 round
   // trip per 64 columns, twelve in a row) was 20 of the kernel's 33 us; here the loads fly under the attention phases.
   // Wave wv owns rows 4 wv + u of each 64-row pass; PF_PASS x PF_IT covers MID <= 128, D <= 384, the rest takes the loop.
-  constexpr int PF_PASS = 2, PF_IT = 6;
+  constexpr int PF_PASS = 2, PF_IT = 6, PF_CH = 4;
   float wreg[PF_PASS][4][PF_IT];
 #pragma unroll
   for (int ps = 0; ps < PF_PASS; ++ps)
@@ -91,7 +91,17 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
       }
 #pragma unroll
       for (int it = 0; it < PF_IT; ++it) s += hv[it] * sw[it];
-      for (int d = lane + 64 * PF_IT; d < D; d += 64) s += hb[(long)t * D + d] * p.w_score[d];
+      for (int d0 = lane + 64 * PF_IT; d0 < D; d0 += 64 * PF_CH) {  // (D > 384: config 5's 2H = 1024) PF_CH loads per round trip
+        float h2[PF_CH], w2[PF_CH];
+#pragma unroll
+        for (int it = 0; it < PF_CH; ++it) {
+          const int d = d0 + 64 * it;
+          h2[it] = d < D ? hb[(long)t * D + d] : 0.f;
+          w2[it] = d < D ? p.w_score[d] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < PF_CH; ++it) s += h2[it] * w2[it];
+      }
       s = wave_sum(s) + bsc;
     }
     if (lane == 0) sc[t] = s;
@@ -157,11 +167,24 @@ __global__ __launch_bounds__(TNT) void tail_fwd_kernel(TailFwdParams p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] += (ps == 0 ? wreg[0][u][it] : wreg[1][u][it]) * xv[it];
     }
-    for (int d = lane + (ps < PF_PASS ? 64 * PF_IT : 0); d < D; d += 64) {
-      const float x = lnv[d];
+    // the columns the prefetch did not cover (D > 384): PF_CH x 4 loads in flight per L2 round trip instead of 4 -- at D = 1024
+    // the one-column-group-at-a-time loop was twenty dependent round trips per workgroup
+    for (int d0 = lane + (ps < PF_PASS ? 64 * PF_IT : 0); d0 < D; d0 += 64 * PF_CH) {
+      float w2[PF_CH][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (o0 + u < MID) acc[u] += p.w1[(long)(o0 + u) * D + d] * x;
+      for (int it = 0; it < PF_CH; ++it)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int d = d0 + 64 * it;
+          w2[it][u] = (d < D && o0 + u < MID) ? p.w1[(long)(o0 + u) * D + d] : 0.f;
+        }
+#pragma unroll
+      for (int it = 0; it < PF_CH; ++it) {
+        const int d = d0 + 64 * it;
+        const float x = d < D ? lnv[d] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += w2[it][u] * x;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = wave_sum(acc[u]);
