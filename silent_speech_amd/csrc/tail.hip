@@ -276,7 +276,10 @@ __global__ __launch_bounds__(TNT) void tail_bwd_kernel(TailBwdParams p) {
   __syncthreads();
   // ---- through Linear(MID -> C), Dropout, ReLU
   for (int o = tid; o < MID; o += TNT) {
+    // (sixteen weight loads per L2 round trip here and below: four at a time, as the compiler unrolls these loops by itself,
+    // made 25 + 32 dependent round trips per workgroup at C = 100, MID = 128 -- most of the kernel)
     float acc = 0.f;
+#pragma unroll 16
     for (int c = 0; c < C; ++c) acc += dl[c] * p.w4[(long)c * MID + o];
     acc *= drop_scale((long)b * MID + o, p.drop_p, p.seed, p.offset);
     if (p.mid[(long)b * MID + o] <= 0.f) acc = 0.f;
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(TNT) void tail_bwd_kernel(TailBwdParams p) {
   float s1 = 0.f, s2 = 0.f;
   for (int d = tid; d < D; d += TNT) {
     float acc = 0.f;
+#pragma unroll 16
     for (int o = 0; o < MID; ++o) acc += dmid[o] * p.w1[(long)o * D + d];
     const float xh = p.xhat[(long)b * D + d];
     // 256 clips adding to the same D addresses serialise at the memory side (~30 ns per add: 8 us of this kernel); with a
@@ -326,15 +330,10 @@ __global__ __launch_bounds__(TNT) void tail_bwd_kernel(TailBwdParams p) {
   __syncthreads();
   for (int d = tid; d < D; d += TNT) {
     const float dpd = dp[d], wd = p.w_score[d];
-    float gw = 0.f;
-    for (int t = 0; t < T; ++t) {
-      float v = 0.f;
-      if (t < len) {
-        v = wt[t] * dpd + ds[t] * wd;
-        gw += ds[t] * hb[(long)t * D + d];
-      }
-      p.d_h[((long)b * T + t) * D + d] = v;
-    }
+    float gw = 0.f;  // (the loads of h apart from the stores of d h: one load per round trip when they shared a loop)
+#pragma unroll 8
+    for (int t = 0; t < len; ++t) gw += ds[t] * hb[(long)t * D + d];
+    for (int t = 0; t < T; ++t) p.d_h[((long)b * T + t) * D + d] = (t < len) ? wt[t] * dpd + ds[t] * wd : 0.f;
     if (p.col_part) p.col_part[((long)b * 3 + 2) * D + d] = gw;
     else atomicAdd(&p.g_wscore[d], gw);
   }
