@@ -344,7 +344,7 @@ extern "C" int ss_gru_fwd_drop(const float* gi, const float* w_hh_f, const float
   const int P = sync_ws ? gru_split_parts(B, T, H) : 0;
   SS_REQUIRE(P || !out_drop, SS_ERR_UNSUPPORTED);
   if (P) {
-    dim3 sgrid(2 * ceil_div(B, SLICE) * P);
+    dim3 sgrid(gru_split_grid_pairs(B, P) * P);
     unsigned* sy = static_cast<unsigned*>(sync_ws);
     u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
     u64* hx = xid + gru_xid_granules(B, P);
@@ -381,7 +381,7 @@ extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* sav
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int P = sync_ws ? gru_split_parts(B, T, H) : 0;
   if (P) {
-    dim3 sgrid(2 * ceil_div(B, SLICE) * P);
+    dim3 sgrid(gru_split_grid_pairs(B, P) * P);
     unsigned* sy = static_cast<unsigned*>(sync_ws);
     u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
     u64* xg = xid + gru_xid_granules(B, P) + gru_fwd_granules(B, H);

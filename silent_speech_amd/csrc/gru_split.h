@@ -67,9 +67,12 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   __shared__ __attribute__((aligned(16))) float hpan[SLICE * LDH];  // previous state of the slice, [clip][unit]
   __shared__ unsigned s_gen;
   // part-major when the pair count is a multiple of 8: workgroups b and b + 8k share an XCD, so do the partners then
-  const int pairs = gridDim.x / P;
-  const bool part_major = (pairs & 7) == 0;
-  const int part = part_major ? blockIdx.x / pairs : blockIdx.x % P, pair = part_major ? blockIdx.x % pairs : blockIdx.x / P;
+  // (the launch pads the pair count to a multiple of 8 where the padded grid still fits -- gru_split_grid_pairs: workgroups of the
+  // pad pairs leave at once -- so small batches, the reference's own 16 clips among them, get the same-XCD exchange too)
+  const int pairs = 2 * ((p.B + SLICE - 1) / SLICE), grid_pairs = gridDim.x / P;
+  const bool part_major = (grid_pairs & 7) == 0;
+  const int part = part_major ? blockIdx.x / grid_pairs : blockIdx.x % P;
+  const int pair = part_major ? blockIdx.x % grid_pairs : blockIdx.x / P;
   const int dir = pair & 1, b0 = (pair >> 1) * SLICE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ut = w % C::UT, kh = w / C::UT;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void gru_split_fwd_kernel(GruFwdParams p, unsi
   const int len = clip_ok ? p.lengths[clip] : 0;
   const int T = p.T;
   if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
-  if (plays_dead(sync)) {  // wave-uniform; tests only
+  if (plays_dead(sync) || pair >= pairs) {  // wave-uniform; tests only, resp. a workgroup of the grid's pad
     __syncthreads();
     finish_launch(sync, s_gen);
     return;
@@ -254,9 +257,12 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   __shared__ __attribute__((aligned(16))) float dsum[SLICE * C::UP];   // summed dh_prev of this part's units
   __shared__ unsigned s_gen;
   // part-major when the pair count is a multiple of 8: workgroups b and b + 8k share an XCD, so do the partners then
-  const int pairs = gridDim.x / P;
-  const bool part_major = (pairs & 7) == 0;
-  const int part = part_major ? blockIdx.x / pairs : blockIdx.x % P, pair = part_major ? blockIdx.x % pairs : blockIdx.x / P;
+  // (the launch pads the pair count to a multiple of 8 where the padded grid still fits -- gru_split_grid_pairs: workgroups of the
+  // pad pairs leave at once -- so small batches, the reference's own 16 clips among them, get the same-XCD exchange too)
+  const int pairs = 2 * ((p.B + SLICE - 1) / SLICE), grid_pairs = gridDim.x / P;
+  const bool part_major = (grid_pairs & 7) == 0;
+  const int part = part_major ? blockIdx.x / grid_pairs : blockIdx.x % P;
+  const int pair = part_major ? blockIdx.x % grid_pairs : blockIdx.x / P;
   const int dir = pair & 1, b0 = (pair >> 1) * SLICE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ut = w % C::UT;
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   const int len = clip_ok ? p.lengths[clip] : 0;
   const int T = p.T;
   if (threadIdx.x == 0) s_gen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, SS_AGENT);
-  if (plays_dead(sync)) {  // wave-uniform; tests only
+  if (plays_dead(sync) || pair >= pairs) {  // wave-uniform; tests only, resp. a workgroup of the grid's pad
     __syncthreads();
     finish_launch(sync, s_gen);
     return;
@@ -428,6 +434,14 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
 inline long gru_xid_granules(int B, int P) { return ((2L * ceil_div(B, SLICE) * P) + 7) / 8 * 8; }
 inline long gru_fwd_granules(int B, int H) { return 2L * (2 * ceil_div(B, SLICE)) * SLICE * H; }
 inline long gru_bwd_granules(int B, int H, int P) { return 2L * (2 * ceil_div(B, SLICE)) * P * SLICE * H; }
+
+// pairs the grid is launched with: the next multiple of 8 when that still fits the co-residency bound.  Workgroup b runs on XCD
+// b % 8 (round-robin dispatch), so with a multiple of 8 pairs and part-major numbering the P partners of a pair share an XCD and
+// exchange their granules through its L2; a grid of 2 pairs x 6 parts (B = 16) had every partner on another XCD.
+inline int gru_split_grid_pairs(int B, int P) {
+  const int pairs = 2 * ceil_div(B, SLICE), pad = (pairs + 7) / 8 * 8;
+  return pad * P <= SPLIT_MAX_WGS ? pad : pairs;
+}
 
 // parts per (slice, direction) for a shape, or 0 when the single-workgroup form is the right one
 inline int gru_split_parts(int B, int T, int H) {

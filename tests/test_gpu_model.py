@@ -75,12 +75,14 @@ def test_gru_lost_partner_reaches_the_host(ss):
         pytest.skip("this shape does not take the multi-CU recurrence")
     m.check_health()
     assert int(ws.gru_sync[2]) == 0
-    ws.gru_sync[5] = 1 + 7  # workgroup 7 of the layer-0 forward launch (and of every later launch) plays dead
+    # workgroup 9 of the layer-0 forward launch (and of every later launch) plays dead: 4 pairs are launched as 8 (the pad that
+    # puts the partners of a pair on one XCD), part-major: workgroup b is pair b % 8, part b // 8
+    ws.gru_sync[5] = 1 + 9
     with torch.no_grad():
         bad = m(Xd, Lh).cpu()
     torch.cuda.synchronize()
     assert int(ws.gru_sync[2]) > 0, "no bounded wait gave up"
-    # workgroup 7 = (slice 0, reverse direction), part 1: its five partners run out of patience and emit NaN for everything they
+    # workgroup 9 = (slice 0, reverse direction), part 1: its five partners run out of patience and emit NaN for everything they
     # own from then on, so the 16 clips of slice 0 are poisoned and the other slice is untouched
     assert torch.isnan(bad[:16]).all(), "the poisoned result did not reach the logits"
     assert torch.equal(bad[16:], good[16:])
