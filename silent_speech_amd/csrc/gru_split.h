@@ -51,7 +51,7 @@ struct SplitCfg {
   static constexpr int UP = H / P;          // hidden units per part
   static constexpr int UT = UP / 16;        // 16-unit MFMA tiles per part
   static constexpr int KSPLIT = 4 / UT;     // forward: waves sharing one tile split the contraction
-  static_assert(UP == 32 && UT * KSPLIT == 4, "a part is two unit tiles");
+  static_assert((UP == 32 || UP == 16) && UT * KSPLIT == 4, "a part is one or two unit tiles (one: forward kernel only)");
   static constexpr int QF = H / 16 / KSPLIT;       // 16-wide k groups per wave, forward (K = H)
   static_assert(QF * 16 * KSPLIT == H, "k split");
   static constexpr int RED = (KSPLIT - 1) * UT * 3 * 64 * 4;
@@ -431,7 +431,8 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
 }
 
 // sync_ws sections, in granules
-inline long gru_xid_granules(int B, int P) { return ((2L * ceil_div(B, SLICE) * P) + 7) / 8 * 8; }
+constexpr int SPLIT_MAX_PARTS = 12;  // the XCD-id rows of the workspace are laid out for the widest split (forward, small batches)
+inline long gru_xid_granules(int B) { return ((2L * ceil_div(B, SLICE) * SPLIT_MAX_PARTS) + 7) / 8 * 8; }
 inline long gru_fwd_granules(int B, int H) { return 2L * (2 * ceil_div(B, SLICE)) * SLICE * H; }
 inline long gru_bwd_granules(int B, int H, int P) { return 2L * (2 * ceil_div(B, SLICE)) * P * SLICE * H; }
 
@@ -441,6 +442,19 @@ inline long gru_bwd_granules(int B, int H, int P) { return 2L * (2 * ceil_div(B,
 inline int gru_split_grid_pairs(int B, int P) {
   const int pairs = 2 * ceil_div(B, SLICE), pad = (pairs + 7) / 8 * 8;
   return pad * P <= SPLIT_MAX_WGS ? pad : pairs;
+}
+
+// The FORWARD recurrence of H = 192 over twelve parts of 16 units where the padded grid has room (up to 16 pairs = 128 clips, the
+// reference's shipped batch of 16 among them): the MFMA stage of a step is at its floor for four waves (288 MFMAs per workgroup:
+// 0.96 us of a 2.6 us step); half the units per workgroup halve it and the gate / publish stage: 2.6 -> 2.0 us per step.  The
+// sweep is unchanged (every workgroup reads the whole 16 x H panel whatever the split).  The backward kernel keeps six parts (its
+// tiles assume 32 units).  The contraction is then cut into four k slices instead of two, so a clip's state differs in the last
+// bits between a batch of <= 128 and a larger one.  (Summing four fixed segments in both splits makes the bits equal -- measured:
+// tests green -- but costs the six-part kernel, i.e. BASELINE config 2, 6 us per step for three more accumulators; not kept.)
+inline int gru_split_fwd_parts(int B, int P) {
+  if (P != 6) return P;
+  const int pad = (2 * ceil_div(B, SLICE) + 7) / 8 * 8;
+  return pad * 12 <= SPLIT_MAX_WGS ? 12 : P;
 }
 
 // parts per (slice, direction) for a shape, or 0 when the single-workgroup form is the right one
