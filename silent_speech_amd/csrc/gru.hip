@@ -320,7 +320,7 @@ STAMP_TABLE(ss_debug_stamps_gru)
 
 extern "C" int ss_gru_sync_bytes(int B, int T, int H, long* bytes) {
   SS_REQUIRE(bytes && B > 0 && T > 0 && H > 0, SS_ERR_ARG);
-  const int P = gru_split_parts(B, T, H);
+  const int P = gru_split_small_parts(B, gru_split_parts(B, T, H));
   *bytes = P ? SYNC_HDR_WORDS * 4L + (gru_xid_granules(B) + gru_fwd_granules(B, H) + gru_bwd_granules(B, H, P)) * 8 : 0;
   return SS_OK;
 }
@@ -344,7 +344,7 @@ extern "C" int ss_gru_fwd_drop(const float* gi, const float* w_hh_f, const float
   const int P = sync_ws ? gru_split_parts(B, T, H) : 0;
   SS_REQUIRE(P || !out_drop, SS_ERR_UNSUPPORTED);
   if (P) {
-    const int PF = gru_split_fwd_parts(B, P);
+    const int PF = gru_split_small_parts(B, P);
     dim3 sgrid(gru_split_grid_pairs(B, PF) * PF);
     unsigned* sy = static_cast<unsigned*>(sync_ws);
     u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
@@ -383,11 +383,13 @@ extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* sav
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int P = sync_ws ? gru_split_parts(B, T, H) : 0;
   if (P) {
-    dim3 sgrid(gru_split_grid_pairs(B, P) * P);
+    const int PB = gru_split_small_parts(B, P);
+    dim3 sgrid(gru_split_grid_pairs(B, PB) * PB);
     unsigned* sy = static_cast<unsigned*>(sync_ws);
     u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
     u64* xg = xid + gru_xid_granules(B) + gru_fwd_granules(B, H);
-    if (H == 192) hipLaunchKernelGGL((gru_split_bwd_kernel<192, 6>), sgrid, dim3(256), 0, s, p, sy, xid, xg);
+    if (H == 192 && PB == 12) hipLaunchKernelGGL((gru_split_bwd_kernel<192, 12>), sgrid, dim3(256), 0, s, p, sy, xid, xg);
+    else if (H == 192) hipLaunchKernelGGL((gru_split_bwd_kernel<192, 6>), sgrid, dim3(256), 0, s, p, sy, xid, xg);
     else hipLaunchKernelGGL((gru_split_bwd_kernel<64, 2>), sgrid, dim3(256), 0, s, p, sy, xid, xg);
     return ss_launch_status();
   }

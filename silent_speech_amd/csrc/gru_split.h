@@ -51,7 +51,7 @@ struct SplitCfg {
   static constexpr int UP = H / P;          // hidden units per part
   static constexpr int UT = UP / 16;        // 16-unit MFMA tiles per part
   static constexpr int KSPLIT = 4 / UT;     // forward: waves sharing one tile split the contraction
-  static_assert((UP == 32 || UP == 16) && UT * KSPLIT == 4, "a part is one or two unit tiles (one: forward kernel only)");
+  static_assert((UP == 32 || UP == 16) && UT * KSPLIT == 4, "a part is one or two unit tiles");
   static constexpr int QF = H / 16 / KSPLIT;       // 16-wide k groups per wave, forward (K = H)
   static_assert(QF * 16 * KSPLIT == H, "k split");
   static constexpr int RED = (KSPLIT - 1) * UT * 3 * 64 * 4;
@@ -251,10 +251,12 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
   constexpr int QK = KR / 16;          // 16-wide k groups
   constexpr int NT = H / 16 / 4;       // output unit tiles per wave
   constexpr int LDP = KR + 4;
-  constexpr int NGP = P;               // granule pairs per thread: 16 * UP / 2 = 256 position pairs x P sources
-  static_assert(QK * 16 == KR && NT * 64 == H && SLICE * C::UP == 512, "tile split");
+  // granule pairs per thread: P sources x 16 * UP / 2 position pairs over 256 threads.  UP = 32: thread = position pair, one per
+  // source; UP = 16 (twelve parts): threads 0..127 take the even sources, 128..255 the odd ones of position pair tid % 128
+  constexpr int NGP = P * C::UP / 32;
+  static_assert(QK * 16 == KR && NT * 64 == H && (SLICE * C::UP == 512 || SLICE * C::UP == 256), "tile split");
   __shared__ __attribute__((aligned(16))) float dpan[SLICE * LDP];     // this part's d_pre, [clip][local row]
-  __shared__ __attribute__((aligned(16))) float dsum[SLICE * C::UP];   // summed dh_prev of this part's units
+  __shared__ __attribute__((aligned(16))) float dsum[SLICE * 32];      // summed dh_prev of this part's units (UP = 16: two halves)
   __shared__ unsigned s_gen;
   // part-major when the pair count is a multiple of 8: workgroups b and b + 8k share an XCD, so do the partners then
   // (the launch pads the pair count to a multiple of 8 where the padded grid still fits -- gru_split_grid_pairs: workgroups of the
@@ -416,13 +418,16 @@ __global__ __launch_bounds__(256) void gru_split_bwd_kernel(GruBwdParams p, unsi
     STAMP(0);
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int q = 0; q < P; ++q) {
+    for (int q = 0; q < NGP; ++q) {
       s0 += xv[2 * q];
       s1 += xv[2 * q + 1];
     }
     *reinterpret_cast<float2*>(&dsum[2 * threadIdx.x]) = float2{s0, s1};
     __syncthreads();
-    if (owner) dh = dcarry + *reinterpret_cast<const f32x4*>(&dsum[i * C::UP + 16 * ut + 4 * g]);
+    if (owner) {
+      dh = dcarry + *reinterpret_cast<const f32x4*>(&dsum[i * C::UP + 16 * ut + 4 * g]);
+      if (C::UP == 16) dh += *reinterpret_cast<const f32x4*>(&dsum[SLICE * 16 + i * 16 + 4 * g]);  // the odd sources' half
+    }
     STAMP(1);
   }
   if (owner) bacc.flush(p, dir, H, j0, i);  // owner is wave-uniform
@@ -444,14 +449,15 @@ inline int gru_split_grid_pairs(int B, int P) {
   return pad * P <= SPLIT_MAX_WGS ? pad : pairs;
 }
 
-// The FORWARD recurrence of H = 192 over twelve parts of 16 units where the padded grid has room (up to 16 pairs = 128 clips, the
+// The recurrences of H = 192 over twelve parts of 16 units where the padded grid has room (up to 16 pairs = 128 clips, the
 // reference's shipped batch of 16 among them): the MFMA stage of a step is at its floor for four waves (288 MFMAs per workgroup:
 // 0.96 us of a 2.6 us step); half the units per workgroup halve it and the gate / publish stage: 2.6 -> 2.0 us per step.  The
-// sweep is unchanged (every workgroup reads the whole 16 x H panel whatever the split).  The backward kernel keeps six parts (its
-// tiles assume 32 units).  The contraction is then cut into four k slices instead of two, so a clip's state differs in the last
+// sweep is unchanged (every workgroup reads the whole 16 x H panel whatever the split).  The backward kernel likewise: its
+// contraction over the part's 3 x 16 gate rows is 144 MFMAs per workgroup instead of 288, a workgroup still publishes one 16 x H
+// panel of partial sums and sweeps P x 16 x 16 of them.  The forward contraction is then cut into four k slices instead of two, so a clip's state differs in the last
 // bits between a batch of <= 128 and a larger one.  (Summing four fixed segments in both splits makes the bits equal -- measured:
 // tests green -- but costs the six-part kernel, i.e. BASELINE config 2, 6 us per step for three more accumulators; not kept.)
-inline int gru_split_fwd_parts(int B, int P) {
+inline int gru_split_small_parts(int B, int P) {
   if (P != 6) return P;
   const int pad = (2 * ceil_div(B, SLICE) + 7) / 8 * 8;
   return pad * 12 <= SPLIT_MAX_WGS ? 12 : P;
