@@ -316,6 +316,7 @@ __global__ __launch_bounds__(H * 4) void gru_bwd_kernel(GruBwdParams p) {
 
 STAMP_TABLE(ss_debug_stamps_gru)
 
+extern int ss_cnn_max_wgs;  // roi_cnn.hip: the CU cap of the persistent CNN kernels (0 = none)
 #include "gru_split.h"
 
 extern "C" int ss_gru_sync_bytes(int B, int T, int H, long* bytes) {
@@ -344,7 +345,9 @@ extern "C" int ss_gru_fwd_drop(const float* gi, const float* w_hh_f, const float
   const int P = sync_ws ? gru_split_parts(B, T, H) : 0;
   SS_REQUIRE(P || !out_drop, SS_ERR_UNSUPPORTED);
   if (P) {
-    const int PF = gru_split_small_parts(B, P);
+    // (while a CU cap is set on the persistent CNN kernels -- Trainer(micro_batches > 1) -- the slices keep six parts: the CUs the cap
+    // reserves hold 96 recurrence workgroups, what two 8-slice micro-batches of six parts need)
+    const int PF = ss_cnn_max_wgs ? P : gru_split_small_parts(B, P);
     dim3 sgrid(gru_split_grid_pairs(B, PF) * PF);
     unsigned* sy = static_cast<unsigned*>(sync_ws);
     u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
@@ -383,7 +386,7 @@ extern "C" int ss_gru_bwd(const float* d_out, const float* out, const float* sav
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int P = sync_ws ? gru_split_parts(B, T, H) : 0;
   if (P) {
-    const int PB = gru_split_small_parts(B, P);
+    const int PB = ss_cnn_max_wgs ? P : gru_split_small_parts(B, P);
     dim3 sgrid(gru_split_grid_pairs(B, PB) * PB);
     unsigned* sy = static_cast<unsigned*>(sync_ws);
     u64* xid = reinterpret_cast<u64*>(sy + SYNC_HDR_WORDS);
