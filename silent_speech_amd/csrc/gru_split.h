@@ -55,6 +55,10 @@ struct SplitCfg {
   static constexpr int QF = H / 16 / KSPLIT;       // 16-wide k groups per wave, forward (K = H)
   static_assert(QF * 16 * KSPLIT == H, "k split");
   static constexpr int RED = (KSPLIT - 1) * UT * 3 * 64 * 4;
+  // (Measured, not kept: every wave of a tile finishing 4 / KSPLIT of a lane's four units -- gates, publish, stash -- instead of the
+  // owner wave all four, the k slices handed over as [wave][gate][unit][lane] and summed in the same order (bit-identical, tests
+  // green): forward launch 0.363 -> 0.393 ms at the shipped batch of 16, 0.173 -> 0.185 at config 2.  Twelve 4-byte LDS stores and
+  // loads and 4-byte global traffic per lane cost more than three quarters of the transcendental chain save.)
   static constexpr int NGP = SLICE * H / 512;      // granule pairs per thread in a sweep of a 16 x H panel
 };
 
