@@ -480,12 +480,17 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     unsigned s2o[S2_IT][2];  // four argmax bytes each
     {
       constexpr int tiles = P / 16;
-#pragma unroll
-      for (int it = 0; it < S2_IT; ++it) {
+      // A last pass that holds at most one tile per wave (48 x 96: 18 tiles, passes of 16) runs WITHOUT the second tile's reads and
+      // MFMAs: as a two-tile pass over a duplicate it made S2 four tile times long where three do (stage timers: 15.8 k cycles
+      // against 8.0 k at 64 x 64, whose 16 tiles are exactly one pass).
+      constexpr int tail_tiles = tiles % (2 * NWV);
+      constexpr bool TAIL_SINGLE = tail_tiles != 0 && tail_tiles <= NWV;
+      auto s2_pass = [&](const int it, auto two_c) {
+        constexpr bool TWO = decltype(two_c)::value;
         const int tile = wvu + 2 * NWV * it;  // wvu: scalar loop control and tile arithmetic
-        if (tile >= tiles) break;
+        if (tile >= tiles) return;
         const int tile2 = tile + NWV;
-        const bool two = tile2 < tiles;
+        const bool two = TWO && tile2 < tiles;
         const int pp0 = 16 * tile + i, pp1 = 16 * (two ? tile2 : tile) + i;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0;
         // per tap and pixel tile: channels 4g..4g+3 in one ds_read_b128 (k-steps 0..3), channels 16+2g, 17+2g in one
@@ -503,31 +508,31 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         auto back_of = [](int tap) { return ((tap / 3) * S2 + (tap % 3)) * DS; };
         b16 = *reinterpret_cast<const f32x4*>(bt16);
         a016 = *reinterpret_cast<const f32x4*>(ap0 + 4 * g);
-        a116 = *reinterpret_cast<const f32x4*>(ap1 + 4 * g);
+        if constexpr (TWO) a116 = *reinterpret_cast<const f32x4*>(ap1 + 4 * g);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int back = back_of(tap);
           b8 = *reinterpret_cast<const float2*>(bt8 + tap * 128);
           a08 = *reinterpret_cast<const float2*>(ap0 - back + 16 + 2 * g);
-          a18 = *reinterpret_cast<const float2*>(ap1 - back + 16 + 2 * g);
+          if constexpr (TWO) a18 = *reinterpret_cast<const float2*>(ap1 - back + 16 + 2 * g);
           SS_SCHED_FENCE();
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             acc0 = mfma16(a016[e], b16[e], acc0);
-            acc1x = mfma16(a116[e], b16[e], acc1x);
+            if constexpr (TWO) acc1x = mfma16(a116[e], b16[e], acc1x);
           }
           SS_SCHED_FENCE();
           if (tap + 1 < 9) {
             const int nb = back_of(tap + 1);
             b16 = *reinterpret_cast<const f32x4*>(bt16 + (tap + 1) * 256);
             a016 = *reinterpret_cast<const f32x4*>(ap0 - nb + 4 * g);
-            a116 = *reinterpret_cast<const f32x4*>(ap1 - nb + 4 * g);
+            if constexpr (TWO) a116 = *reinterpret_cast<const f32x4*>(ap1 - nb + 4 * g);
           }
           SS_SCHED_FENCE();
           acc0 = mfma16(a08.x, b8.x, acc0);
-          acc1x = mfma16(a18.x, b8.x, acc1x);
+          if constexpr (TWO) acc1x = mfma16(a18.x, b8.x, acc1x);
           acc0 = mfma16(a08.y, b8.y, acc0);
-          acc1x = mfma16(a18.y, b8.y, acc1x);
+          if constexpr (TWO) acc1x = mfma16(a18.y, b8.y, acc1x);
           SS_SCHED_FENCE();
         }
         // the masked gradient and the pool-2 argmax of its four pixels stay in registers: this wave scatters them into the
@@ -555,6 +560,11 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
           }
         }
         s2o[it][1] = o1;
+      };
+#pragma unroll
+      for (int it = 0; it < S2_IT; ++it) {
+        if (TAIL_SINGLE && it == S2_IT - 1) s2_pass(it, std::false_type{});
+        else s2_pass(it, std::true_type{});
       }
     }
     if (FAST && wvu == NWV - 1) ss_dma_wait();  // the next frame's d_out row has landed: published by barrier D
