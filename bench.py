@@ -20,6 +20,7 @@ One JSON line on rank 0.  ``value`` = clips of all ranks / max-over-ranks wall t
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -198,21 +199,45 @@ def config4_block(ss, dev, D, C, roi, steps, warmup):
 
 
 
-def latest_profile(suffix, exclude=None):
-    """Newest committed rocprofv3 summary under profiles/ whose name ends in ``suffix`` (rounds sort by name)."""
+PROFILE_NAME = re.compile(r"^round(\d+)_([a-z0-9]+)_(?:(c5|ship)_)?pmc_(traffic|mfma|issue)\.json$")
+
+
+def latest_profile(kind, block="config2", names=None):
+    """Newest committed PMC summary of ``kind`` ("traffic" | "mfma" | "issue") that was TAKEN ON ``block``'s workload:
+    ``round<N>_<tag>_pmc_<kind>.json`` = the headline (config 2, 64x64 ROI), ``..._c5_pmc_...`` = config 5, ``..._ship_pmc_...`` =
+    the reference's shipped shape (48x96 ROI, T = 90).  The name must match exactly -- a profile of another workload is never a
+    stand-in (round 3's driver line carried the 48x96 kernel's counters for config 2 because ``_ship_`` sorted last).
+    ``names`` (a directory listing) is for the CPU test."""
     pdir = os.path.join(ROOT, "profiles")
-    names = sorted(n for n in (os.listdir(pdir) if os.path.isdir(pdir) else []) if n.endswith(suffix) and not (exclude and exclude in n))
-    return os.path.join(pdir, names[-1]) if names else None
+    if names is None:
+        names = os.listdir(pdir) if os.path.isdir(pdir) else []
+    want = {"config2": None, "config5": "c5", "shipped": "ship"}[block]
+    best = None
+    for n in names:
+        m = PROFILE_NAME.match(n)
+        if m and m.group(3) == want and m.group(4) == kind:
+            key = (int(m.group(1)), m.group(2))
+            if best is None or key > best[0]:
+                best = (key, n)
+    return os.path.join(pdir, best[1]) if best else None
 
 
 def pmc_lookup(path, stems):
-    """Entry of a tools/pmc_summary.py JSON whose kernel name contains every string of ``stems``."""
+    """Entry of a tools/pmc_summary.py JSON whose kernel name contains every string of ``stems`` -- exactly one kernel may
+    match (two instantiations of one template in a file is a lookup that needs a sharper stem, not an average)."""
     if not path or not os.path.exists(path):
         return None
-    for name, d in json.load(open(path))["kernels"].items():
-        if all(st in name for st in stems):
-            return d
-    return None
+    hits = [d for name, d in json.load(open(path))["kernels"].items() if all(st in name for st in stems)]
+    return hits[0] if len(hits) == 1 else None
+
+
+def kernel_stems(tag, roi_hw=None):
+    """Substrings a profile's kernel name must contain for launch tag ``tag``; the ROI kernels are templated on the frame
+    geometry, so the geometry is part of the stem: a profile of another frame size yields None, not another kernel's numbers."""
+    st = list(KERNEL_STEMS.get(tag, [tag]))
+    if tag in ("ss_roi_cnn_bwd", "ss_roi_cnn_fwd_stash") and roi_hw is not None:
+        st.append("Geom<%d, %d>" % tuple(roi_hw))
+    return st
 
 
 # launch tag -> substrings of the kernel's name in the rocprofv3 summaries
@@ -268,7 +293,7 @@ def spec_for(config, B, T, K, roi, C):
                           "train step = fwd + CE(ls .05) + bwd + grad all-reduce + clip(1.0) + Adam, dropout on"))
 
 
-def train_block(ss, L, dev, world, rank, spec, X, lengths, R, y, steps, warmup, kernel_times, micro_batches, dist_on):
+def train_block(ss, L, dev, world, rank, spec, X, lengths, R, y, steps, warmup, kernel_times, micro_batches, dist_on, extra_windows=0):
     """W warm-up steps, then exactly K timed steps of the fused training step between barriers (max over ranks); then K more
     steps on one stream with a HIP-event pair around every launch for the per-kernel table and the dominant kernel's roofline."""
     import torch.distributed as dist
@@ -301,6 +326,20 @@ def train_block(ss, L, dev, world, rank, spec, X, lengths, R, y, steps, warmup, 
     final_loss = float(loss)
     assert final_loss == final_loss, "loss is NaN"
     model.check_health()
+    # run-to-run spread: four more windows of K steps, timed the same way (``value`` stays the contract's first window)
+    windows = [elapsed]
+    for _ in range(extra_windows):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.step(X, lengths, R, y, global_batch=gb)
+        barrier()
+        w = time.perf_counter() - t0
+        if dist_on:
+            tw = torch.tensor([w], device=dev, dtype=torch.float64)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            w = float(tw)
+        windows.append(w)
 
     kernels, roof, kernel_tf, allreduce_ms = {}, None, None, None
     if kernel_times:
@@ -329,29 +368,42 @@ def train_block(ss, L, dev, world, rank, spec, X, lengths, R, y, steps, warmup, 
             gf = gfs.get(dom)
             if gf is not None:
                 achieved = gf / kernels[dom]["ms_per_step"]  # GFLOP per step / ms per step = TFLOP/s
-                tr_ = pmc_lookup(latest_profile("_c5_pmc_traffic.json"), KERNEL_STEMS.get(dom, [dom])) if full_size else None
+                tr_file = latest_profile("traffic", "config5") if full_size else None
+                tr_ = pmc_lookup(tr_file, kernel_stems(dom))
                 roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                         "traffic": int(tr_["hbm_bytes_per_launch"] * kernels[dom]["launches_per_step"]) if tr_ else None,
                         "algorithmic_gflop_per_step": round(gf, 2), "launches_per_step": kernels[dom]["launches_per_step"],
                         "ms_per_step": round(kernels[dom]["ms_per_step"], 4)}
-                mb_ = pmc_lookup(latest_profile("_c5_pmc_mfma.json"), KERNEL_STEMS.get(dom, [dom])) if full_size else None
+                mb_file = latest_profile("mfma", "config5") if full_size else None
+                mb_ = pmc_lookup(mb_file, kernel_stems(dom))
                 if mb_:
                     roof["mfma_busy_frac"] = mb_.get("mfma_busy_frac")
+                roof["profile_files"] = [os.path.basename(f) for f, d in ((tr_file, tr_), (mb_file, mb_)) if d]
             kernel_tf = {k: round(gfs[k] / v["ms_per_step"], 1) for k, v in kernels.items() if k in gfs}
         else:
             gf = algorithmic_gflop(dom, B, T, D, E, H, C, spec["roi_hw"])
             if gf is not None:
                 achieved = gf / kernels[dom]["avg_ms"]  # GFLOP / ms = TFLOP/s
-                at_bench = full_size and spec["roi_hw"] == (64, 64)
-                tr_ = pmc_lookup(latest_profile("_pmc_traffic.json", exclude="_c5_"), KERNEL_STEMS.get(dom, [dom])) if at_bench else None
+                # counters exist for the headline (B = 256, T = 30, 64x64) and for the shipped shape at batch 256 (T = 90, 48x96)
+                block = "config2" if spec["config"] == 2 else "shipped"
+                profiled = (B, T) == ((256, 30) if block == "config2" else (256, SHIPPED["T"]))
+                stems = kernel_stems(dom, spec["roi_hw"])
+                tr_file = latest_profile("traffic", block) if profiled else None
+                if block == "shipped" and tr_file and "batch 256 only" not in json.load(open(tr_file)).get("source", ""):
+                    tr_file = None  # round 3's ship summaries average the batch-16 and batch-256 launches of one kernel name
+                tr_ = pmc_lookup(tr_file, stems)
                 roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": int(tr_["hbm_bytes_per_launch"]) if tr_ else None,
                         "algorithmic_gflop_per_launch": round(gf, 3), "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
-                mb_ = pmc_lookup(latest_profile("_pmc_mfma.json", exclude="_c5_"), KERNEL_STEMS.get(dom, [dom])) if at_bench else None
+                mb_file = latest_profile("mfma", block) if profiled else None
+                if block == "shipped" and mb_file and "batch 256 only" not in json.load(open(mb_file)).get("source", ""):
+                    mb_file = None
+                mb_ = pmc_lookup(mb_file, stems)
                 if mb_:
                     roof["mfma_busy"] = mb_
+                roof["profile_files"] = [os.path.basename(f) for f, d in ((tr_file, tr_), (mb_file, mb_)) if d]
 
     out = {
         "metric": "clips/sec (%d-frame, fwd+bwd)" % T, "value": round(B * world * steps / elapsed, 1), "unit": "clips/s",
@@ -361,6 +413,11 @@ def train_block(ss, L, dev, world, rank, spec, X, lengths, R, y, steps, warmup, 
                    "micro_batches_in_flight": micro_batches},
         "final_loss": round(final_loss, 5),
     }
+    if len(windows) > 1:
+        ms = sorted(1000 * w / steps for w in windows)
+        out["extra"] = {"windows": len(ms), "steps_per_window": steps, "ms_per_step_windows": [round(1000 * w / steps, 4) for w in windows],
+                        "ms_per_step_median": round(ms[len(ms) // 2], 4), "ms_per_step_min": round(ms[0], 4),
+                        "clips_per_s_median": round(B * world / ms[len(ms) // 2] * 1e3, 1), "clips_per_s_best": round(B * world / ms[0] * 1e3, 1)}
     if roof:
         out["roofline"] = roof
     # whole-step figure of SURVEY.md 8(d): clips/s x algorithmic GFLOP per clip against the dense MFMA peak (of the dtype) of the GPUs used
@@ -386,7 +443,8 @@ def shipped_blocks(ss, L, dev, world, rank, args, dist_on):
     """The configuration the reference actually runs: BATCH_SIZE 16 (as shipped) and 256 clips of MAX_T = 90 frames, 88 landmarks
     (D = 180), ROI 96 wide x 48 high, 10 words."""
     out = {}
-    for name, B in (("b16", 16), ("b256", 256)):
+    for B in [int(v) for v in args.shipped_batches.split(",")]:
+        name = "b%d" % B
         sp = spec_for("shipped", B, SHIPPED["T"], SHIPPED["K"], SHIPPED["roi_hw"], SHIPPED["C"])
         X, l, R, y = synth_inputs(L, dev, rank, B, sp["T"], sp["K"], sp["roi_hw"], sp["C"])
         out[name] = train_block(ss, L, dev, world, rank, sp, X, l, R, y, args.steps, max(2, args.warmup // 2),
@@ -455,6 +513,9 @@ def main():
     ap.add_argument("--shipped", dest="shipped_only", action="store_true",
                     help="only the reference's shipped configuration (48x96 ROI, 88 landmarks -> D=180, 10 words, T=90; batch 16 as "
                          "shipped and batch 256), one JSON line with its CPU row")
+    ap.add_argument("--extra-windows", type=int, default=4,
+                    help="further timed windows of --steps steps behind the contract's one: median / min under 'extra'")
+    ap.add_argument("--shipped-batches", default="16,256", help="batches of the shipped-configuration block (a profile takes 256 only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="join an 'nccl' (= RCCL) process group and run the data-parallel leg -- broadcast of the parameters, the flat "
                          "gradient all-reduce every step, barriers, max-over-ranks timing -- even with one rank")
@@ -487,8 +548,11 @@ def main():
         if dist_on:
             dist.destroy_process_group()
         if rank == 0:
-            head = dict(out["b16"])  # the contract's keys describe the batch the reference ships; b256 rides along
-            head["b256"] = out["b256"]
+            first = "b16" if "b16" in out else sorted(out)[0]
+            head = dict(out[first])  # the contract's keys describe the batch the reference ships; the others ride along
+            for k in out:
+                if k.startswith("b") and k != first:
+                    head[k] = out[k]
             if "cpu_baseline" in out:
                 head["cpu_baseline"] = out["cpu_baseline"]
             print(json.dumps(head), flush=True)
@@ -630,7 +694,7 @@ def main():
         return
     spec = spec_for(args.config, B, T, K, roi, C)
     out = train_block(ss, L, dev, world, rank, spec, X, lengths, R, y, args.steps, args.warmup, not args.no_kernel_times,
-                      args.micro_batches, dist_on)
+                      args.micro_batches, dist_on, extra_windows=args.extra_windows)
     solo = rank == 0 and world == 1
     # ---- the other BASELINE configs ride along in the default run, so that the driver's one command measures them too
     if args.config == 2 and not args.no_config5:

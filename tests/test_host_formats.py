@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import silent_speech_amd as ss
+from oracle import dataset_ref as DR
 from silent_speech_amd import data as D
 
 
@@ -27,22 +28,22 @@ def test_npz_schema_and_pad_trim(tmp_path):
     d = np.load(p1, allow_pickle=True)
     assert set(d.files) == {"X", "ts", "label", "speaker", "idxs", "roi"} and str(d["label"]) == "yes"
     assert d["roi"].shape == (20, 48, 96) and d["roi"].dtype == np.uint8  # trimmed to len(X), record…:245-248
-    ds = D.NPZWordDataset([p1, p2, p3], {"yes": 0, "no": 1}, max_t=90, augment=False)
+    ds = DR.ClipDatasetRef([p1, p2, p3], {"yes": 0, "no": 1}, max_t=90, augment=False)
     X, T, R, y = ds[0]
     assert X.shape == (90, 180) and int(T) == 20 and R.shape == (90, 48, 96) and int(y) == 0
     assert torch.equal(X[:20], torch.from_numpy(X1)) and float(X[20:].abs().sum()) == 0 and int(R[20:].sum()) == 0
     X, T, R, y = ds[1]
     assert int(T) == 90 and torch.equal(X, torch.from_numpy(X2[:90])) and int(y) == 1
-    Xb, Tb, Rb, yb = D.collate_fn([ds[0], ds[1], ds[2]])
+    Xb, Tb, Rb, yb = DR.collate_ref([ds[0], ds[1], ds[2]])
     assert Xb.shape == (3, 90, 180) and Tb.tolist() == [20, 90, 7] and Rb.shape == (3, 90, 48, 96) and Rb.dtype == torch.uint8
     assert int(Rb[2].sum()) == 0 and Tb.dtype == torch.int64 and yb.dtype == torch.int64
-    Xn, Tn, Rn, yn = D.collate_fn([ds[2]])
+    Xn, Tn, Rn, yn = DR.collate_ref([ds[2]])
     assert Rn is None
 
 
 def test_augmentation_follows_reference_rules(tmp_path):
     p, X0 = _clip(str(tmp_path), "a", 30)
-    ds = D.NPZWordDataset([p], {"yes": 0}, augment=True)
+    ds = DR.ClipDatasetRef([p], {"yes": 0}, augment=True)
     random.seed(0)
     np.random.seed(0)
     lens = set()
@@ -90,11 +91,11 @@ def test_dataset_and_collate_reproduce_the_reference_batches(tmp_path):
     """Same seeds, same visiting order -> the batches the reference's NPZWordDataset(augment=True) + collate_fn built."""
     golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     d, files = _golden_clips(str(tmp_path), golden_dir)
-    ds = D.NPZWordDataset(files, {"no": 0, "yes": 1}, max_t=int(d["max_t"]), augment=True)
+    ds = DR.ClipDatasetRef(files, {"no": 0, "yes": 1}, max_t=int(d["max_t"]), augment=True)
     for b in range(int(d["n_batches"])):
         random.seed(1000 + b)
         np.random.seed(2000 + b)
-        Xb, Tb, Rb, yb = D.collate_fn([ds[i] for i in d[f"batch{b}::order"]], roi_hw=(16, 16))
+        Xb, Tb, Rb, yb = DR.collate_ref([ds[i] for i in d[f"batch{b}::order"]], roi_hw=(16, 16))
         assert np.array_equal(Xb.numpy(), d[f"batch{b}::X"]) and np.array_equal(Tb.numpy(), d[f"batch{b}::T"])
         assert np.array_equal(Rb.numpy(), d[f"batch{b}::R"]) and np.array_equal(yb.numpy(), d[f"batch{b}::y"])
 

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 output directories into the small files kept under profiles/.
 
     python tools/pmc_summary.py stats  gpurun_out/prof2      profiles/round1_b_kernel_stats.csv
-    python tools/pmc_summary.py pmc    gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round1_pmc_traffic.json
+    python tools/pmc_summary.py pmc    gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round1_pmc_traffic.json [workload note]
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports exactly half the bytes of a wide (16 B/lane) coalesced streaming read, which is how every large read
@@ -30,7 +30,7 @@ def stats(src, dst):
     print("wrote", dst, len(rows) - 1, "kernels")
 
 
-def pmc(fetch_dir, write_dir, dst):
+def pmc(fetch_dir, write_dir, dst, workload="bench.py config 2, B=256"):
     res = collections.defaultdict(dict)
     for key, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
         f = (glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"))[0]
@@ -49,7 +49,7 @@ def pmc(fetch_dir, write_dir, dst):
         d["hbm_read_bytes_per_launch_corrected"] = rd
         d["hbm_write_bytes_per_launch"] = wr
         d["hbm_bytes_per_launch"] = rd + wr
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py config 2, B=256",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), " + workload,
                "kernels": res}, open(dst, "w"), indent=1, sort_keys=True)
     print("wrote", dst, len(res), "kernels")
 
@@ -90,4 +90,4 @@ if __name__ == "__main__":
     elif sys.argv[1] == "mfma":
         mfma(sys.argv[2], sys.argv[3], " ".join(sys.argv[4:]))
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], *([" ".join(sys.argv[5:])] if len(sys.argv) > 5 else []))
