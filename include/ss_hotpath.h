@@ -177,7 +177,9 @@ typedef struct ss_gemm_problem {
   long stride_a, stride_b, stride_c;
 } ss_gemm_problem;
 int ss_gemm_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats);
-int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream);
+/* ws_floats = the floats the caller allocated at ws: the entry points recompute the layout and return SS_ERR_ARG when it does not fit
+ * (a caller that sized ws for another group would otherwise be written past its end, silently). */
+int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, long ws_floats, ss_stream_t stream);
 /* The same for bf16 operands (config 5; csrc/gemm_bf16.hip): A and B point at bf16 data (k-major, a_kcontig = b_kcontig = 0; lda /
  * ldb / strides in bf16 elements, multiples of 8; K a multiple of 64; n <= 8), C[b] += A[b]^T B[b] in f32.  A group with at least
  * half a chip of 256 x 128 output tiles runs one workgroup per tile over all of K (neighbouring tiles share operand panels in L2);
@@ -185,7 +187,7 @@ int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, 
  * (ss_gemm_bf16_splitk_group_ws_floats() floats, 16-byte aligned, contents irrelevant) and a second launch folds them into C.
  * `splits` is ignored. */
 int ss_gemm_bf16_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats);
-int ss_gemm_bf16_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream);
+int ss_gemm_bf16_splitk_group(const ss_gemm_problem* problems, int n, float* ws, long ws_floats, ss_stream_t stream);
 
 /* a[0..na) = 0 and b[0..nb) = 0 in one launch (either may be empty; 16-byte aligned): the destinations the d layer_in GEMMs
  * sum into with float atomics are cleared by this, off the critical path, instead of two library fills */
@@ -266,7 +268,9 @@ int ss_gemm_bf16_batched(int a_kcontig, int b_kcontig, int M, int N, int K, cons
  *   ZEROED ONCE by the caller, kept consistent by the kernels afterwards) a layer is ONE persistent launch per clip chunk:
  *   a (16-clip slice, direction) is spread over H/64 workgroups that keep their rows of W_hh in registers for all T steps
  *   and exchange the state (forward) / partial d h_prev (backward) through tagged 8-byte granules (csrc/gru_bf16_pers.h).
- *   sync_ws = NULL, or a shape outside that range: one launch per time step.
+ *   sync_ws = NULL, or a shape outside that range: one launch per time step.  sync_bytes = the bytes the caller allocated at
+ *   sync_ws: the layout is a function of (B, T, H) -- and not monotone in B -- so the entry points recompute it and return
+ *   SS_ERR_ARG when an area sized for another batch is too small for this one.
  *   sync_ws words: [0] launch generation, [1] arrivals, [2] bounded waits that gave up (a lost partner: the workgroups
  *   concerned emit NaN from then on; the owner reads this word where it synchronises), [3] same-XCD fast-path count,
  *   [5] fault injection for tests (1 + index of a workgroup that plays dead; 0 = off).
@@ -285,11 +289,11 @@ int ss_gru_bf16_sync_bytes(int B, int T, int H, long* bytes);
 int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const float* b_hh_f, const float* b_hh_r,
                     const int32_t* lengths, int B, int T, int H, float* out, float* save, uint16_t* out_bf16,
                     uint16_t* out_drop_bf16, float drop_p, uint64_t seed, uint64_t offset, void* ws, void* sync_ws,
-                    ss_stream_t stream);
+                    long sync_bytes, ss_stream_t stream);
 int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, const uint16_t* whh_t_bf16,
                     const int32_t* lengths, int B, int T, int H, float* d_g, uint16_t* d_g_bf16, float drop_p,
                     uint64_t seed, uint64_t offset, float* g_bih_f, float* g_bhh_f, float* g_bih_r, float* g_bhh_r,
-                    void* ws, void* sync_ws, ss_stream_t stream);
+                    void* ws, void* sync_ws, long sync_bytes, ss_stream_t stream);
 int ss_cvt_bf16_rows(const float* x, int ld_x, uint16_t* y, int ld_y, long rows, int cols, float drop_p, uint64_t seed,
                      uint64_t offset, ss_stream_t stream);
 

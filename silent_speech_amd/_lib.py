@@ -58,15 +58,15 @@ SIGNATURES = {
     "ss_gru_bf16_prep": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "ss_gru_bf16_ws_bytes": [_i, _i, _vp],
     "ss_gru_bf16_sync_bytes": [_i, _i, _i, _vp],
-    "ss_gru_bf16_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _u64, _u64, _vp, _vp, _vp],
-    "ss_gru_bf16_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ss_gru_bf16_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _u64, _u64, _vp, _vp, _l, _vp],
+    "ss_gru_bf16_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp],
     "ss_cvt_bf16_rows": [_vp, _i, _vp, _i, _l, _i, _f, _u64, _u64, _vp],
     "ss_gemm_splitk_ws_floats": [_i, _i, _i, _i, _i, _vp],
     "ss_gemm_splitk_reduce": [_vp, _i, _i, _i, _i, _i, _vp, _i, _l, _vp],
     "ss_gemm_splitk_group_ws_floats": [_vp, _i, _vp],
-    "ss_gemm_f32_splitk_group": [_vp, _i, _vp, _vp],
+    "ss_gemm_f32_splitk_group": [_vp, _i, _vp, _l, _vp],
     "ss_gemm_bf16_splitk_group_ws_floats": [_vp, _i, _vp],
-    "ss_gemm_bf16_splitk_group": [_vp, _i, _vp, _vp],
+    "ss_gemm_bf16_splitk_group": [_vp, _i, _vp, _l, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
     "ss_zero_f32x2": [_vp, _l, _vp, _l, _vp],
     "ss_train_prologue": [_vp, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -188,6 +188,11 @@ def ptr(t):
     if t is None:
         return None
     return t.data_ptr()
+
+
+def nbytes(t) -> int:
+    """Bytes behind ``ptr(t)`` (0 for None): the size arguments the ABI checks workspace layouts against."""
+    return 0 if t is None else t.numel() * t.element_size()
 
 
 def stream():

@@ -563,7 +563,7 @@ int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s)
   if (lds_bytes > 160 * 1024) return SS_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
     return SS_ERR_LAUNCH;
-  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256;  // (the cap makes a test walk many frames per workgroup)
+  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : ss_device_cus();  // (the cap makes a test walk many frames per workgroup)
   const int grid = N < cap ? N : cap;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();

@@ -1135,7 +1135,7 @@ int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s,
   if (lds_bytes > 0 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
     return SS_ERR_LAUNCH;
-  const int cap = (ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256) * wgs_per_cu;  // (the cap makes a test walk many frames per workgroup)
+  const int cap = (ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : ss_device_cus()) * wgs_per_cu;  // (the cap makes a test walk many frames per workgroup)
   const int grid = N < cap ? N : cap;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();
@@ -1144,7 +1144,7 @@ int launch_persistent(K kernel, const P& p, int lds_bytes, int N, hipStream_t s,
 // weight-gradient launch with the partial sums through `part` (may be null: float atomics) + the reduce launch
 template <class K>
 int launch_wgrad(K kernel, ConvBwdParams& p, int lds_bytes, int N, int total, float* part, long part_floats, hipStream_t s) {
-  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256;
+  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : ss_device_cus();
   const int grid = N < cap ? N : cap;
   p.part = (part && part_floats >= (long)grid * total) ? part : nullptr;
   const int st = launch_persistent(kernel, p, lds_bytes, N, s);

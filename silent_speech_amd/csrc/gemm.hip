@@ -760,8 +760,14 @@ extern "C" int ss_gemm_splitk_group_ws_floats(const ss_gemm_problem* problems, i
   return SS_OK;
 }
 
-extern "C" int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream) {
+extern "C" int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, long ws_floats, ss_stream_t stream) {
   SS_REQUIRE(problems && ws && n >= 1 && n <= GEMM_GROUP_MAX, SS_ERR_ARG);
+  {
+    long need = 0;
+    const int st = ss_gemm_splitk_group_ws_floats(problems, n, &need);
+    if (st != SS_OK) return st;
+    SS_REQUIRE(ws_floats >= need, SS_ERR_ARG);
+  }
   SS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, SS_ERR_ARG);
   GemmGroup gg;
   ReduceGroup rg;

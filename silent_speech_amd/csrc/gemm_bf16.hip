@@ -795,17 +795,7 @@ int launch_gemm_bf16(int a_kcontig, int b_kcontig, const GemmBfParams& p, dim3 g
 
 // ---- grouped weight-gradient GEMMs (ring kernel, stream-K over the group; see gemm_bf16_ring_group_kernel)
 static const bool ss_gemm_bf16_group_split = getenv("SS_GEMM_BF16_GROUP_SPLIT") != nullptr;  // diagnostic: always the stream-K form
-static int ring_group_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-  }
-  return cus;
-}
+static int ring_group_cus() { return ss_device_cus(); }
 static int ring_group_prepare(const ss_gemm_problem* pr, int n, float* ws, ring::RingGroup* out, int* wgs, long* floats) {
   SS_REQUIRE(pr && n >= 1 && n <= ring::GROUP_MAX, SS_ERR_ARG);
   ring::RingGroup& gg = *out;
@@ -851,13 +841,14 @@ extern "C" int ss_gemm_bf16_splitk_group_ws_floats(const ss_gemm_problem* proble
   return ring_group_prepare(problems, n, nullptr, &gg, &wgs, floats);
 }
 
-extern "C" int ss_gemm_bf16_splitk_group(const ss_gemm_problem* problems, int n, float* ws, ss_stream_t stream) {
+extern "C" int ss_gemm_bf16_splitk_group(const ss_gemm_problem* problems, int n, float* ws, long ws_floats, ss_stream_t stream) {
   SS_REQUIRE(ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, SS_ERR_ARG);
   ring::RingGroup gg;
   int wgs = 0;
   long floats = 0;
   const int st = ring_group_prepare(problems, n, ws, &gg, &wgs, &floats);
   if (st != SS_OK) return st;
+  SS_REQUIRE(gg.whole || ws_floats >= floats, SS_ERR_ARG);  // (one workgroup per tile over all of K stores no slabs)
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(ring::gemm_bf16_ring_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -321,16 +321,7 @@ __global__ __launch_bounds__(256) void cvt_bf16_rows_kernel(const float* __restr
   }
 }
 
-int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
+int device_cus() { return ss_device_cus(); }
 
 void cvt_rows(const float* x, int ld_x, bf16_t* y, int ld_y, long rows, int cols, float drop_p, uint64_t seed, uint64_t offset,
               hipStream_t st) {
@@ -413,13 +404,16 @@ extern "C" int ss_cvt_bf16_rows(const float* x, int ld_x, uint16_t* y, int ld_y,
 extern "C" int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const float* b_hh_f, const float* b_hh_r,
                                const int32_t* lengths, int B, int T, int H, float* out, float* save, uint16_t* out_bf16,
                                uint16_t* out_drop_bf16, float drop_p, uint64_t seed, uint64_t offset, void* ws, void* sync_ws,
-                               ss_stream_t stream) {
+                               long sync_bytes, ss_stream_t stream) {
   SS_REQUIRE(gi && whh_bf16 && b_hh_f && b_hh_r && lengths && out && ws, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
   SS_REQUIRE(H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);  // (step kernels: four waves x whole 32-deep k steps; built: 128..512, 1024)
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int chunk = (sync_ws && pers_supported(H) && T <= 1022) ? pers_chunk_clips(B, H, device_cus()) : 0;
   if (chunk > 0) {
+    long need = 0;
+    if (ss_gru_bf16_sync_bytes(B, T, H, &need) != SS_OK) return SS_ERR_ARG;
+    SS_REQUIRE(sync_bytes >= need, SS_ERR_ARG);  // the section offsets below are derived from B: an area sized for another batch may be short
     PersFwdParams q;
     q.gi = gi; q.whh = whh_bf16; q.bhh_f = b_hh_f; q.bhh_r = b_hh_r; q.lengths = lengths; q.B = B; q.T = T;
     q.out = out; q.save = save; q.out_bf = out_bf16; q.out_drop_bf = out_drop_bf16; q.drop_p = drop_p; q.seed = seed; q.offset = offset;
@@ -453,7 +447,7 @@ extern "C" int ss_gru_bf16_fwd(const float* gi, const uint16_t* whh_bf16, const 
 extern "C" int ss_gru_bf16_bwd(const float* d_out, const float* out, const float* save, const uint16_t* whh_t_bf16,
                                const int32_t* lengths, int B, int T, int H, float* d_g, uint16_t* d_g_bf16, float drop_p,
                                uint64_t seed, uint64_t offset, float* g_bih_f, float* g_bhh_f, float* g_bih_r, float* g_bhh_r,
-                               void* ws, void* sync_ws, ss_stream_t stream) {
+                               void* ws, void* sync_ws, long sync_bytes, ss_stream_t stream) {
   SS_REQUIRE(d_out && out && save && whh_t_bf16 && lengths && (d_g || d_g_bf16) && ws, SS_ERR_ARG);
   SS_REQUIRE(B > 0 && T > 0 && drop_p >= 0.f && drop_p < 1.f, SS_ERR_ARG);
   SS_REQUIRE(H >= 128 && H % 128 == 0, SS_ERR_UNSUPPORTED);
@@ -462,6 +456,9 @@ extern "C" int ss_gru_bf16_bwd(const float* d_out, const float* out, const float
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int chunk = (sync_ws && pers_supported(H) && T <= 1022) ? pers_chunk_clips(B, H, device_cus()) : 0;
   if (chunk > 0) {
+    long need = 0;
+    if (ss_gru_bf16_sync_bytes(B, T, H, &need) != SS_OK) return SS_ERR_ARG;
+    SS_REQUIRE(sync_bytes >= need, SS_ERR_ARG);  // the section offsets below are derived from B: an area sized for another batch may be short
     PersBwdParams q;
     q.d_out = d_out; q.out = out; q.save = save; q.whht = whh_t_bf16; q.lengths = lengths; q.B = B; q.T = T;
     q.dG = d_g; q.dG_bf = d_g_bf16; q.drop_p = drop_p; q.seed = seed; q.offset = offset;

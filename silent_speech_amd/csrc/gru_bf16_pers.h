@@ -101,7 +101,12 @@ __global__ __launch_bounds__(256) void gru_pers_fwd_kernel(PersFwdParams p, unsi
   constexpr int P = H / PUNITS, KS = H / 32;
   constexpr int LDH = H + 16;                   // panel row stride (bf16) == 16 (mod 32): conflict-free under ds_read_b128's lane groups
   constexpr int NGP = H / 64;                   // granule pairs per thread in a sweep of the 16 x H panel (4 H / 256)
-  __shared__ __attribute__((aligned(16))) bf16_t hpan[PSLICE * LDH];
+  // Two panels, by step parity.  A step has ONE workgroup barrier (between the panel writes and the fragment reads), and nothing
+  // else orders a wave's panel writes of step s + 1 behind its siblings' fragment reads of step s: a wave whose sweep only covers
+  // units that OTHER parts publish (H = 512: wave 1 of part 0 sweeps units 256..511) can pass the sweep of step s + 1 while a
+  // sibling still reads step s's panel.  With two panels step s + 1 writes the other one, and step s + 2 -- which reuses this
+  // one -- lies behind the barrier of step s + 1, which every sibling reaches only after its reads of step s.
+  __shared__ __attribute__((aligned(16))) bf16_t hpan2[2][PSLICE * LDH];
   __shared__ unsigned s_gen;
   int groups, group, part;
   pers_ids(P, groups, group, part);
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(256) void gru_pers_fwd_kernel(PersFwdParams p, unsi
       if (!dead && !sweep_check<NGP>(raw, base + (unsigned)s, hv)) dead = !sweep_pairs<NGP>(hrs, pr, 256, base + (unsigned)s, hv, &sync[2], lane);
       STAMP(0);
       if (s + 1 < T) load_gi(s + 1);  // behind the sweep: a whole step to arrive
+      bf16_t* hpan = hpan2[s & 1];
 #pragma unroll
       for (int k = 0; k < NGP; ++k) {
         const int q = tid + 256 * k;  // clip = q / (H/4), units 4 (q % (H/4)) ..

@@ -43,7 +43,8 @@
 
 namespace {
 
-constexpr int SPLIT_MAX_WGS = 240;   // co-residency bound (256 CUs, one 4-wave workgroup each, some slack)
+// co-residency bound of the multi-CU recurrence: one 4-wave workgroup per CU, 16 CUs of slack (240 on MI355X's 256 CUs)
+inline int split_max_wgs() { return ss_device_cus() - 16; }
 constexpr int SPLIT_MAX_T = 1022;
 
 template <int H, int P>
@@ -450,7 +451,7 @@ inline long gru_bwd_granules(int B, int H, int P) { return 2L * (2 * ceil_div(B,
 // exchange their granules through its L2; a grid of 2 pairs x 6 parts (B = 16) had every partner on another XCD.
 inline int gru_split_grid_pairs(int B, int P) {
   const int pairs = 2 * ceil_div(B, SLICE), pad = (pairs + 7) / 8 * 8;
-  return pad * P <= SPLIT_MAX_WGS ? pad : pairs;
+  return pad * P <= split_max_wgs() ? pad : pairs;
 }
 
 // The recurrences of H = 192 over twelve parts of 16 units where the padded grid has room (up to 16 pairs = 128 clips, the
@@ -464,7 +465,7 @@ inline int gru_split_grid_pairs(int B, int P) {
 inline int gru_split_small_parts(int B, int P) {
   if (P != 6) return P;
   const int pad = (2 * ceil_div(B, SLICE) + 7) / 8 * 8;
-  return pad * 12 <= SPLIT_MAX_WGS ? 12 : P;
+  return pad * 12 <= split_max_wgs() ? 12 : P;
 }
 
 // parts per (slice, direction) for a shape, or 0 when the single-workgroup form is the right one
@@ -472,7 +473,7 @@ inline int gru_split_parts(int B, int T, int H) {
   const int pairs = 2 * ceil_div(B, SLICE);
   if (T > SPLIT_MAX_T) return 0;
   const int P = H == 192 ? 6 : (H == 64 ? 2 : 0);
-  return (P && pairs * P <= SPLIT_MAX_WGS) ? P : 0;
+  return (P && pairs * P <= split_max_wgs()) ? P : 0;
 }
 
 }  // namespace

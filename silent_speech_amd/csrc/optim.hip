@@ -245,7 +245,7 @@ extern "C" int ss_colsum_f32(const float* A, int rows, int cols, int lda, float*
   return ss_launch_status();
 }
 
-extern "C" int ss_abi_version(void) { return 1; }
+extern "C" int ss_abi_version(void) { return 2; }
 
 extern "C" const char* ss_status_string(int status) {
   switch (status) {

@@ -513,7 +513,7 @@ int launch_fwd(const CnnFwdParams& p, hipStream_t s) {
       return SS_ERR_LAUNCH;
     attr_set = true;
   }
-  const int cap = 2 * (ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256);  // the cap counts CUs
+  const int cap = 2 * (ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : ss_device_cus());  // the cap counts CUs
   const int grid = p.N < cap ? p.N : cap;
   hipLaunchKernelGGL(roi_cnn_fwd_kernel<G>, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();

@@ -973,7 +973,7 @@ int launch_bwd(const CnnBwdParams& p, hipStream_t s) {
       return SS_ERR_LAUNCH;
     attr_set = true;
   }
-  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : 256;
+  const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : ss_device_cus();
   const int grid = p.N < cap ? p.N : cap;
   hipLaunchKernelGGL(roi_cnn_bwd_kernel<G>, dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();

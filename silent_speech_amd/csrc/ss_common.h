@@ -135,6 +135,20 @@ __device__ __forceinline__ float relu_f(float x) { return x < 0.f ? 0.f : x; }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Compute units of the current device (MI355X: 256).  Every persistent grid, co-residency bound and workspace layout that depends
+// on the chip's size asks here -- no launcher hard-codes 256.  One query per translation unit, then cached.
+static inline int ss_device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    int n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    cus = n > 0 ? n : 256;  // (no device: the size queries a CPU test makes answer for the target chip)
+  }
+  return cus;
+}
+
 // ---- diagnostic build only (-DSS_STAMP): per-stage cycle shares of the persistent kernels.
 // Thread 0 of every workgroup accumulates s_memtime deltas between barriers; the real build has no stamps.
 #ifdef SS_STAMP

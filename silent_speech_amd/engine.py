@@ -371,7 +371,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             with torch.cuda.stream(side):
                 side.wait_event(ws.ev_fork)
                 L.call("ss_gemm_f32_splitk_group", *L.gemm_group(dw_problems(ws, G, cfg, l, lin, ld_in)), ws.splitk_ws.data_ptr(),
-                       L.stream(), tag="gemm_gru_dW")
+                       ws.splitk_ws.numel(), L.stream(), tag="gemm_gru_dW")
         # the weight-gradient GEMMs of the upper layers start only when this layer's d layer_in GEMM is through: two
         # MFMA-bound GEMMs side by side gain nothing and the one on the critical path loses half its rate; beside the
         # latency-bound recurrence of the layer below they fill idle matrix pipes.  Layer 0 has no recurrence left to

@@ -87,6 +87,32 @@ def dw_group_ok(problems) -> bool:
     return USE_DW_GROUP and all(q.K % 64 == 0 for q in problems)
 
 
+DW_GROUP_MAX = 8  # problems per ss_gemm_bf16_splitk_group launch (csrc/gemm_bf16.hip ring::GROUP_MAX)
+
+
+def dw_flush_after(cfg, l: int, pending: int) -> bool:
+    """Does backward() launch the pending weight-gradient problems behind layer ``l`` (walking top-down), ``pending`` of them
+    queued including this layer's?  One rule for the launches and for the scratch size (WorkspaceBf16 replays it): a group
+    holds at most DW_GROUP_MAX problems and a layer adds up to three, so it is flushed as soon as another layer might not fit."""
+    return l == 0 or not DW_ALL_LAYERS or pending + 3 > DW_GROUP_MAX
+
+
+def dw_group_schedule(cfg, B, T, kp):
+    """The groups of shape-only problem records backward() will launch, in launch order."""
+    groups, pending = [], []
+    for l in range(cfg.gru_layers - 1, -1, -1):
+        pr = dw_problems(cfg, B, T, l, kp[l])
+        if not dw_group_ok(pr):
+            continue  # this layer goes through the three-launch form; the queue is untouched
+        pending = pending + pr
+        if dw_flush_after(cfg, l, len(pending)):
+            groups.append(pending)
+            pending = []
+    if pending:
+        groups.append(pending)
+    return groups
+
+
 def _pstride(P, a: str, b: str) -> int:
     return (P[b].data_ptr() - P[a].data_ptr()) // 4
 
@@ -172,15 +198,11 @@ class WorkspaceBf16:
             self.dG = [torch.empty(2, N, 4, H, **f32) if self.gru_sync is None else None for _ in range(cfg.gru_layers)]
             self.dG_bf = [torch.empty(2, N, 4, H, **i16) for _ in range(cfg.gru_layers)]
             self.d_out = torch.empty(N, 2 * H, **f32)
-            need, allp = 0, []
-            for l in range(cfg.gru_layers):
-                pr = dw_problems(cfg, B, T, l, self.kp[l])
-                if dw_group_ok(pr):
-                    need = max(need, L.gemm_group_ws_floats(pr, bf16=True))
-                    allp += pr
-            if allp and DW_ALL_LAYERS and len(allp) <= 8:
-                need = max(need, L.gemm_group_ws_floats(allp, bf16=True))
-            self.dw_ws = torch.empty(need, **f32) if need else None
+            # scratch of the grouped weight-gradient launches: the largest group of the schedule backward() really runs (round 3
+            # sized it for one layer or all layers; with three GRU layers the launches are {2, 1} and {0}, and {2, 1} was larger
+            # than either -- 18.9 MB written past the end)
+            groups = dw_group_schedule(cfg, B, T, self.kp)
+            self.dw_ws = torch.empty(max(4, max(L.gemm_group_ws_floats(g, bf16=True) for g in groups)), **f32) if groups else None
             self.d_lower = [None] + [torch.empty(N, 2 * H, **f32) for _ in range(1, cfg.gru_layers)]
             self.xhat = torch.empty(B, 2 * H, **f32)
             self.rstd = torch.empty(B, **f32)
@@ -252,7 +274,7 @@ def forward(P: Dict[str, torch.Tensor], cfg, ws: WorkspaceBf16, X: torch.Tensor,
         L.call("ss_gru_bf16_fwd", ws.gi[l].data_ptr(), ws.whh[l].data_ptr(), P[f"gru.bias_hh_l{l}"].data_ptr(),
                P[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.lengths.data_ptr(), B, T, H, ws.out[l].data_ptr(),
                ws.save[l].data_ptr() if stash else None, ws.out_bf[l].data_ptr(), ws.out_drop_bf[l].data_ptr() if drop else None,
-               cfg.gru_dropout if drop else 0.0, seed, (l + 1) << 40, ws.gru_ws.data_ptr(), L.ptr(ws.gru_sync), s)
+               cfg.gru_dropout if drop else 0.0, seed, (l + 1) << 40, ws.gru_ws.data_ptr(), L.ptr(ws.gru_sync), L.nbytes(ws.gru_sync), s)
         lin = ws.out_drop_bf[l] if drop else ws.out_bf[l]
         ws.lin_bf = getattr(ws, "lin_bf", {})
         ws.lin_bf[l + 1] = lin
@@ -316,7 +338,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
                0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed,
                (l + 1) << 40, G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
                G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.gru_ws.data_ptr(),
-               L.ptr(ws.gru_sync), s)
+               L.ptr(ws.gru_sync), L.nbytes(ws.gru_sync), s)
         Kp = ws.kp[l]
         lin = (ws.lin_bf0 if l == 0 else ws.lin_bf[l]).data_ptr()  # what the forward pass multiplied W_ih with (dropped out or not)
         dg = ws.dG_bf[l].data_ptr()
@@ -332,9 +354,9 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
                 # config-5 shapes = one workgroup per tile and CU walking all of K (no K split, no slabs; neighbouring tiles share
                 # operand panels in L2) -- per layer (144 / 72 tiles) the K tiles had to be dealt over the CUs, 154 + 80 us
                 dw_pending.extend(pr)
-                if l == 0 or not DW_ALL_LAYERS or len(dw_pending) > 5:  # (a group holds at most 8 problems)
+                if dw_flush_after(cfg, l, len(dw_pending)):
                     arr, n = L.gemm_group(dw_pending)
-                    L.call("ss_gemm_bf16_splitk_group", arr, n, ws.dw_ws.data_ptr(), L.stream(), tag="gemm_bf16_dW")
+                    L.call("ss_gemm_bf16_splitk_group", arr, n, ws.dw_ws.data_ptr(), ws.dw_ws.numel(), L.stream(), tag="gemm_bf16_dW")
                     dw_pending.clear()
                 return
             # ---- weight gradients: d W_ih = dGi^T . layer_in;  d W_hh = dGh^T . h_prev (rows r|z from columns [0,2H), rows n from [3H,4H))
@@ -383,6 +405,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
                 param_grads()
         else:
             param_grads()
+    assert not dw_pending, "a weight-gradient group was queued and never launched"  # (dw_flush_after flushes at l == 0)
     if cfg.use_roi:
         if d_X is not None:
             L.call("ss_copy_rows_f32", ws.dZ.data_ptr(), cfg.in_dim, d_X.data_ptr(), cfg.x_dim, N, cfg.x_dim, s)

@@ -137,7 +137,7 @@ class Trainer:
             n = B // M
             cur = torch.cuda.current_stream()
             self.ev_start.record(cur)
-            L.call("ss_roi_cnn_set_max_workgroups", 256 - self.CNN_RESERVED_CUS)
+            L.call("ss_roi_cnn_set_max_workgroups", torch.cuda.get_device_properties(X.device).multi_processor_count - self.CNN_RESERVED_CUS)
             parts = [(X[m * n:(m + 1) * n], lengths[m * n:(m + 1) * n], None if R is None else R[m * n:(m + 1) * n],
                       y[m * n:(m + 1) * n]) for m in range(M)]
             # issue order fwd(0), fwd(1), ..., bwd(0), bwd(1), ...: the host never runs far ahead on one stream

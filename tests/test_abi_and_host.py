@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/ss_hotpath.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.ss_abi_version() == 1
+    assert lib.ss_abi_version() == 2
     assert lib.ss_status_string(-3) == b"unsupported shape"
 
 
@@ -126,3 +126,32 @@ def test_bf16_weight_gradient_group_size_query_needs_no_gpu():
     with pytest.raises(RuntimeError):
         _lib.gemm_group_ws_floats(l1 + l0 + l1, bf16=True)                      # nine problems
 
+
+
+def test_bf16_weight_gradient_scratch_covers_every_group_backward_launches():
+    """with three GRU layers backward() launches the groups {layer 2, layer 1} and {layer 0}; the scratch was
+    sized for one layer or for all layers, and {2, 1} is larger than either.  The sizing now replays the launch rule."""
+    from types import SimpleNamespace
+
+    from silent_speech_amd import _lib
+    from silent_speech_amd import engine_bf16 as E
+
+    for layers in (1, 2, 3, 4):
+        cfg = SimpleNamespace(hidden=512, in_dim=148, gru_layers=layers)
+        kp = [152] + [1024] * (layers - 1)
+        groups = E.dw_group_schedule(cfg, 256, 30, kp)
+        assert sum(len(g) for g in groups) == 3 * layers and all(len(g) <= E.DW_GROUP_MAX for g in groups)
+        # the schedule is what backward() does: walk top-down with the same flush rule
+        pending, launched = 0, []
+        for l in range(layers - 1, -1, -1):
+            pending += 3
+            if E.dw_flush_after(cfg, l, pending):
+                launched.append(pending)
+                pending = 0
+        assert pending == 0 and launched == [len(g) for g in groups]
+    cfg = SimpleNamespace(hidden=512, in_dim=148, gru_layers=3)
+    groups = E.dw_group_schedule(cfg, 256, 30, [152, 1024, 1024])
+    assert [len(g) for g in groups] == [6, 3]
+    need = max(_lib.gemm_group_ws_floats(g, bf16=True) for g in groups)
+    per_layer = max(_lib.gemm_group_ws_floats(E.dw_problems(cfg, 256, 30, l, k), bf16=True) for l, k in ((0, 152), (1, 1024), (2, 1024)))
+    assert need >= _lib.gemm_group_ws_floats(groups[0], bf16=True) > per_layer  # the case that overflowed

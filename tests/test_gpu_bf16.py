@@ -195,7 +195,7 @@ def test_gemm_bf16_splitk_group(L, Bc, T, H, Kin):
                             1, 2, sa, sb, 3 * H * H)]
         ws = torch.full((L.gemm_group_ws_floats(pr, bf16=True),), float("nan"), device="cuda")
         arr, n = L.gemm_group(pr)
-        L.call("ss_gemm_bf16_splitk_group", arr, n, ws.data_ptr(), L.stream())
+        L.call("ss_gemm_bf16_splitk_group", arr, n, ws.data_ptr(), ws.numel(), L.stream())
         torch.cuda.synchronize()
         for got, want in ((G_ih, want_ih), (G_hh, want_hh)):
             assert float((got.cpu() - want).abs().max()) < 3e-4 * float(want.abs().max()), rep
@@ -291,7 +291,7 @@ def test_gru_bf16_fwd_bwd(L, B, T, H, drop_p, persistent):
     out_drop_bf = torch.full((N, 2 * H), 0x7fc0, device="cuda", dtype=torch.int16)
     L.call("ss_gru_bf16_fwd", gid.data_ptr(), wb.data_ptr(), b_f.data_ptr(), b_r.data_ptr(), lens.data_ptr(), B, T, H,
            out.data_ptr(), save.data_ptr(), out_bf.data_ptr(), out_drop_bf.data_ptr(), drop_p, seed, offset, ws.data_ptr(),
-           L.ptr(sync), L.stream())
+           L.ptr(sync), L.nbytes(sync), L.stream())
     torch.cuda.synchronize()
     if sync is not None:
         assert int(sync[2]) == 0, "a bounded wait of the persistent recurrence gave up"
@@ -311,7 +311,7 @@ def test_gru_bf16_fwd_bwd(L, B, T, H, drop_p, persistent):
     gb = [torch.zeros(3 * H, device="cuda") for _ in range(4)]  # d b_ih fwd, d b_hh fwd, d b_ih rev, d b_hh rev
     L.call("ss_gru_bf16_bwd", d_out_d.data_ptr(), out.data_ptr(), save.data_ptr(), wtb.data_ptr(),
            lens.data_ptr(), B, T, H, dG.data_ptr(), dG_bf.data_ptr(), drop_p, seed, offset, *[t_.data_ptr() for t_ in gb],
-           ws.data_ptr(), L.ptr(sync), L.stream())
+           ws.data_ptr(), L.ptr(sync), L.nbytes(sync), L.stream())
     torch.cuda.synchronize()
     if sync is not None:
         assert int(sync[2]) == 0
@@ -319,7 +319,7 @@ def test_gru_bf16_fwd_bwd(L, B, T, H, drop_p, persistent):
     if sync is not None:  # the f32 gate gradients are optional there: only the bf16 copy
         dG_bf2 = torch.full_like(dG_bf, 0x7fc0)
         L.call("ss_gru_bf16_bwd", d_out_d.data_ptr(), out.data_ptr(), save.data_ptr(), wtb.data_ptr(), lens.data_ptr(), B, T, H,
-               None, dG_bf2.data_ptr(), drop_p, seed, offset, None, None, None, None, ws.data_ptr(), L.ptr(sync), L.stream())
+               None, dG_bf2.data_ptr(), drop_p, seed, offset, None, None, None, None, ws.data_ptr(), L.ptr(sync), L.nbytes(sync), L.stream())
         torch.cuda.synchronize()
         assert torch.equal(dG_bf2, dG_bf)
     dGs = dG.cpu().view(2, N, 4, H).sum(1)  # (2, 4, H) column sums

@@ -169,7 +169,7 @@ def test_gemm_splitk_group(L, aligned):
     need = L.gemm_group_ws_floats(probs)
     ws = torch.full((need + 8,), float("nan"), device="cuda")
     arr, n = L.gemm_group(probs)
-    L.call("ss_gemm_f32_splitk_group", arr, n, ws.data_ptr(), L.stream())
+    L.call("ss_gemm_f32_splitk_group", arr, n, ws.data_ptr(), ws.numel(), L.stream())
     sync()
     for j in range(3):
         assert_close(f"group problem {j}", outs[j], refs[j], atol=3e-4, rtol=1e-5)

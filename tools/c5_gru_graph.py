@@ -31,7 +31,7 @@ def main():
 
     def run():
         L.call("ss_gru_bf16_fwd", gi.data_ptr(), wb.data_ptr(), bf_.data_ptr(), br_.data_ptr(), lens.data_ptr(), B, T, H,
-               out.data_ptr(), save.data_ptr(), ws.data_ptr(), L.stream())
+               out.data_ptr(), save.data_ptr(), None, None, 0.0, 0, 0, ws.data_ptr(), None, 0, L.stream())
 
     def timed(fn, reps=20):
         for _ in range(3):

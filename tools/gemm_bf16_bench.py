@@ -59,12 +59,12 @@ def run_group(name, l, reps=20):
     ws = torch.empty(L.gemm_group_ws_floats(pr, bf16=True), device="cuda")
     arr, n = L.gemm_group(pr)
     for _ in range(3):
-        L.call("ss_gemm_bf16_splitk_group", arr, n, ws.data_ptr(), L.stream())
+        L.call("ss_gemm_bf16_splitk_group", arr, n, ws.data_ptr(), ws.numel(), L.stream())
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        L.call("ss_gemm_bf16_splitk_group", arr, n, ws.data_ptr(), L.stream())
+        L.call("ss_gemm_bf16_splitk_group", arr, n, ws.data_ptr(), ws.numel(), L.stream())
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps

@@ -50,9 +50,9 @@ def main():
         s = L.stream()
         tf = timeit(lambda: L.call("ss_gru_bf16_fwd", gi.data_ptr(), whh.data_ptr(), bhh[0].data_ptr(), bhh[1].data_ptr(), lens.data_ptr(), B, T,
                                    H, out.data_ptr(), save.data_ptr(), out_bf.data_ptr(), out_dr.data_ptr(), 0.1, 1, 1 << 40, ws.data_ptr(),
-                                   sync.data_ptr(), s))
+                                   sync.data_ptr(), L.nbytes(sync), s))
         tb = timeit(lambda: L.call("ss_gru_bf16_bwd", d_out.data_ptr(), out.data_ptr(), save.data_ptr(), whht.data_ptr(), lens.data_ptr(), B, T,
-                                   H, None, dG_bf.data_ptr(), 0.1, 1, 1 << 40, *[t_.data_ptr() for t_ in gb], ws.data_ptr(), sync.data_ptr(), s))
+                                   H, None, dG_bf.data_ptr(), 0.1, 1, 1 << 40, *[t_.data_ptr() for t_ in gb], ws.data_ptr(), sync.data_ptr(), L.nbytes(sync), s))
         res[T] = (tf, tb)
         print(f"T={T:3d}: forward {tf:7.1f} us   backward {tb:7.1f} us", flush=True)
     for k, nm in ((0, "forward"), (1, "backward")):

@@ -48,7 +48,7 @@ def main():
     fn(buf.ctypes.data)
     for _ in range(reps):
         L.call("ss_gru_bf16_fwd", gi.data_ptr(), whh.data_ptr(), bhh[0].data_ptr(), bhh[1].data_ptr(), lens.data_ptr(), B, T, H, out.data_ptr(),
-               save.data_ptr(), out_bf.data_ptr(), out_dr.data_ptr(), 0.1, 1, 1 << 40, ws.data_ptr(), sync.data_ptr(), L.stream())
+               save.data_ptr(), out_bf.data_ptr(), out_dr.data_ptr(), 0.1, 1, 1 << 40, ws.data_ptr(), sync.data_ptr(), L.nbytes(sync), L.stream())
     report("forward", {15: "loop top + gi loads issued", 0: "sweep of the previous state", 1: "panel write + barrier", 2: "fragment reads + 48 MFMAs",
                        3: "gates + publish", 4: "out / bf16 copies / save stores"})
     d_out = torch.randn(N, 2 * H, device=dev)
@@ -56,7 +56,7 @@ def main():
     gb = [torch.zeros(3 * H, device=dev) for _ in range(4)]
     for _ in range(reps):
         L.call("ss_gru_bf16_bwd", d_out.data_ptr(), out.data_ptr(), save.data_ptr(), whht.data_ptr(), lens.data_ptr(), B, T, H, None,
-               dG_bf.data_ptr(), 0.1, 1, 1 << 40, *[t_.data_ptr() for t_ in gb], ws.data_ptr(), sync.data_ptr(), L.stream())
+               dG_bf.data_ptr(), 0.1, 1, 1 << 40, *[t_.data_ptr() for t_ in gb], ws.data_ptr(), sync.data_ptr(), L.nbytes(sync), L.stream())
     report("backward", {15: "loop top", 5: "gate gradients + d_pre panel write", 6: "barrier", 7: "fragment reads + 48 MFMAs + publish", 8: "d_g stores + sums",
                         9: "next step's inputs (loads, Philox)", 10: "sweep of the partial sums", 11: "sum + LDS + barrier + d h"})
     torch.cuda.synchronize()
