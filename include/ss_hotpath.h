@@ -52,6 +52,18 @@ int ss_feature_fuse(const float* lm, const uint8_t* reset, int B, int T, int K, 
                     int a_right, int a_up, int a_lo, int variant, float* X, int ldx, float* center,
                     double* fourth, ss_stream_t stream);
 
+/* The live chain's front for n DISTINCT streams, one frame each (live_infer_official.py:264-296): the distance gate
+ * band_lo <= mouth_w <= band_hi (MOUTH_W_MIN_PX / MAX_PX, :23-24, :272) decides whether a frame is KEPT; a kept frame gets
+ * extract_feature with the stream's velocity state, a dropped frame of a recording stream clears that state (:295-296), so the
+ * first kept frame after re-entry has vel = 0.  State, resident in HBM, zero-initialised by the caller: prev_lm (S,K,2) = raw
+ * landmarks of the stream's previous kept frame, has_prev (S) u8.  recording (n) u8 or NULL (= all recording): 0 leaves the
+ * stream untouched (``if recording`` false).  Outputs per frame i: X row (zeros when dropped), center, fourth (as
+ * ss_feature_fuse), kept[i].  stream_ids must be distinct and in [0, n_streams) -- the caller checks. */
+int ss_feature_fuse_stream(const float* lm, const int32_t* stream_ids, const uint8_t* recording, int n, int n_streams, int K,
+                           int w, int h, int a_left, int a_right, int a_up, int a_lo, int variant, double band_lo,
+                           double band_hi, float* prev_lm, uint8_t* has_prev, float* X, int ldx, float* center,
+                           double* fourth, uint8_t* kept, ss_stream_t stream);
+
 /* ---- a2: ROI crop rectangle ---------------------------------------------------------------
  * replaces the index arithmetic of crop_roi (record_landmarks_official.py:106-114, variant 0) and
  * crop_roi_gray (live_infer_official.py:172-181, variant 1).  Bit-exact integers.
@@ -218,7 +230,9 @@ int ss_batch_gather_u8(const uint8_t* src, int frame_bytes, const int32_t* frame
  * ss_mouth_openness: the openness signal itself, float64 like the reference's Python floats.  lm (n,K,2) f32 normalised
  *   (x,y) landmarks; mode 0: |y[i_bot] - y[i_top]| / (dist2d(lm[i_eye_l], lm[i_eye_r]) + 1e-6)
  *   (important_landmarks.py:64-67, 131-133; within one ulp of its ``** 0.5``); mode 1: max(y) - min(y) over the K
- *   landmarks (inactive/live_test_5.py:92-94; the i_* arguments are ignored).
+ *   landmarks (inactive/live_test_5.py:92-94; the i_* arguments are ignored); mode 2: |lm[i_top] - lm[i_bot]| / (|lm[i_eye_r] -
+ *   lm[i_eye_l]| + 1e-6) in float32, every operation rounded (inactive/live_feed.py:69-78 with i_top/i_bot = 13/14 and the
+ *   mouth corners 61/291 in the two "eye" slots).  All three are pinned by the reference's own outputs (tests/golden/serving.npz).
  * ss_mouth_gate: EMA (alpha) of the openness and its open/close hysteresis, carried in float64
  *   (important_landmarks.py:136-144: ``mouth_ema`` is a Python float).
  * ss_clip_gate: openness-gated clip segmentation of n DISTINCT streams (inactive/live_test_5.py:146-152, 233-272):

@@ -4,8 +4,11 @@ Follows /root/reference/inactive/live_feed.py:155 (``deque(maxlen=max_t)``), :16
 ``WARMUP_MIN = min(10, max_t)``), :201-207 (predict when ``len(buf) >= WARMUP_MIN and frame_idx % PRED_EVERY == 0`` on the
 buffer zero-padded to ``(max_t, D)``) and /root/reference/important_landmarks.py:57-61, :136-144 (EMA with
 ``EMA_ALPHA = 0.25``, open/close hysteresis at 0.02 / 0.02).  The reference runs this per camera inside its capture loop,
-which cannot be called; parity of this file is therefore by restatement only (PARITY UNPINNED), the model forward it
-feeds is pinned through oracle/model_ref.py.
+which cannot be called: the LOOPS (ring / deque, EMA + hysteresis, clip gating) are restatements (PARITY UNPINNED); the
+SIGNALS they consume are pinned -- ``openness_eye_span``, ``openness_y_range``, ``face_to_xvec`` and ``feat83_and_openness`` are
+held to what the reference's own ``dist2d`` / ``compute_openness`` / ``face_to_xvec`` / ``extract_83_and_openness`` returned on
+seeded faces (tests/golden/serving.npz, made by tests/golden/make_golden.py:gen_serving) -- and the model forward is pinned
+through oracle/model_ref.py.
 
 ``openness_eye_span`` / ``openness_y_range`` restate important_landmarks.py:64-67, 131-133 and
 inactive/live_test_5.py:92-94 literally (Python floats = float64, ``** 0.5``); ``ClipGateRef`` restates the clip-gating
@@ -75,6 +78,42 @@ def openness_y_range(face_xy) -> float:
     """inactive/live_test_5.py:92-94 over the landmarks given."""
     ys = [float(p[1]) for p in face_xy]
     return float(max(ys) - min(ys))
+
+
+def face_to_xvec(face_xy, idxs, with_openness: bool) -> np.ndarray:
+    """inactive/live_test_5.py:96-112: float32 x / y of the clip's landmarks, each centred on its own mean, interleaved
+    (x0, y0, x1, y1, ...); optionally one more entry, the y range of the CENTRED float32 values."""
+    pts = np.asarray([[float(face_xy[i][0]), float(face_xy[i][1])] for i in idxs], np.float64)
+    xs, ys = pts[:, 0].astype(np.float32), pts[:, 1].astype(np.float32)
+    xs, ys = xs - xs.mean(), ys - ys.mean()
+    v = np.stack([xs, ys], 1).reshape(-1).astype(np.float32)
+    if with_openness:
+        v = np.concatenate([v, np.asarray([float(ys.max() - ys.min())], np.float32)])
+    return v
+
+
+LIP_ORDER_LIVE_FEED = (185, 40, 39, 37, 0, 267, 269, 270, 409, 415, 310, 311, 312, 13, 82, 81, 42, 183, 78,
+                       61, 146, 91, 181, 84, 17, 314, 405, 321, 375, 291, 308, 324, 318, 402, 317, 14, 87, 178, 88, 95)
+
+
+def _norm2_f32(v) -> np.float32:
+    """np.linalg.norm of a float32 2-vector: both squares, their sum and the root rounded to float32 one by one."""
+    a, b = np.float32(v[0]), np.float32(v[1])
+    return np.sqrt(np.float32(np.float32(a * a) + np.float32(b * b)))
+
+
+def feat83_and_openness(lm: np.ndarray, lip_order=LIP_ORDER_LIVE_FEED):
+    """inactive/live_feed.py:57-86 on a (478, 2) float32 landmark array: the 40 lip points centred on their centroid and
+    divided by the mouth width (|lm[291] - lm[61]| + 1e-6), then openness = |lm[13] - lm[14]| / width,
+    height = |lm[0] - lm[17]| / width and corner = |lm[61] - lm[291]| / width - 1 -- all in float32."""
+    lm = np.asarray(lm, np.float32)
+    pts = lm[list(lip_order)]
+    width = _norm2_f32(lm[291] - lm[61]) + np.float32(1e-6)
+    feat80 = ((pts - pts.mean(axis=0, keepdims=True)) / width).reshape(-1).astype(np.float32)
+    openness = float(_norm2_f32(lm[13] - lm[14]) / width)
+    height = float(_norm2_f32(lm[0] - lm[17]) / width)
+    corner = float(_norm2_f32(lm[61] - lm[291]) / width) - 1.0
+    return np.concatenate([feat80, np.asarray([openness, height, corner], np.float32)]), openness
 
 
 # ------------------------------------------------------------------ clip gating (inactive/live_test_5.py:146-152, 233-272)

@@ -12,7 +12,7 @@ from .device_data import DeviceClipStore
 from .engine import Config
 from .features import crop_boxes, crop_rois, extract_features
 from .infer import GraphedInference
-from .serving import ClipGateServer, StreamServer, mouth_openness
+from .serving import ClipGateServer, LiveFrontEnd, StreamServer, mouth_openness
 from .model import AttnPool, BiGRUClassifier, TinyROICNN
 from .train import Trainer, allreduce_flat_grads, shard_range
 

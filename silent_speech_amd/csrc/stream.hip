@@ -68,6 +68,14 @@ __global__ __launch_bounds__(256) void mouth_openness_kernel(const float* __rest
     const double dx = (double)f[2 * i_eye_l] - (double)f[2 * i_eye_r], dy = (double)f[2 * i_eye_l + 1] - (double)f[2 * i_eye_r + 1];
     const double span = __dadd_rn(__dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))), 1e-6);
     out[i] = __ddiv_rn(gap, span);
+  } else if (mode == 2) {
+    // inactive/live_feed.py:69-78 on float32 landmark arrays: np.linalg.norm of a 2-vector is sqrt(x*x + y*y) with every
+    // operation rounded to float32 (no FMA: pinned by tests/golden/serving.npz), the width gets + 1e-6 in float32
+    const float gx = __fsub_rn(f[2 * i_top], f[2 * i_bot]), gy = __fsub_rn(f[2 * i_top + 1], f[2 * i_bot + 1]);
+    const float wx = __fsub_rn(f[2 * i_eye_r], f[2 * i_eye_l]), wy = __fsub_rn(f[2 * i_eye_r + 1], f[2 * i_eye_l + 1]);
+    const float gap = __fsqrt_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));
+    const float wid = __fadd_rn(__fsqrt_rn(__fadd_rn(__fmul_rn(wx, wx), __fmul_rn(wy, wy))), 1e-6f);
+    out[i] = (double)__fdiv_rn(gap, wid);
   } else {
     float lo = f[1], hi = f[1];
     for (int k = 1; k < K; ++k) {
@@ -170,8 +178,8 @@ extern "C" int ss_ring_window_map(const int32_t* stream_ids, int n, int max_t, c
 
 extern "C" int ss_mouth_openness(const float* lm, int n, int K, int mode, int i_top, int i_bot, int i_eye_l, int i_eye_r,
                                  double* openness, ss_stream_t stream) {
-  SS_REQUIRE(lm && openness && n > 0 && K > 0 && (mode == 0 || mode == 1), SS_ERR_ARG);
-  if (mode == 0) SS_REQUIRE(i_top >= 0 && i_top < K && i_bot >= 0 && i_bot < K && i_eye_l >= 0 && i_eye_l < K && i_eye_r >= 0 && i_eye_r < K, SS_ERR_ARG);
+  SS_REQUIRE(lm && openness && n > 0 && K > 0 && mode >= 0 && mode <= 2, SS_ERR_ARG);
+  if (mode != 1) SS_REQUIRE(i_top >= 0 && i_top < K && i_bot >= 0 && i_bot < K && i_eye_l >= 0 && i_eye_l < K && i_eye_r >= 0 && i_eye_r < K, SS_ERR_ARG);
   hipLaunchKernelGGL(mouth_openness_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), lm, n, K, mode,
                      i_top, i_bot, i_eye_l, i_eye_r, openness);
   return ss_launch_status();

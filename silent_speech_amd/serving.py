@@ -27,15 +27,85 @@ OPEN_THRESH, START_N, END_N, MAX_CLIP, MIN_CLIP = 0.18, 3, 5, 60, 6
 def mouth_openness(landmarks: torch.Tensor, mode: str = "eye_span", idx=(MOUTH_TOP, MOUTH_BOTTOM, LEFT_EYE_CORNER, RIGHT_EYE_CORNER)):
     """(n, K, 2) f32 normalised landmarks on the device -> (n,) float64 openness.  ``eye_span``:
     important_landmarks.py:131-133 (lip gap over the eye-corner distance; ``idx`` = positions of landmarks 13, 14, 33, 263
-    in the K given); ``y_range``: inactive/live_test_5.py:92-94 (max y - min y over the K landmarks)."""
+    in the K given); ``y_range``: inactive/live_test_5.py:92-94 (max y - min y over the K landmarks); ``width_norm``:
+    inactive/live_feed.py:69-78 in float32 (|lm[13] - lm[14]| over the mouth width |lm[291] - lm[61]| + 1e-6; ``idx`` =
+    positions of landmarks 13, 14, 61, 291)."""
     if not landmarks.is_cuda:
         raise RuntimeError("mouth_openness runs on the HIP device (there is no CPU path)")
     lm = landmarks.to(torch.float32).contiguous()
     n, K, _ = lm.shape
     out = torch.empty(n, device=lm.device, dtype=torch.float64)
-    L.call("ss_mouth_openness", lm.data_ptr(), n, K, 0 if mode == "eye_span" else 1, *[int(v) for v in idx], out.data_ptr(),
+    L.call("ss_mouth_openness", lm.data_ptr(), n, K, {"eye_span": 0, "y_range": 1, "width_norm": 2}[mode], *[int(v) for v in idx], out.data_ptr(),
            L.stream())
     return out
+
+
+class LiveFrontEnd:
+    """The per-frame front of the live script for S streams as ONE chain of device launches
+    (/root/reference/live_infer_official.py:264-296): distance gate on the mouth width -> ``extract_feature`` with the
+    stream's velocity state (``prev_xy``, cleared whenever a frame of a recording stream falls outside the 60-150 px band,
+    :295-296) -> ``crop_roi_gray`` box -> BGR2GRAY + INTER_AREA resize (zeros when the box is rejected, :292-293).
+    State per stream lives in HBM: the previous kept frame's landmarks and a flag (``ss_feature_fuse_stream``)."""
+
+    def __init__(self, n_streams: int, idxs: Sequence[int], frame_wh, roi_hw=None, variant: str = "live",
+                 band=(None, None), device="cuda"):
+        from . import features as F
+
+        L.load()
+        self.S, self.idxs, self.K = n_streams, tuple(int(i) for i in idxs), len(idxs)
+        self.w, self.h = int(frame_wh[0]), int(frame_wh[1])
+        self.roi_hw, self.variant = roi_hw, variant
+        self.band = (float(F.MOUTH_W_MIN_PX if band[0] is None else band[0]), float(F.MOUTH_W_MAX_PX if band[1] is None else band[1]))
+        self.anchors = F.anchor_positions(self.idxs)
+        dev = self.device = torch.device(device)
+        self.prev_lm = torch.zeros(n_streams, self.K, 2, device=dev)
+        self.has_prev = torch.zeros(n_streams, device=dev, dtype=torch.uint8)
+
+    def reset(self, stream_ids: Optional[Sequence[int]] = None):
+        """``prev_xy = None`` for the given streams (all by default): the start of a recording, live...:333-336."""
+        if stream_ids is None:
+            self.has_prev.zero_()
+        else:
+            self.has_prev[torch.as_tensor(list(stream_ids), device=self.device, dtype=torch.long)] = 0
+
+    def __call__(self, stream_ids: Sequence[int], lm: torch.Tensor, frames_bgr: Optional[torch.Tensor] = None,
+                 recording: Optional[torch.Tensor] = None):
+        """lm (n,K,2) f32 normalised landmarks of the K selected indices, frames_bgr (n,h,w,3) u8 (or None without ROI) ->
+        kept (n,) bool on the HOST (the one read-back of a tick), X (n,2K+4) f32, rois (n,H,W) u8 or None; rows of dropped
+        frames are zeros and must not be appended."""
+        from . import features as F
+
+        ids = np.asarray(stream_ids, np.int32)
+        n = len(ids)
+        if len(set(ids.tolist())) != n:
+            raise ValueError("one frame per stream and tick")
+        if n and (ids.min() < 0 or ids.max() >= self.S):
+            raise ValueError(f"stream ids must be in [0, {self.S})")
+        if not lm.is_cuda:
+            raise RuntimeError("the live front end runs on the HIP device (there is no CPU path)")
+        if tuple(lm.shape) != (n, self.K, 2) or lm.dtype != torch.float32:
+            raise ValueError(f"lm must be float32 ({n}, {self.K}, 2), got {lm.dtype} {tuple(lm.shape)}")
+        dev = self.device
+        lm = lm.contiguous()
+        ids_d = torch.from_numpy(ids).to(dev)
+        rec = recording.to(dev, torch.uint8).contiguous() if recording is not None else None
+        if rec is not None and rec.numel() != n:
+            raise ValueError(f"recording must hold {n} values")
+        D = 2 * self.K + 4
+        X = torch.empty(n, D, device=dev)
+        center = torch.empty(n, 2, device=dev)
+        fourth = torch.empty(n, device=dev, dtype=torch.float64)
+        kept = torch.empty(n, device=dev, dtype=torch.uint8)
+        L.call("ss_feature_fuse_stream", lm.data_ptr(), ids_d.data_ptr(), L.ptr(rec), n, self.S, self.K, self.w, self.h, *self.anchors,
+               F._VARIANTS[self.variant], self.band[0], self.band[1], self.prev_lm.data_ptr(), self.has_prev.data_ptr(),
+               X.data_ptr(), D, center.data_ptr(), fourth.data_ptr(), kept.data_ptr(), L.stream())
+        rois = None
+        if self.roi_hw is not None:
+            if frames_bgr is None or tuple(frames_bgr.shape) != (n, self.h, self.w, 3) or frames_bgr.dtype != torch.uint8:
+                raise ValueError(f"frames_bgr must be uint8 ({n}, {self.h}, {self.w}, 3)")
+            boxes = F.crop_boxes(center, fourth, self.w, self.h, self.variant)
+            rois = F.crop_rois(frames_bgr.to(dev), boxes, self.roi_hw, self.variant)
+        return kept.cpu().numpy().astype(bool), X, rois
 
 
 class StreamServer:
@@ -54,6 +124,7 @@ class StreamServer:
         self.frames_seen = torch.zeros(n_streams, device=dev, dtype=torch.int32)
         self.ema = torch.zeros(n_streams, device=dev, dtype=torch.float64)  # a Python float in the reference
         self.mouth_open = torch.zeros(n_streams, device=dev, dtype=torch.uint8)
+        self.front: Optional[LiveFrontEnd] = None  # attach_front_end(): landmarks + camera frames instead of feature rows
         # host mirrors of the two counters decide who is due without reading the device back
         self._count = np.zeros(n_streams, np.int64)
         self._seen = np.zeros(n_streams, np.int64)
@@ -87,6 +158,29 @@ class StreamServer:
         with torch.no_grad():
             logits = self.model(X, T, R if self.model.use_roi else None)
         return due, logits, T
+
+    def attach_front_end(self, idxs: Sequence[int], frame_wh, variant: str = "live", band=(None, None)) -> "LiveFrontEnd":
+        """Landmarks + camera frames in, instead of ready-made feature rows: see ``push_landmarks``."""
+        if 2 * len(idxs) + 4 != self.D:
+            raise ValueError(f"the model takes {self.D} features per frame, {len(idxs)} landmarks give {2 * len(idxs) + 4}")
+        self.front = LiveFrontEnd(self.S, idxs, frame_wh, self.roi_hw, variant, band, self.device)
+        return self.front
+
+    def push_landmarks(self, stream_ids: Sequence[int], lm: torch.Tensor, frames_bgr: Optional[torch.Tensor] = None,
+                       openness: Optional[torch.Tensor] = None):
+        """The live chain as one device entry point (live_infer_official.py:264-296 per stream, then live_feed.py's window rule):
+        distance gate -> feature fuse with per-stream velocity state -> crop box -> gray + resize -> ring push of the KEPT
+        frames -> one forward over the streams that are due.  Returns ``(kept (n,) bool, result)`` with ``result`` as ``push``."""
+        if self.front is None:
+            raise RuntimeError("call attach_front_end(idxs, frame_wh) first")
+        kept, X, rois = self.front(stream_ids, lm, frames_bgr)
+        if not kept.any():
+            return kept, None
+        ids = np.asarray(stream_ids, np.int32)[kept]
+        sel = torch.from_numpy(np.flatnonzero(kept)).to(self.device)
+        op = openness.to(self.device).index_select(0, sel) if openness is not None else None
+        res = self.push(ids, X.index_select(0, sel), rois.index_select(0, sel) if rois is not None else None, op)
+        return kept, res
 
     def windows(self, ids: np.ndarray):
         """Zero-padded windows (oldest frame first) of the given streams: X (n,max_t,D), lengths (n,), R or None."""

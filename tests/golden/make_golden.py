@@ -366,11 +366,107 @@ def gen_loader(live):
     print("wrote loader: top-3 of clip 0", out["l2::top_labels0"], out["l2::top_probs0"])
 
 
+def _functions_of(path, wanted, constants=()):
+    """The named top-level functions (and constants) of a reference script whose MODULE BODY cannot run here
+    (inactive/live_feed.py loads a checkpoint, builds a MediaPipe landmarker and opens the camera at import).  The script is
+    parsed, every top-level statement except imports, the named constant assignments and the named function definitions is
+    dropped, and what is left -- the reference's own, unmodified code objects -- is executed in a fresh namespace with the
+    same empty cv2 / mediapipe placeholders the other imports use.  Nothing of the source is kept: the fixture holds numbers."""
+    import ast
+
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = []
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            keep.append(node)
+        elif isinstance(node, ast.FunctionDef) and node.name in wanted:
+            keep.append(node)
+        elif isinstance(node, ast.Assign) and all(isinstance(t, ast.Name) and t.id in constants for t in node.targets):
+            keep.append(node)
+    tree.body = keep
+    ns = {"__name__": "reference_functions"}
+    exec(compile(tree, path, "exec"), ns)
+    missing = [w for w in list(wanted) + list(constants) if w not in ns]
+    assert not missing, missing
+    return ns
+
+
+def gen_serving():
+    """The serving SIGNALS the reference computes per frame, from its own functions on seeded synthetic faces:
+
+    * ``important_landmarks.dist2d`` (:64-67) on the eye corners and the openness formed exactly as :131-133
+      (``abs(face[MOUTH_BOTTOM].y - face[MOUTH_TOP].y) / (dist2d(...) + 1e-6)``, Python floats);
+    * ``inactive/live_test_5.compute_openness`` (:92-94) and ``face_to_xvec`` (:96-112) over a clip's landmark indices;
+    * ``inactive/live_feed.extract_83_and_openness`` (:57-86) on (478, 2) float32 landmark arrays.
+
+    The EMA / hysteresis / clip-gating / sliding-window LOOPS live inline in the scripts' capture loops and cannot be called:
+    oracle/stream_ref.py restates them (stated there)."""
+    import important_landmarks as il
+    import live_test_5 as lt5
+
+    lf = _functions_of(os.path.join(REF, "inactive", "live_feed.py"), ["extract_83_and_openness"],
+                       ["LOWER_LIPS", "UPPER_LIPS", "LIP_ORDER"])
+    rs = np.random.RandomState(77)
+    n_faces, n_lm = 96, 478
+    lm = rs.uniform(0.2, 0.8, size=(n_faces, n_lm, 2)).astype(np.float32)
+    # a talking mouth: inner lips a small, varying gap apart; eye corners ~0.25 apart; values within a few ulps of each other too
+    gap = rs.uniform(0.0, 0.06, size=n_faces).astype(np.float32)
+    lm[:, il.MOUTH_TOP, 1] = 0.60
+    lm[:, il.MOUTH_BOTTOM, 1] = (np.float32(0.60) + gap).astype(np.float32)
+    lm[:, il.LEFT_EYE_CORNER] = (np.array([0.38, 0.40], np.float32) + rs.normal(0, 0.01, (n_faces, 2))).astype(np.float32)
+    lm[:, il.RIGHT_EYE_CORNER] = (np.array([0.63, 0.41], np.float32) + rs.normal(0, 0.01, (n_faces, 2))).astype(np.float32)
+    lm[0, il.MOUTH_BOTTOM, 1] = lm[0, il.MOUTH_TOP, 1]            # closed mouth: openness 0
+    lm[1, il.RIGHT_EYE_CORNER] = lm[1, il.LEFT_EYE_CORNER]        # degenerate span: the 1e-6 carries the division
+    lm[2, il.MOUTH_BOTTOM, 1] = np.nextafter(lm[2, il.MOUTH_TOP, 1], np.float32(1))  # one float32 ulp of gap
+    lm[3, 291] = lm[3, 61]                                        # live_feed: zero mouth width -> 1e-6
+
+    class P:  # a landmark as MediaPipe hands it over: attributes x, y holding Python floats
+        __slots__ = ("x", "y")
+
+        def __init__(self, x, y):
+            self.x, self.y = float(x), float(y)
+
+    idxs = [int(i) for i in lt5_landmark_idxs()]
+    out = dict(lm=lm, idxs=np.asarray(idxs, np.int32), mouth_top=il.MOUTH_TOP, mouth_bottom=il.MOUTH_BOTTOM,
+               eye_l=il.LEFT_EYE_CORNER, eye_r=il.RIGHT_EYE_CORNER, lip_order=np.asarray(lf["LIP_ORDER"], np.int32))
+    eye_span, open_eye, open_yr, xv41, xv40, f83, open83 = [], [], [], [], [], [], []
+    for f in range(n_faces):
+        face = [P(x, y) for x, y in lm[f]]
+        d = il.dist2d(face[il.LEFT_EYE_CORNER], face[il.RIGHT_EYE_CORNER])
+        eye_span.append(d)
+        lip_gap = abs(face[il.MOUTH_BOTTOM].y - face[il.MOUTH_TOP].y)   # important_landmarks.py:131
+        open_eye.append(lip_gap / (d + 1e-6))                           # :132-133
+        open_yr.append(lt5.compute_openness(face, idxs))
+        xv41.append(lt5.face_to_xvec(face, idxs, 2 * len(idxs) + 1))
+        xv40.append(lt5.face_to_xvec(face, idxs, 2 * len(idxs)))
+        a, b = lf["extract_83_and_openness"](lm[f])
+        f83.append(a)
+        open83.append(b)
+    out.update(eye_span=np.asarray(eye_span, np.float64), openness_eye=np.asarray(open_eye, np.float64),
+               openness_yrange=np.asarray(open_yr, np.float64), xvec_with_open=np.stack(xv41), xvec=np.stack(xv40),
+               feat83=np.stack(f83), openness83=np.asarray(open83, np.float64))
+    assert out["feat83"].dtype == np.float32 and out["xvec"].dtype == np.float32
+    np.savez_compressed(os.path.join(HERE, "serving.npz"), **out)
+    print("wrote serving: openness_eye[:4]", out["openness_eye"][:4], "openness83[:4]", out["openness83"][:4])
+
+
+def lt5_landmark_idxs():
+    """inactive/live_test_5.py reads its landmark indices from a recorded clip's ``idxs`` (:78-84); the synthetic clip here uses
+    the 40 lip landmarks of the official recorder (record_landmarks_official.py:30-44 order does not matter to either function)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), ".."))
+    from silent_speech_amd.features import LIP_IDXS_40
+
+    return LIP_IDXS_40
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
     tmo, rec, live, tred = import_reference()
     only = set(sys.argv[1:])  # python make_golden.py [case names]: regenerate only those model cases
+    if only == {"serving"}:
+        gen_serving()
+        return
     for i, case in enumerate(MODEL_CASES):
         if not only or case[0] in only:
             gen_model_case(tmo, live, *case, seed=100 + i)
@@ -382,6 +478,7 @@ def main():
     gen_dataset(tmo)
     gen_harness(tmo)
     gen_loader(live)
+    gen_serving()
 
 
 if __name__ == "__main__":

@@ -445,12 +445,16 @@ def test_full_size_properties(ss):
         b = m(Xd[perm.cuda()], Lh[perm], Rd[perm.cuda()])
         sub = m(Xd[:160].contiguous(), Lh[:160], Rd[:160].contiguous())
         sub16 = m(Xd[:16].contiguous(), Lh[:16], Rd[:16].contiguous())
+        sub64 = m(Xd[:64].contiguous(), Lh[:64], Rd[:64].contiguous())
+        sub128 = m(Xd[:128].contiguous(), Lh[:128], Rd[:128].contiguous())
     assert torch.isfinite(a).all()
     assert torch.equal(a[perm.cuda()], b)
     assert torch.equal(a[:160], sub), "a clip's logits depend on the batch size"
     # up to 128 clips the forward recurrence runs over twelve parts instead of six (gru_split_fwd_parts): its contraction is cut
     # into four k slices instead of two, so the sums associate differently -- the last bits of h, not more
     assert float((a[:16] - sub16).abs().max()) < 2e-5, "a small batch's logits drift from the large batch's"
+    # ... and INSIDE each regime the bits do not depend on the batch size ("Batch size and the last bits")
+    assert torch.equal(sub64[:16], sub16) and torch.equal(sub128[:64], sub64), "logits differ between two batches of <= 128 clips"
     # training decreases the loss on a fixed batch, and stays finite
     tr = ss.Trainer(m, dropout=True)
     m.train()
@@ -605,6 +609,94 @@ def test_stream_server_matches_the_restated_loop(ss):
     assert n_pred > 40
 
 
+def test_live_chain_one_entry_point_band_leave_and_reentry(ss):
+    """landmarks + camera frames in, windows + logits out, as ONE device entry point
+    (``StreamServer.push_landmarks`` = live_infer_official.py:264-296 per stream: width gate -> extract_feature with the stream's
+    ``prev_xy`` -> crop_roi_gray -> buffers; then the sliding-window rule).  The trace leaves the 60-150 px band and comes back:
+    frames outside are not appended, ``prev_xy`` is cleared (:295-296) so the first frame after re-entry has velocity exactly 0,
+    and the windows equal the per-stream Python restatement (features to the feature kernel's tolerance, ROI bytes bit for bit)."""
+    from oracle import features_ref as FR
+    from oracle import resize_ref as RR
+    from oracle import stream_ref as SR
+    from silent_speech_amd import features as Fm
+
+    rng = np.random.default_rng(11)
+    idxs = Fm.FIXED_IDXS_88
+    K, Dm = len(idxs), 2 * len(idxs) + 4
+    S, max_t, hw, w, h = 5, 10, (16, 32), 320, 240
+    anchors = Fm.anchor_positions(idxs)
+    sd = W.make_state_dict(5, Dm, 10, True)
+    m = ss.BiGRUClassifier(Dm, 10, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    srv = ss.StreamServer(m, S, max_t, roi_hw=hw)
+    srv.attach_front_end(idxs, (w, h), variant="live")
+    with pytest.raises(ValueError):
+        ss.StreamServer(m, S, max_t, roi_hw=hw).attach_front_end(idxs[:40], (w, h))
+    refs = [SR.StreamRef(max_t, Dm, hw) for _ in range(S)]
+    prev = [None] * S
+    base = rng.uniform(0.35, 0.65, (S, K, 2)).astype(np.float32)
+
+    def width_of(s, tick):  # mouth width in pixels the synthetic face is given
+        if s == 1 and 8 <= tick < 12:
+            return 30.0       # too far away: leaves the band for four ticks, then re-enters
+        if s == 2 and tick % 7 == 3:
+            return 190.0      # too close, single frames
+        if s == 4 and tick < 5:
+            return 20.0       # starts outside
+        if s == 3:
+            return (60.0, 150.0, 59.99, 150.01)[tick % 4]  # on and just off the band's edges
+        return 95.0 + 20.0 * np.sin(0.3 * tick + s)
+
+    n_pred, reentry_checked, dropped = 0, 0, 0
+    for tick in range(26):
+        ids = np.flatnonzero(rng.random(S) < 0.9)
+        if len(ids) == 0:
+            continue
+        lm = (base[ids] + rng.normal(0, 0.003, (len(ids), K, 2))).astype(np.float32)
+        for k, s in enumerate(ids):
+            half = np.float32(width_of(int(s), tick) / w / 2)
+            lm[k, anchors[0]] = [np.float32(0.5) - half, 0.55]
+            lm[k, anchors[1]] = [np.float32(0.5) + half, 0.55]
+        frames = rng.integers(0, 256, (len(ids), h, w, 3), dtype=np.uint8)
+        kept, got = srv.push_landmarks(ids, torch.from_numpy(lm).cuda(), torch.from_numpy(frames).cuda())
+        want = {}
+        for k, s in enumerate(ids):
+            s = int(s)
+            mw = FR.mouth_width_px(lm[k, anchors[0]], lm[k, anchors[1]], w, h, "live")
+            in_range = Fm.MOUTH_W_MIN_PX <= mw <= Fm.MOUTH_W_MAX_PX
+            assert bool(kept[k]) == in_range, (tick, s, mw)
+            if not in_range:
+                prev[s] = None
+                dropped += 1
+                continue
+            was_reset = prev[s] is None
+            feat, prev[s], c, fourth = FR.extract_feature(lm[k], w, h, *anchors, prev_xy=prev[s], variant="live")
+            if was_reset:
+                assert feat[2 * K] == 0.0
+                reentry_checked += 1
+            roi = RR.crop_gray_resize(frames[k], FR.crop_box(c, fourth, w, h, "live"), hw[0], hw[1], "area")
+            want[s] = refs[s].push(feat, roi)
+        due = [s for s, wv in want.items() if wv is not None]
+        if not due:
+            assert got is None
+            continue
+        g_ids, logits, T = got
+        assert g_ids.tolist() == due
+        X, T2, R = srv.windows(np.asarray(due))
+        for k, s in enumerate(due):
+            assert int(T[k]) == want[s]["T"] == int(T2[k])
+            xg, xw = X[k].cpu().numpy(), want[s]["X"]
+            np.testing.assert_allclose(xg[:, : 2 * K], xw[:, : 2 * K], rtol=0, atol=1.2e-7)
+            np.testing.assert_allclose(xg[:, 2 * K:], xw[:, 2 * K:], rtol=1e-6, atol=1e-7)
+            assert np.array_equal(xg[:, 2 * K] == 0.0, xw[:, 2 * K] == 0.0)  # the reset frames: velocity exactly 0 in both
+            assert np.array_equal(R[k].cpu().numpy(), want[s]["R"])
+        ref = MR.forward(sd, X.cpu(), T.cpu(), R.cpu(), impl="aten")
+        assert float((logits.cpu() - ref).abs().max()) < TIGHT
+        n_pred += len(due)
+    assert n_pred > 20 and reentry_checked >= S + 3 and dropped > 10
+
+
 def test_mouth_gate_is_float64_near_the_thresholds(ss):
     """the reference's ``mouth_ema`` is a Python float.  Traces built to land the EMA within a few
     float64 ulps of the thresholds -- where a float32 EMA flips the other way -- must give the restated loop's states."""
@@ -655,6 +747,26 @@ def test_mouth_openness_kernel(ss):
     sub = np.ascontiguousarray(lm[:, idx])
     got2 = mouth_openness(torch.from_numpy(sub).cuda(), "y_range").cpu().numpy()
     assert np.array_equal(got2, np.asarray([SR.openness_y_range(sub[i]) for i in range(n)]))
+
+
+def test_mouth_openness_against_the_reference_functions(ss, golden_dir):
+    """The three openness signals on the faces of tests/golden/serving.npz, whose expected values the REFERENCE's own functions
+    returned (important_landmarks.dist2d + :131-133, inactive/live_test_5.compute_openness, inactive/live_feed.
+    extract_83_and_openness): y-range and width-normalised forms bit for bit, the eye-span form to one ulp of a double (the
+    reference's ``** 0.5`` is libm pow, the kernel takes the correctly rounded root)."""
+    import os
+
+    from silent_speech_amd.serving import mouth_openness
+
+    d = np.load(os.path.join(golden_dir, "serving.npz"))
+    lm = torch.from_numpy(d["lm"]).cuda()
+    got = mouth_openness(lm, "eye_span", (int(d["mouth_top"]), int(d["mouth_bottom"]), int(d["eye_l"]), int(d["eye_r"]))).cpu().numpy()
+    want = d["openness_eye"]
+    assert np.all(np.abs(got - want) <= 2.3e-16 * np.abs(want)) and (got == want).mean() > 0.95
+    assert got[0] == 0.0
+    sub = lm[:, torch.from_numpy(d["idxs"].astype(np.int64)).cuda()].contiguous()
+    assert np.array_equal(mouth_openness(sub, "y_range").cpu().numpy(), d["openness_yrange"])
+    assert np.array_equal(mouth_openness(lm, "width_norm", (13, 14, 61, 291)).cpu().numpy(), d["openness83"])
 
 
 def test_clip_gate_server_matches_the_restated_state_machine(ss):
