@@ -140,12 +140,21 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
   float bw2[18];  // conv2: k-step kk -> tap = kk/2, c = 4*(kk%2)+g ; n = i
 #pragma unroll
   for (int kk = 0; kk < 18; ++kk) bw2[kk] = w2s[i * 72 + (4 * (kk & 1) + g) * 9 + (kk >> 1)];
-  float bw3a[36], bw3b[36];  // conv3: tap = kk/4, c = 4*(kk%4)+g ; n = i and 16+i
+  // conv3: 24 output channels on 16-wide tiles.  Channels 0..15 fill one tile (k-step kk: tap = kk/4, c = 4*(kk%4)+g; n = i).
+  // Channels 16..23 would waste half of a second one (round 3: 25 % of conv3's MFMAs multiplied zero columns), so they share a
+  // tile between the pixel rows y and y+1 -- column i = (channel 16 + (i&7), row y + (i>>3)) -- over the 4 x 3 window both rows
+  // touch, conv1's trick: K = 4 rows x 3 columns x 16 channels = 192 with zero weights where a row lies outside its 3 x 3
+  // kernel.  120 MFMAs per 32 pixels instead of 144, and the 48 A values feed all three accumulators.
+  float bw3a[36], bw3b[48];
 #pragma unroll
   for (int kk = 0; kk < 36; ++kk) {
     const int c = 4 * (kk & 3) + g, tap = kk >> 2;
     bw3a[kk] = w3s[i * 144 + c * 9 + tap];
-    bw3b[kk] = (i < 8) ? w3s[(16 + i) * 144 + c * 9 + tap] : 0.f;
+  }
+#pragma unroll
+  for (int kk = 0; kk < 48; ++kk) {  // kk = (ry * 3 + kx) * 4 + cg
+    const int c = 4 * (kk & 3) + g, ry = (kk >> 2) / 3, kx = (kk >> 2) % 3, ky = ry - (i >> 3);
+    bw3b[kk] = (ky >= 0 && ky <= 2) ? w3s[(16 + (i & 7)) * 144 + c * 9 + ky * 3 + kx] : 0.f;
   }
   __syncthreads();
   for (int q = tid; q < LL::total; q += NT) lds[q] = 0.f;
@@ -417,60 +426,64 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
     }
     STAMP(3);
 
-    // ---------------- stage 3: conv3 (MFMA) + ReLU + global average
+    // ---------------- stage 3: conv3 (MFMA) + ReLU + global average.  A unit = 16 pixels of an even row y (linear over the even
+    // rows) and their neighbours in row y + 1: accumulators a0 / a1 = channels 0..15 of the two rows, ab = channels 16..23 of both.
     {
-      constexpr int tiles = P / 16;
-      float fa = 0.f, fb = 0.f;  // per-lane partial channel sums (tile 0: n=i, tile 1: n=16+i)
+      constexpr int units = P / 32;
+      float fa = 0.f, fb = 0.f;  // per-lane partial channel sums (a: channel i; b: channel 16 + (i&7), row y + (i>>3))
       float ca = 0.f, cb = 0.f;  // and counts of positive outputs
-      const float bias_a = s_b3[i], bias_b = (i < 8) ? s_b3[16 + i] : 0.f;
+      const int c8 = i & 7, sB = i >> 3;
+      const float bias_a = s_b3[i], bias_b = s_b3[16 + c8];
       __builtin_amdgcn_s_setprio(2);
-      for (int u = wv; u < tiles; u += NWV) {
-        const int pa = 16 * u + i;
-        const float* base = a2 + g * P2 + (pa / W4) * S2 + (pa % W4);
-        f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = acca;
+      for (int u = wv; u < units; u += NWV) {
+        const int qa = 16 * u + i;  // this lane's A row: pixel (2 (qa / W4), qa % W4)
+        const float* base = a2 + g * P2 + (2 * (qa / W4)) * S2 + (qa % W4);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, accb = acc0;
 #pragma unroll
-        for (int kb = 0; kb < 36; kb += 9) {
-          float av[9];
+        for (int kx = 0; kx < 3; ++kx) {
+          float av[4][4];  // [ry][cg]
 #pragma unroll
-          for (int u = 0; u < 9; ++u) {
-            const int kk = kb + u, tap = kk >> 2, ky = tap / 3, kx = tap % 3;
-            av[u] = base[4 * (kk & 3) * P2 + ky * S2 + kx];
-          }
+          for (int ry = 0; ry < 4; ++ry)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) av[ry][cg] = base[4 * cg * P2 + ry * S2 + kx];
           SS_SCHED_FENCE();
 #pragma unroll
-          for (int u = 0; u < 9; ++u) {
-            acca = mfma16(av[u], bw3a[kb + u], acca);
-            accb = mfma16(av[u], bw3b[kb + u], accb);
-          }
+          for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+            for (int ry = 0; ry < 4; ++ry) {
+              if (ry < 3) acc0 = mfma16(av[ry][cg], bw3a[(ry * 3 + kx) * 4 + cg], acc0);
+              if (ry > 0) acc1 = mfma16(av[ry][cg], bw3a[((ry - 1) * 3 + kx) * 4 + cg], acc1);
+              accb = mfma16(av[ry][cg], bw3b[(ry * 3 + kx) * 4 + cg], accb);
+            }
           SS_SCHED_FENCE();
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float va = acca[r] + bias_a, vb = accb[r] + bias_b;
-          const bool pa = va > 0.f, pb = vb > 0.f;
-          fa += fmaxf(va, 0.f);  // (one v_max + v_add instead of compare, select, add)
+          const float v0 = acc0[r] + bias_a, v1 = acc1[r] + bias_a, vb = accb[r] + bias_b;
+          const bool p0 = v0 > 0.f, p1 = v1 > 0.f, pb = vb > 0.f;
+          fa += fmaxf(v0, 0.f) + fmaxf(v1, 0.f);  // (one v_max + v_add instead of compare, select, add)
           fb += fmaxf(vb, 0.f);
-          ca += pa ? 1.f : 0.f;
+          ca += (p0 ? 1.f : 0.f) + (p1 ? 1.f : 0.f);
           cb += pb ? 1.f : 0.f;
-          if (stash) {  // D row 4g+r = pixel, column i = channel: pixel-major bytes
-            uint8_t* mp = m3s + (16 * u + 4 * g + r) * 32;
-            mp[i] = pa;
-            if (i < 8) {
-              mp[16 + i] = pb;
-              mp[24 + i] = 0;
-            }
+          if (stash) {  // D row 4g+r = pixel, column i = channel: pixel-major bytes, 32 per pixel (24..31 zero)
+            const int qd = 16 * u + 4 * g + r;
+            uint8_t* mp = m3s + ((2 * (qd / W4)) * W4 + qd % W4) * 32;
+            mp[i] = p0;
+            mp[W4 * 32 + i] = p1;
+            mp[sB * W4 * 32 + 16 + c8] = pb;
+            mp[sB * W4 * 32 + 24 + c8] = 0;
           }
         }
       }
       __builtin_amdgcn_s_setprio(0);
-      // reduce over the 4 lane groups (rows of the tiles), then over waves through LDS
+      // reduce over the 4 lane groups (rows of the tiles), the two rows of the shared tile, then over waves through LDS
       fa += __shfl_xor(fa, 16, 64); fa += __shfl_xor(fa, 32, 64);
-      fb += __shfl_xor(fb, 16, 64); fb += __shfl_xor(fb, 32, 64);
+      fb += __shfl_xor(fb, 16, 64); fb += __shfl_xor(fb, 32, 64); fb += __shfl_xor(fb, 8, 64);
       ca += __shfl_xor(ca, 16, 64); ca += __shfl_xor(ca, 32, 64);
-      cb += __shfl_xor(cb, 16, 64); cb += __shfl_xor(cb, 32, 64);
+      cb += __shfl_xor(cb, 16, 64); cb += __shfl_xor(cb, 32, 64); cb += __shfl_xor(cb, 8, 64);
       if (g == 0) {
-        s_fp[wv * 32 + i] = fa; s_fp[wv * 32 + 16 + i] = fb;
-        s_cp[wv * 32 + i] = ca; s_cp[wv * 32 + 16 + i] = cb;
+        s_fp[wv * 32 + i] = fa; s_cp[wv * 32 + i] = ca;
+        s_fp[wv * 32 + 16 + i] = i < 8 ? fb : 0.f; s_cp[wv * 32 + 16 + i] = i < 8 ? cb : 0.f;
       }
     }
     __syncthreads();

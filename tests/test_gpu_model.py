@@ -122,6 +122,11 @@ def test_autograd_grads_match_oracle_and_golden(ss, golden_dir, name):
     for k, p in m.named_parameters():
         ref = grads[k]
         got = p.grad.cpu()
+        if k == "pool.score.bias":
+            # softmax is shift-invariant: the true gradient is exactly 0 and both sides hold rounding noise of the sum over the
+            # attention weights (~1e-8; its size moves with the summation order of the kernels in front)
+            assert float(got.abs().max()) < 1e-6 and float(ref.abs().max()) < 1e-6
+            continue
         scale = max(float(ref.abs().max()), 1e-4)
         bad = (got - ref).abs() > 2e-4 * scale + 2e-3 * ref.abs()
         assert not bad.any(), f"{k}: max err {float((got - ref).abs().max()):.3e} vs scale {scale:.3e}"
