@@ -55,7 +55,7 @@ __device__ __forceinline__ FrameNorm frame_norm(const float* __restrict__ pts, i
   } else {
     const float dx = __fsub_rn(__fmul_rn(lx, fw), __fmul_rn(rx, fw));
     const float dy = __fsub_rn(__fmul_rn(ly, fh), __fmul_rn(ry, fh));
-    r.mw = (double)__fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    r.mw = (double)ss_sqrt_rn_f32(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
   }
   r.scale32 = (float)__dadd_rn(r.mw, 1e-6);
   return r;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(FF_WAVES * 64) void feature_fuse_kernel(FeatParams 
       const float qx = __fdiv_rn(__fsub_rn(__fmul_rn(prv[wv][2 * k], fw), pr.cx), pr.scale32);
       const float qy = __fdiv_rn(__fsub_rn(__fmul_rn(prv[wv][2 * k + 1], fh), pr.cy), pr.scale32);
       const float dx = nx - qx, dy = ny - qy;
-      vsum += __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+      vsum += ss_sqrt_rn_f32(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
     }
   }
   vsum = wave_sum(vsum);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(FF_WAVES * 64) void feature_fuse_kernel(FeatParams 
     const float ux = __fmul_rn(cur[wv][2 * p.a_up], fw), uy = __fmul_rn(cur[wv][2 * p.a_up + 1], fh);
     const float lx = __fmul_rn(cur[wv][2 * p.a_lo], fw), ly = __fmul_rn(cur[wv][2 * p.a_lo + 1], fh);
     const float dx = __fsub_rn(ux, lx), dy = __fsub_rn(uy, ly);
-    const float open_px = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    const float open_px = ss_sqrt_rn_f32(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
     const double aspect = (double)open_px / __dadd_rn(c.mw, 1e-6);
     xr[2 * K] = has_prev ? vsum / (float)K : 0.f;
     xr[2 * K + 1] = open_px;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(FF_WAVES * 64) void feature_fuse_stream_kernel(Feat
       const float qx = __fdiv_rn(__fsub_rn(__fmul_rn(prv[wv][2 * k], fw), pr.cx), pr.scale32);
       const float qy = __fdiv_rn(__fsub_rn(__fmul_rn(prv[wv][2 * k + 1], fh), pr.cy), pr.scale32);
       const float dx = nx - qx, dy = ny - qy;
-      vsum += __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+      vsum += ss_sqrt_rn_f32(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
     }
     pdst[2 * k] = cur[wv][2 * k];  // this frame becomes the stream's previous kept frame
     pdst[2 * k + 1] = cur[wv][2 * k + 1];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(FF_WAVES * 64) void feature_fuse_stream_kernel(Feat
     const float ux = __fmul_rn(cur[wv][2 * p.a_up], fw), uy = __fmul_rn(cur[wv][2 * p.a_up + 1], fh);
     const float lx = __fmul_rn(cur[wv][2 * p.a_lo], fw), ly = __fmul_rn(cur[wv][2 * p.a_lo + 1], fh);
     const float dx = __fsub_rn(ux, lx), dy = __fsub_rn(uy, ly);
-    const float open_px = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    const float open_px = ss_sqrt_rn_f32(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
     const double aspect = (double)open_px / __dadd_rn(c.mw, 1e-6);
     xr[2 * K] = has_prev ? vsum / (float)K : 0.f;
     xr[2 * K + 1] = open_px;

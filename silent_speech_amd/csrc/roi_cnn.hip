@@ -58,7 +58,7 @@ struct CnnFwdParams {
   int ld_out;
   // training stash (all null together)
   float* st_a1;     // [N][8][P1]  haloed LDS image of the pooled-1 map, as is
-  uint8_t* st_i1;   // [N][8][I1S] (plane stride Geom::I1S = H2*W2 bytes)
+  uint8_t* st_i1;   // [N][8][I1S] (plane stride Geom::I1S = H2*W2 + 16 bytes)
   float* st_a2;     // [N][16][P2] haloed LDS image of the pooled-2 map, as is
   uint8_t* st_i2;   // [N][H4][W4][16]  pixel-major: the backward pass consumes it next to its pixel-major da2
   uint8_t* st_m3;   // [N][P][32]  pixel-major, channels 24..31 unused: the backward turns 16 bytes into 16 floats of one pixel
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
   if (tid < 16) s_b2[tid] = p.b2[tid];
   if (tid < 24) s_b3[tid] = p.b3[tid];
 
+  const float level_f = (float)(tid & 255) / 255.0f;  // fl(u / 255) of this thread's grey level: the same for every frame
   uint4 px[NCH];
   auto load_frame = [&](int n) {
 #pragma unroll
@@ -186,15 +187,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
     for (int k = 0; k < NCH; ++k) {
       const int q = tid + k * NT;
       if (q * 16 < HW) {
+        // four pixels per instruction: v_dot4_u32_u8 (exact integer sums; a 64x64 frame's sum of squares is < 2^29)
         const unsigned wds[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const unsigned u = (wds[e] >> (8 * b)) & 255u;
-            su += u;
-            sq += u * u;
-          }
+        for (int e = 0; e < 4; ++e) {
+          su = __builtin_amdgcn_udot4(wds[e], 0x01010101u, su, false);
+          sq = __builtin_amdgcn_udot4(wds[e], wds[e], sq, false);
+        }
       }
     }
     su = wave_sum_u32(su);
@@ -206,11 +205,16 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
       for (int k = 0; k < NWV; ++k) { tsu += s_red[2 * k]; tsq += s_red[2 * k + 1]; }
       float mu = 0.f, sd = 1.f;
       if (p.standardize) {
-        const double nn = (double)HW;
-        // mean of u/255: for a constant frame this reproduces fl(u/255) exactly, so xn == 0
-        mu = (float)((double)tsu / nn) / 255.0f;
-        double var = ((double)tsq - (double)tsu * (double)tsu / nn) / (nn - 1.0);
-        sd = (float)(sqrt(var > 0.0 ? var : 0.0) / 255.0);
+        // exact integer sums -> mean and unbiased variance in double.  Products with the reciprocals of the (compile-time) pixel
+        // counts instead of f64 divides, one f32 root instead of an f64 one: the serial section every other wave of the
+        // workgroup waits for was 133 vector instructions, and its result is rounded to f32 anyway (the reference computes
+        // mean and std in f32 altogether).  For a constant frame mu == fl(u / 255) still holds exactly -- tsu / HW is u to
+        // within 1e-16, so the f32 rounding returns u -- and xn == 0.
+        constexpr double inv_n = 1.0 / (double)HW, inv_n1 = 1.0 / ((double)HW - 1.0);
+        const double mean_u = (double)tsu * inv_n;
+        mu = (float)mean_u / 255.0f;
+        const double var = ((double)tsq - (double)tsu * mean_u) * inv_n1;
+        sd = sqrtf((float)(var > 0.0 ? var : 0.0)) / 255.0f;
         sd = fmaxf(sd, 1e-6f);
       }
       s_stat[0] = mu;
@@ -221,10 +225,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
       }
     }
     __syncthreads();
-    if (tid < 256) {  // xn = (u/255 - mu)/sd once per grey level; pixels then look their value up
-      const float rr = (float)tid / 255.0f;
-      s_xn[tid] = p.standardize ? (rr - s_stat[0]) / s_stat[1] : rr;
-    }
+    if (tid < 256) s_xn[tid] = p.standardize ? (level_f - s_stat[0]) / s_stat[1] : level_f;  // one IEEE divide per grey level
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {

@@ -67,15 +67,17 @@ struct BwdLds {
   static constexpr int XSB = G::XS + (8 - G::XS % 32 + 32) % 32;
   static constexpr int XHN = (G::H + 2) * XSB;
   static constexpr int o_i1b = (o_xh + XHN + 3) & ~3;
-  // pool-1 argmax planes in LDS, one bank apart: S5 reads one byte per channel plane and the stash's plane stride (H2*W2
-  // bytes, a multiple of 128) would put all eight on the same bank
-  static constexpr int I1SB = G::I1S + 4;
+  // pool-1 argmax planes in LDS as they lie in the stash (plane stride H2*W2 + 16 bytes: four banks apart -- S5 reads one byte
+  // per channel plane): the image arrives by linear LDS-DMA under S1, into a part of the phase-2 area that phase 1 never touches
+  static constexpr int I1SB = G::I1S;
+  static_assert(I1SB % 16 == 0, "argmax planes are moved in 16-byte pieces");
   static constexpr int end2 = (o_i1b + 2 * I1SB + 3) & ~3;
   // W3 (13.8 KB) stays resident behind the phase area when the CU's 160 KB allow it; otherwise it lives in the
   // phase-1 part and is re-staged from L2 every frame
   static constexpr int fixed = 192 * 16 + 512;             // w2t + misc
   static constexpr bool W3_RESIDENT = ((end1a > end2 ? end1a : end2) + 3456 + fixed) * 4 <= 160 * 1024;
   static constexpr int end1 = W3_RESIDENT ? end1a : end1a + 3456;
+  static_assert(o_i1b >= end1, "the pool-1 argmax image is filled while phase 1 is live");
   static constexpr int ph_end = end1 > end2 ? end1 : end2;
   static constexpr int o_w3s = W3_RESIDENT ? ph_end : end1a;
   static constexpr int o_w2t = W3_RESIDENT ? ph_end + 3456 : ph_end;
@@ -165,9 +167,13 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, W2H = LL::W2H;
   constexpr int NCH = (HW / 8 + NT - 1) / NT;     // 8-byte pixel chunks per thread (every thread of a 64x64 frame has one)
   constexpr int I1S = G::I1S;
+  // The pool-1 argmax image (8 planes as they lie in the stash) reaches LDS either by LDS-DMA under S1 (shapes that are short of
+  // registers: 48 x 96 spilled 43 VGPRs with the bytes held in registers through S2, 24 without) or through registers, fetched in
+  // front of S2 and stored inside S3 (64 x 64: measured 682 against 693 us per launch for the DMA form, A/B on one box)
+  constexpr bool I1_BY_DMA = !LL::W3_RESIDENT;
+  constexpr int NI1 = I1_BY_DMA ? 1 : (I1S / 2 + NT - 1) / NT;  // 16-byte pool-1 argmax chunks per thread
   constexpr int DS = LL::DS;
   static_assert(DS == DY3_STRIDE && DS % 4 == 0 && DS >= 24, "dy3 pixel stride");
-  constexpr int NI1 = (I1S / 2 + NT - 1) / NT;    // 16-byte pool-1 argmax chunks per thread
   float* a1h = lds + LL::o_a1h;
   float* a2h = lds + LL::o_ph;
   float* dy3h = lds + LL::o_dy3h;
@@ -175,7 +181,6 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   float* w3s = lds + LL::o_w3s;
   float* dy2 = lds + LL::o_ph;
   float* xh = lds + LL::o_xh;
-  uint8_t* i1b = reinterpret_cast<uint8_t*>(lds + LL::o_i1b);
   float* w2t = lds + LL::o_w2t;
   float* misc = lds + LL::o_misc;
   float* s_dout = misc;          // [64]
@@ -215,6 +220,30 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     }
   };
   if (LL::W3_RESIDENT) stage_w3();
+  // Shapes whose LDS image has no room to keep W3 (48 x 96: the slot lies under phase 2's normalised frame) re-stage it every
+  // frame.  Round 3 did that with plain loads at the frame top -- seven dependent 4-byte L2 gathers per thread with every wave
+  // waiting: 3.6 k of the frame's 78.8 k cycles (profiles/round3_f_stamp_64x64_vs_48x96.txt).  Now the same gather goes by
+  // LDS-DMA with per-lane source addresses (global_load_lds_dword: lane l's word lands at base + 4 l, i.e. w3s[64 piece + l]),
+  // issued at the frame top and landing under S1, which does not read W3; the wait sits in front of the barrier that ends S1.
+  auto stage_w3_dma = [&]() {
+    static_assert(3456 % 64 == 0, "whole wave pieces");
+    for (int piece = wvu; piece < 3456 / 64; piece += NWV) {
+      const int q = piece * 64 + lane;
+      int nn, c, tap;
+      if (q < 2304) {
+        const int e = q & 3, r = q >> 2;
+        c = r & 15;
+        nn = 4 * ((r >> 4) & 3) + e;
+        tap = r >> 6;
+      } else {
+        const int q2 = q - 2304, e = q2 & 1, r = q2 >> 1;
+        c = r & 15;
+        nn = 16 + 2 * ((r >> 4) & 3) + e;
+        tap = r >> 6;
+      }
+      ss_dma4(p.w3 + nn * 144 + c * 9 + tap, (unsigned)((LL::o_w3s + piece * 64) * 4));
+    }
+  };
   // S4's B operand: k = (t*3+kx)*16 + n, column j = (c, s): W2[n][c][ky = s+2-t][kx], zero outside the 3x3 window.
   // Stored [tap tk][g][column j][e] with n = 4g + e: lane (j, g) takes its four k-steps of a tap in ONE ds_read_b128
   // (MFMA slot (e, g) carries n = 4g + e for both operands).
@@ -270,12 +299,20 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   // earlier, inside S3 (its inputs are requested in S1).  The two waves of a SIMD then run their fronts at DIFFERENT passes of S5, one
   // wave's vector / LDS work under the other's MFMAs (tools/microbench/mfma_valu: a wave's v_fma stream does not slow the
   // partner's MFMAs at all); with barriers in it the front costs its full length wherever it is put.
-  constexpr bool FAST = (2 * P == NT) && ((P / NWV) % W4 == 0);
+  // Round 4: any shape whose waves own whole rows of the pooled-2 grid -- wave w rows [w H4 / NWV, (w + 1) H4 / NWV), one or
+  // two mask items per lane (48 x 96: 12 rows over 8 waves, 48 or 96 items per wave) -- as long as a wave's mask bytes (32 per
+  // pixel) fit into the cells of its first row (96 bytes per pixel): up to three rows per wave.  The 48 x 96 frames of the
+  // reference ran the generic form (two workgroup barriers inside S5, the front at full length: S5 15.2 k cycles against 8.1 k).
+  constexpr int H4 = G::H4;
+  constexpr int RPW_MAX = (H4 + NWV - 1) / NWV;          // rows a wave owns at most
+  constexpr int NM3F = (RPW_MAX * 2 * W4 + 63) / 64;      // mask items per lane at most
+  constexpr bool FAST = H4 >= NWV && RPW_MAX <= 3 && 2 * W4 <= 64;
+  const int own_r0 = (wvu * H4) / NWV, own_r1 = ((wvu + 1) * H4) / NWV;  // this wave's rows of the pooled-2 grid
+  const int own_items = (own_r1 - own_r0) * 2 * W4;
   auto m3_own_dst = [&]() {  // float offset of this wave's first interior pixel in the dy3 image
-    const int pix0 = (P / NWV) * wvu;
-    return LL::o_dy3h + ((pix0 / W4 + 1) * S2 + pix0 % W4 + 1) * DS;
+    return LL::o_dy3h + ((own_r0 + 1) * S2 + 1) * DS;
   };
-  static_assert(!FAST || W4 * DS >= 256, "a wave's mask piece stays inside its first row");
+  static_assert(!FAST || RPW_MAX * 2 * W4 * 16 <= W4 * DS * 4, "a wave's mask piece stays inside its first row");
   auto misc_dma = [&](int nf) {  // d_out row, averaged features, counts, mean / std: one wave, four tiny DMAs
     if (wvu == NWV - 1) {
       if (lane < E) ss_dma4(p.d_out + (long)nf * p.ld_dout + lane, (unsigned)((LL::o_misc) * 4));
@@ -293,7 +330,12 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     const char* pxsrc = reinterpret_cast<const char*>(p.R + (long)nf * HW);
     const char* m3src = reinterpret_cast<const char*>(p.st_m3 + (long)nf * 32 * P);
     const char* i2src = reinterpret_cast<const char*>(p.st_i2 + (long)nf * 16 * P);
-    if (FAST) ss_dma16(m3src + (wvu * 64 + lane) * 16, (unsigned)(m3_own_dst() * 4));
+    if (FAST) {  // this wave's mask bytes into the cells of its own first row (front_own reads them back)
+#pragma unroll
+      for (int k = 0; k < NM3F; ++k)
+        if (lane + 64 * k < own_items)
+          ss_dma16(m3src + (2 * own_r0 * W4 + 64 * k + lane) * 16, (unsigned)(m3_own_dst() * 4 + k * 1024));
+    }
     for (int piece = wvu; piece < A2_PIECES + PX_PIECES + M3_PIECES + I2_PIECES; piece += NWV) {
       int q = piece;
       if (q < A2_PIECES) {
@@ -347,26 +389,25 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   };
   // dy3 = mask3 * dfeat / P, pixel-major [haloed pixel][24 channels]: an item is 16 mask bytes = 16 channels of one
   // pixel -> four (two for channels 16..23) 16-byte stores
-  auto front_fill = [&](const uint4 (&m3w)[NM3]) {
+  auto fill_item = [&](const int item, const uint4& mw) {
+    const int pix = item >> 1, half = item & 1;
+    const unsigned wds[4] = {mw.x, mw.y, mw.z, mw.w};
+    float* dst = dy3h + ((pix / W4 + 1) * S2 + (pix % W4) + 1) * DS + 16 * half;
 #pragma unroll
-    for (int k = 0; k < NM3; ++k) {
-      const int item = tid + k * NT;
-      if (item < 2 * P) {
-        const int pix = item >> 1, half = item & 1;
-        const unsigned wds[4] = {m3w[k].x, m3w[k].y, m3w[k].z, m3w[k].w};
-        float* dst = dy3h + ((pix / W4 + 1) * S2 + (pix % W4) + 1) * DS + 16 * half;
+    for (int e = 0; e < 4; ++e) {
+      if (half == 0 || e < 2) {
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(&s_dfeat[16 * half + 4 * e]);
+        f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (half == 0 || e < 2) {
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(&s_dfeat[16 * half + 4 * e]);
-            f32x4 v;
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) v[bb] = ((wds[e] >> (8 * bb)) & 1u) ? dv[bb] : 0.f;
-            *reinterpret_cast<f32x4*>(dst + 4 * e) = v;
-          }
-        }
+        for (int bb = 0; bb < 4; ++bb) v[bb] = ((wds[e] >> (8 * bb)) & 1u) ? dv[bb] : 0.f;
+        *reinterpret_cast<f32x4*>(dst + 4 * e) = v;
       }
     }
+  };
+  auto front_fill = [&](const uint4 (&m3w)[NM3]) {
+#pragma unroll
+    for (int k = 0; k < NM3; ++k)
+      if (tid + k * NT < 2 * P) fill_item(tid + k * NT, m3w[k]);
   };
   auto front_gb3 = [&]() {
     if (tid < 24) s_gb3[tid] += s_dfeat[tid] * s_cnt[tid];  // d b3 = d feat x (number of positive conv3 outputs)
@@ -400,19 +441,22 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   // NWV - 1 the top / bottom row as well); d feat was published a stage ago
   auto front_own = [&]() {
     ss_dma_wait();
-    uint4 m3w[NM3];
-    m3w[0] = *reinterpret_cast<const uint4*>(lds + m3_own_dst() + lane * 4);
-    constexpr int RPW = P / NWV / W4;  // rows of the pooled-2 grid per wave
-    for (int q = lane; q < 2 * RPW * 6; q += 64) {  // left / right halo pixel of each own row, six 16-byte pieces each
+    uint4 m3w[NM3F];
+#pragma unroll
+    for (int k = 0; k < NM3F; ++k)
+      m3w[k] = (lane + 64 * k < own_items) ? *reinterpret_cast<const uint4*>(lds + m3_own_dst() + (lane + 64 * k) * 4) : uint4{0, 0, 0, 0};
+    for (int q = lane; q < 2 * (own_r1 - own_r0) * 6; q += 64) {  // left / right halo pixel of each own row, six 16-byte pieces each
       const int hp = q / 6, part = q - 6 * hp;
-      const int pixh = (RPW * wvu + (hp >> 1) + 1) * S2 + ((hp & 1) ? W4 + 1 : 0);
+      const int pixh = (own_r0 + (hp >> 1) + 1) * S2 + ((hp & 1) ? W4 + 1 : 0);
       reinterpret_cast<f32x4*>(dy3h + pixh * DS)[part] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (wvu == 0 || wvu == NWV - 1) {
       const int row = wvu == 0 ? 0 : G::H4 + 1;
       for (int q = lane; q < S2 * DS / 4; q += 64) reinterpret_cast<f32x4*>(dy3h + row * S2 * DS)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    front_fill(m3w);
+#pragma unroll
+    for (int k = 0; k < NM3F; ++k)
+      if (lane + 64 * k < own_items) fill_item(2 * own_r0 * W4 + lane + 64 * k, m3w[k]);
     front_table();
     front_gb3();
   };
@@ -442,7 +486,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     for (int k = 0; k < NCH; ++k)
       if ((tid + k * NT) * 8 < HW) px[k] = reinterpret_cast<const uint2*>(lds + STG_PX)[tid + k * NT];
     if (tid * 16 < 16 * P) reinterpret_cast<uint4*>(i2b)[tid] = reinterpret_cast<const uint4*>(lds + STG_I2)[tid];
-    if (!LL::W3_RESIDENT) stage_w3();  // (read in S2, behind the barrier that ends S1)
+    if (!LL::W3_RESIDENT) stage_w3_dma();  // (read in S2, behind the wait + barrier that end S1)
     STAMP(0);
 
     // ---------------- S1: dW3
@@ -451,11 +495,18 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     auto a1_dma = [&](int part, int nparts) {
       // FAST: the next frame's d_out row / features / statistics are requested here (d feat is made inside S3)
       if (FAST && part == 0 && n + (int)gridDim.x < p.N) misc_dma(n + gridDim.x);
-      constexpr int BYTES = 8 * P1 * 4;
+      constexpr int BYTES = 8 * P1 * 4, A1_PIECES = (BYTES + 1023) / 1024;
+      constexpr int I1_BYTES = 8 * I1S, I1_PIECES = I1_BY_DMA ? (I1_BYTES + 1023) / 1024 : 0;  // the pool-1 argmax image rides along
       const char* src = reinterpret_cast<const char*>(p.st_a1 + (long)n * 8 * P1);
-      for (int piece = wvu + NWV * part; piece * 1024 < BYTES; piece += NWV * nparts) {
-        const int off = piece * 1024 + lane * 16;
-        if (off < BYTES) ss_dma16(src + off, (unsigned)(LL::o_a1h * 4 + piece * 1024));
+      const char* isrc = reinterpret_cast<const char*>(p.st_i1 + (long)n * 8 * I1S);
+      for (int piece = wvu + NWV * part; piece < A1_PIECES + I1_PIECES; piece += NWV * nparts) {
+        if (piece < A1_PIECES) {
+          const int off = piece * 1024 + lane * 16;
+          if (off < BYTES) ss_dma16(src + off, (unsigned)(LL::o_a1h * 4 + piece * 1024));
+        } else {
+          const int off = (piece - A1_PIECES) * 1024 + lane * 16;
+          if (off < I1_BYTES) ss_dma16(isrc + off, (unsigned)(LL::o_i1b * 4 + (piece - A1_PIECES) * 1024));
+        }
       }
     };
     if (s1_half == 0) s1_rows<G, 0>(dy3h, a2h, s1_kg, i, g, acc3, a1_dma);
@@ -466,106 +517,94 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // the staged pixels, hipcc sank the frame top's LDS read of them to the end of S1 -- legal for one wave -- where a
     // faster wave's stores overtook it: d W1 moved by up to 4e-2 relative between identical launches;
     // tools/bwd_determinism.py and the kernel test now check that.)
+    if (!LL::W3_RESIDENT) ss_dma_wait();  // this wave's pieces of W3 (and of the pooled-1 map issued so far) have landed
     __syncthreads();
     STAMP(3);
-    // pool-1 argmaxes for the phase switch: fetched here so that HBM answers under S2
+    // pool-1 argmaxes for S5: fetched here so that HBM answers under S2 (register form)
     uint4 ix1[NI1];
 #pragma unroll
     for (int k = 0; k < NI1; ++k)
-      if ((tid + k * NT) * 16 < 8 * I1S)
+      if (!I1_BY_DMA && (tid + k * NT) * 16 < 8 * I1S)
         ix1[k] = reinterpret_cast<const uint4*>(p.st_i1 + (long)n * 8 * I1S)[tid + k * NT];
-    // ---------------- S2: da2 (masked by a2 > 0), kept in registers ; db2.  Two pixel tiles per pass share the W3 reads.
-    constexpr int S2_IT = (P / 16 + 2 * NWV - 1) / (2 * NWV);  // passes of two pixel tiles per wave
-    float s2v[S2_IT][2][4];
-    unsigned s2o[S2_IT][2];  // four argmax bytes each
+    // ---------------- S2: da2 (masked by a2 > 0), kept in registers ; db2.  ONE pass per wave over all its pixel tiles (tile
+    // w, w + NWV, w + 2 NWV: two at 64 x 64, two or three at 48 x 96), which share the W3 reads.  (Round 3 ran 48 x 96's 18 tiles
+    // as a pass of sixteen and a second pass of two: a second set of B reads, a second epilogue and two register sets of results
+    // held through the phase switch -- S2 13.0 k cycles for an MFMA floor of 8.6 k.)
+    constexpr int S2_TILES = P / 16;
+    constexpr int S2_MAXT = (S2_TILES + NWV - 1) / NWV;  // tiles of a wave at most
+    constexpr int S2_FULL = S2_TILES % NWV;              // waves [0, S2_FULL) hold S2_MAXT tiles, the others one fewer (0: all S2_MAXT)
+    static_assert(S2_MAXT >= 1 && S2_MAXT <= 3, "S2 tile split");
+    float s2v[S2_MAXT][4];
+    unsigned s2o[S2_MAXT];  // four argmax bytes each
     {
-      constexpr int tiles = P / 16;
-      // A last pass that holds at most one tile per wave (48 x 96: 18 tiles, passes of 16) runs WITHOUT the second tile's reads and
-      // MFMAs: as a two-tile pass over a duplicate it made S2 four tile times long where three do (stage timers: 15.8 k cycles
-      // against 8.0 k at 64 x 64, whose 16 tiles are exactly one pass).
-      constexpr int tail_tiles = tiles % (2 * NWV);
-      constexpr bool TAIL_SINGLE = tail_tiles != 0 && tail_tiles <= NWV;
-      auto s2_pass = [&](const int it, auto two_c) {
-        constexpr bool TWO = decltype(two_c)::value;
-        const int tile = wvu + 2 * NWV * it;  // wvu: scalar loop control and tile arithmetic
-        if (tile >= tiles) return;
-        const int tile2 = tile + NWV;
-        const bool two = TWO && tile2 < tiles;
-        const int pp0 = 16 * tile + i, pp1 = 16 * (two ? tile2 : tile) + i;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1x = acc0;
-        // per tap and pixel tile: channels 4g..4g+3 in one ds_read_b128 (k-steps 0..3), channels 16+2g, 17+2g in one
-        // ds_read_b64 (k-steps 4, 5); the tap shift is an immediate
-        const float* ap0 = dy3h + ((pp0 / W4 + 2) * S2 + (pp0 % W4 + 2)) * DS;
-        const float* ap1 = dy3h + ((pp1 / W4 + 2) * S2 + (pp1 % W4 + 2)) * DS;
+      auto s2_pass = [&](auto nt_c) {
+        constexpr int NTW = decltype(nt_c)::value;  // tiles of this wave
         int w3off = (LL::o_w3s + (g * 16 + i) * 4) * 4, w3off8 = (LL::o_w3s + 2304 + (g * 16 + i) * 2) * 4;
         asm volatile("" : "+v"(w3off), "+v"(w3off8));  // W3 may lie beyond the 64 KB reach of a ds_read immediate (see S5)
         const float* bt16 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + w3off);
         const float* bt8 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + w3off8);
-        // a tap is two steps -- channels 0..15 (3 x ds_read_b128, 8 MFMAs) and 16..23 (3 x ds_read_b64, 4 MFMAs) -- and
+        // per tap and pixel tile: channels 4g..4g+3 in one ds_read_b128 (k-steps 0..3), channels 16+2g, 17+2g in one
+        // ds_read_b64 (k-steps 4, 5); the tap shift is an immediate
+        const float* ap[NTW];
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          const int pp = 16 * (wvu + NWV * j) + i;
+          ap[j] = dy3h + ((pp / W4 + 2) * S2 + (pp % W4 + 2)) * DS;
+          acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // a tap is two steps -- channels 0..15 (ds_read_b128 each, 4 NTW MFMAs) and 16..23 (ds_read_b64 each, 2 NTW MFMAs) -- and
         // every step's reads are issued before the MFMAs of the step in front of it (see S3)
-        f32x4 b16, a016, a116;
-        float2 b8, a08, a18;
+        f32x4 b16, a16[NTW];
+        float2 b8, a8[NTW];
         auto back_of = [](int tap) { return ((tap / 3) * S2 + (tap % 3)) * DS; };
         b16 = *reinterpret_cast<const f32x4*>(bt16);
-        a016 = *reinterpret_cast<const f32x4*>(ap0 + 4 * g);
-        if constexpr (TWO) a116 = *reinterpret_cast<const f32x4*>(ap1 + 4 * g);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) a16[j] = *reinterpret_cast<const f32x4*>(ap[j] + 4 * g);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int back = back_of(tap);
           b8 = *reinterpret_cast<const float2*>(bt8 + tap * 128);
-          a08 = *reinterpret_cast<const float2*>(ap0 - back + 16 + 2 * g);
-          if constexpr (TWO) a18 = *reinterpret_cast<const float2*>(ap1 - back + 16 + 2 * g);
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) a8[j] = *reinterpret_cast<const float2*>(ap[j] - back + 16 + 2 * g);
           SS_SCHED_FENCE();
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc0 = mfma16(a016[e], b16[e], acc0);
-            if constexpr (TWO) acc1x = mfma16(a116[e], b16[e], acc1x);
-          }
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[j] = mfma16(a16[j][e], b16[e], acc[j]);
           SS_SCHED_FENCE();
           if (tap + 1 < 9) {
             const int nb = back_of(tap + 1);
             b16 = *reinterpret_cast<const f32x4*>(bt16 + (tap + 1) * 256);
-            a016 = *reinterpret_cast<const f32x4*>(ap0 - nb + 4 * g);
-            if constexpr (TWO) a116 = *reinterpret_cast<const f32x4*>(ap1 - nb + 4 * g);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) a16[j] = *reinterpret_cast<const f32x4*>(ap[j] - nb + 4 * g);
           }
           SS_SCHED_FENCE();
-          acc0 = mfma16(a08.x, b8.x, acc0);
-          if constexpr (TWO) acc1x = mfma16(a18.x, b8.x, acc1x);
-          acc0 = mfma16(a08.y, b8.y, acc0);
-          if constexpr (TWO) acc1x = mfma16(a18.y, b8.y, acc1x);
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[j] = mfma16(a8[j].x, b8.x, acc[j]);
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[j] = mfma16(a8[j].y, b8.y, acc[j]);
           SS_SCHED_FENCE();
         }
         // the masked gradient and the pool-2 argmax of its four pixels stay in registers: this wave scatters them into the
         // dense dy2 image itself, right behind barrier D (no da2m image, no second barrier)
-        unsigned o0 = 0, o1 = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int pq = 16 * tile + 4 * g + r;
-          const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
-          const float v = av > 0.f ? acc0[r] : 0.f;
-          s2v[it][0][r] = v;
-          o0 |= (unsigned)i2b[pq * 16 + i] << (8 * r);
-          accb2 += v;
-        }
-        s2o[it][0] = o0;
-        if (two) {
+        for (int j = 0; j < NTW; ++j) {
+          unsigned o = 0;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int pq = 16 * tile2 + 4 * g + r;
+            const int pq = 16 * (wvu + NWV * j) + 4 * g + r;
             const float av = a2h[i * P2 + (pq / W4 + 1) * S2 + (pq % W4) + 1];
-            const float v = av > 0.f ? acc1x[r] : 0.f;
-            s2v[it][1][r] = v;
-            o1 |= (unsigned)i2b[pq * 16 + i] << (8 * r);
+            const float v = av > 0.f ? acc[j][r] : 0.f;
+            s2v[j][r] = v;
+            o |= (unsigned)i2b[pq * 16 + i] << (8 * r);
             accb2 += v;
           }
+          s2o[j] = o;
         }
-        s2o[it][1] = o1;
       };
-#pragma unroll
-      for (int it = 0; it < S2_IT; ++it) {
-        if (TAIL_SINGLE && it == S2_IT - 1) s2_pass(it, std::false_type{});
-        else s2_pass(it, std::true_type{});
-      }
+      if (S2_FULL == 0 || wvu < S2_FULL) s2_pass(std::integral_constant<int, S2_MAXT>{});
+      else if constexpr (S2_MAXT > 1) s2_pass(std::integral_constant<int, (S2_MAXT > 1 ? S2_MAXT - 1 : 1)>{});
     }
     if (FAST && wvu == NWV - 1) ss_dma_wait();  // the next frame's d_out row has landed: published by barrier D
     __syncthreads();  // D: dy3h / a2h / w3 / the pool-2 argmaxes are dead
@@ -575,30 +614,27 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // barrier D): each wave expands the pixels it computed in S2 -- the value goes to its pool winner's cell, zeros to the
     // other three.
     {
-      constexpr int tiles = P / 16;
 #pragma unroll
-      for (int it = 0; it < S2_IT; ++it)
+      for (int j = 0; j < S2_MAXT; ++j) {
+        const int tile = wvu + NWV * j;
+        if (tile < S2_TILES) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int tile = wvu + 2 * NWV * it + NWV * h;
-          if (tile < tiles) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int pq = 16 * tile + 4 * g + r, qy = pq / W4, qx = pq % W4;
-              // a wave's store covers 4 pixels (one per lane group g) x 16 channels and a dy2 pixel is 16 banks wide: odd
-              // lane groups write the right-hand window column first, so that the 32 lanes of a half spread over all banks
-              const int par = g & 1;
-              float* d0 = dy2 + ((2 * qy) * W2H + 2 * qx + 1 + par) * 16 + i;
-              float* d1 = dy2 + ((2 * qy) * W2H + 2 * qx + 2 - par) * 16 + i;
-              const float v = s2v[it][h][r];
-              const int o = (s2o[it][h] >> (8 * r)) & 255u;
-              d0[0] = o == par ? v : 0.f;
-              d1[0] = o == 1 - par ? v : 0.f;
-              d0[16 * W2H] = o == 2 + par ? v : 0.f;
-              d1[16 * W2H] = o == 3 - par ? v : 0.f;
-            }
+          for (int r = 0; r < 4; ++r) {
+            const int pq = 16 * tile + 4 * g + r, qy = pq / W4, qx = pq % W4;
+            // a wave's store covers 4 pixels (one per lane group g) x 16 channels and a dy2 pixel is 16 banks wide: odd
+            // lane groups write the right-hand window column first, so that the 32 lanes of a half spread over all banks
+            const int par = g & 1;
+            float* d0 = dy2 + ((2 * qy) * W2H + 2 * qx + 1 + par) * 16 + i;
+            float* d1 = dy2 + ((2 * qy) * W2H + 2 * qx + 2 - par) * 16 + i;
+            const float v = s2v[j][r];
+            const int o = (s2o[j] >> (8 * r)) & 255u;
+            d0[0] = o == par ? v : 0.f;
+            d1[0] = o == 1 - par ? v : 0.f;
+            d0[16 * W2H] = o == 2 + par ? v : 0.f;
+            d1[16 * W2H] = o == 3 - par ? v : 0.f;
           }
         }
+      }
       STAMP(10);
     }
     ss_dma_wait();    // this wave's share of the pooled-1 map has landed in LDS
@@ -606,7 +642,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     STAMP(5);
 
     // The normalised frame (interior by table lookup, halo cells zeroed: the area held phase-1 data) and the pool-1 argmax
-    // bytes are needed by S5 only, and every thread makes them from its OWN registers (px, ix1) and the grey-level table:
+    // bytes are needed by S5 only; the frame is made by every thread from its OWN registers (px) and the grey-level table (the
+    // argmax bytes arrive by DMA since round 4):
     // like the next frame's front they run per wave, without a barrier, inside S3 -- the two waves of a SIMD at
     // different passes, one wave's table lookups and LDS stores under its partner's MFMAs (they were 2.4 k cycles of
     // the phase switch, with every wave storing and nobody multiplying).  The zero columns of dy2 and the next frame's
@@ -636,9 +673,8 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
 #pragma unroll
       for (int k = 0; k < NI1; ++k)
-        if ((tid + k * NT) * 16 < 8 * I1S) {  // 16 stash bytes -> their plane's place in the padded LDS layout
-          const int q = (tid + k * NT) * 16;
-          uint32_t* dst = reinterpret_cast<uint32_t*>(i1b + q + 4 * (q / I1S));
+        if (!I1_BY_DMA && (tid + k * NT) * 16 < 8 * I1S) {  // the stash's plane layout is the LDS layout
+          uint32_t* dst = reinterpret_cast<uint32_t*>(lds + LL::o_i1b) + 4 * (tid + k * NT);
           dst[0] = ix1[k].x; dst[1] = ix1[k].y; dst[2] = ix1[k].z; dst[3] = ix1[k].w;
         }
       // the zero columns of dy2 (the area held phase-1 data): S3 reads interior columns only, S4 is behind a barrier

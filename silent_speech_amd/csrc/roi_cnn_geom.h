@@ -21,8 +21,10 @@ struct Geom {
   static constexpr int XS = W + 2;                              // haloed normalised image, row stride
   static constexpr int S1 = W2 + 2, P1 = plane_stride((H2 + 2) * S1);  // haloed pooled-1 map
   static constexpr int S2 = W4 + 2, P2 = plane_stride((H4 + 2) * S2);  // haloed pooled-2 map
-  // pool-1 argmax bytes, plane stride per channel (padding the planes apart by one bank was measured: no gain)
-  static constexpr int I1S = HW2;
+  // pool-1 argmax bytes, plane stride per channel: 16 bytes of padding put the eight planes four LDS banks apart (the backward's S5
+  // reads one byte per plane) and keep them 16-byte aligned, so the stash IS the backward kernel's LDS image and arrives by
+  // linear LDS-DMA (round 3: the planes went through registers to be laid out one bank apart)
+  static constexpr int I1S = HW2 + 16;
   static_assert(H % 4 == 0 && W % 32 == 0 && H2 % 2 == 0 && P % 32 == 0 && HW2 % 32 == 0, "unsupported ROI size");
 };
 

@@ -135,6 +135,11 @@ __device__ __forceinline__ float relu_f(float x) { return x < 0.f ? 0.f : x; }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Correctly rounded float32 square root (what np.sqrt / np.linalg.norm give on float32): the double root, rounded once more to
+// float32 -- exact, since 53 >= 2 * 24 + 2 bits.  HIP's __fsqrt_rn is the hardware's v_sqrt_f32, one ulp off on ~10 % of
+// arguments (found against the reference's own extract_83_and_openness outputs, tests/golden/serving.npz).
+__device__ __forceinline__ float ss_sqrt_rn_f32(float x) { return (float)__dsqrt_rn((double)x); }
+
 // Compute units of the current device (MI355X: 256).  Every persistent grid, co-residency bound and workspace layout that depends
 // on the chip's size asks here -- no launcher hard-codes 256.  One query per translation unit, then cached.
 static inline int ss_device_cus() {

@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void mouth_openness_kernel(const float* __rest
     // operation rounded to float32 (no FMA: pinned by tests/golden/serving.npz), the width gets + 1e-6 in float32
     const float gx = __fsub_rn(f[2 * i_top], f[2 * i_bot]), gy = __fsub_rn(f[2 * i_top + 1], f[2 * i_bot + 1]);
     const float wx = __fsub_rn(f[2 * i_eye_r], f[2 * i_eye_l]), wy = __fsub_rn(f[2 * i_eye_r + 1], f[2 * i_eye_l + 1]);
-    const float gap = __fsqrt_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));
-    const float wid = __fadd_rn(__fsqrt_rn(__fadd_rn(__fmul_rn(wx, wx), __fmul_rn(wy, wy))), 1e-6f);
+    const float gap = ss_sqrt_rn_f32(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));
+    const float wid = __fadd_rn(ss_sqrt_rn_f32(__fadd_rn(__fmul_rn(wx, wx), __fmul_rn(wy, wy))), 1e-6f);
     out[i] = (double)__fdiv_rn(gap, wid);
   } else {
     float lo = f[1], hi = f[1];

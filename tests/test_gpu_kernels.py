@@ -744,7 +744,7 @@ def test_feature_fuse_vs_golden(L, golden_dir, tag, variant):
     if not np.array_equal(cen[0].cpu().numpy(), d[f"center_{vname}_{tag}"]):
         pytest.fail("centre must be bit-exact: max diff %g" % np.abs(cen[0].cpu().numpy() - d[f"center_{vname}_{tag}"]).max(),
                     pytrace=False)
-    np.testing.assert_allclose(fourth[0].cpu().numpy(), d[f"fourth_{vname}_{tag}"], rtol=1e-15 if variant == 0 else 2e-7)
+    np.testing.assert_allclose(fourth[0].cpu().numpy(), d[f"fourth_{vname}_{tag}"], rtol=1e-15)
     got = X[0].cpu().numpy()
     np.testing.assert_allclose(got[:, : 2 * K], ref[:, : 2 * K], rtol=0, atol=1.2e-7)
     np.testing.assert_allclose(got[:, 2 * K:], ref[:, 2 * K:], rtol=1e-6, atol=1e-7)

@@ -628,7 +628,7 @@ def test_live_chain_one_entry_point_band_leave_and_reentry(ss):
     rng = np.random.default_rng(11)
     idxs = Fm.FIXED_IDXS_88
     K, Dm = len(idxs), 2 * len(idxs) + 4
-    S, max_t, hw, w, h = 5, 10, (16, 32), 320, 240
+    S, max_t, hw, w, h = 5, 10, (32, 32), 320, 240
     anchors = Fm.anchor_positions(idxs)
     sd = W.make_state_dict(5, Dm, 10, True)
     m = ss.BiGRUClassifier(Dm, 10, use_roi=True)
