@@ -65,12 +65,24 @@ struct CnnFwdParams {
   float* st_feat;   // [N][ST_FEAT]  24 averaged conv3 features, 24 counts of positive conv3 outputs (for d b3), mean, std
 };
 
+// conv1 with lane-local pool windows (round 4, below) reads the frame with lanes that walk a 2 x 2 window x 4 windows: a row
+// stride == 8 (mod 32) keeps the two rows of a window and the four windows on different banks (W + 2 == 2 (mod 32) put row 1 of
+// window w on the banks of row 0 of window w + 1)
+// MEASURED AND NOT USED (A/B on one box, tools/cnn_ab.py, 64 x 64: 437.7 us per launch against 427.3; 48 x 96: 535.1 / 538.5):
+// the 128 extra MFMAs per frame cost what the 17 instructions saved per pooled output gain -- the same null result as round 1's
+// lane-local pool, now with the cheap epilogue.  Kept behind the macro as the record of that experiment.
+#ifndef SS_CONV1_LOCAL
+#define SS_CONV1_LOCAL 0
+#endif
+template <class G>
+constexpr int fwd_xs() { return SS_CONV1_LOCAL ? G::XS + (8 - G::XS % 32 + 32) % 32 : G::XS; }
+
 template <class G>
 struct FwdLds {
   // region U holds the normalised frame + pool-1 argmaxes while conv1 runs, then the pooled-2 map + pool-2 argmaxes
   // (conv2 writes them when conv1's inputs are dead): the image stays under half a CU's LDS
   static constexpr int o_xh = 0;                                // [(H+2)][XS]
-  static constexpr int o_i1 = ((G::H + 2) * G::XS + 3) & ~3;    // bytes [8][I1S]
+  static constexpr int o_i1 = ((G::H + 2) * fwd_xs<G>() + 3) & ~3;    // bytes [8][I1S]
   static constexpr int o_a2 = 0;                                // [16][P2]
   static constexpr int o_i2 = 16 * G::P2;                       // bytes [P][16]
   static constexpr int u_end1 = o_i1 + 2 * G::I1S, u_end2 = o_i2 + 4 * G::P;
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = FwdLds<G>;
   constexpr int H = G::H, W = G::W, H2 = G::H2, W2 = G::W2, W4 = G::W4, HW = G::HW, P = G::P;
-  constexpr int XS = G::XS, S1 = G::S1, P1 = G::P1, S2 = G::S2, P2 = G::P2;
+  constexpr int XS = fwd_xs<G>(), S1 = G::S1, P1 = G::P1, S2 = G::S2, P2 = G::P2;
   constexpr int NCH = (HW / 16 + NT - 1) / NT;  // 16-byte pixel chunks per thread
   float* xh = lds + LL::o_xh;
   float* a1 = lds + LL::o_a1;
@@ -129,6 +141,20 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
   const float* w3s = lds + 1152;
   // conv1: k = 4kk+g -> (ry = k/3, kx = k%3) over the 4x3 input window of output rows y, y+1;
   // column i = (c = i&7, s = i>>3): W1[c][ky = ry - s][kx], zero outside the 3x3 kernel
+#if SS_CONV1_LOCAL
+  // lane-local pool windows: M = the 16 pixels of four 2 x 2 windows (D rows 4g + r = position r of window g: a lane ends up with
+  // ONE whole window), N = (8 channels) x (row pairs yq and yq + 1 of a 4-row band), K = the 5 x 3 input window both row pairs
+  // touch = 15 -> 16: k = 4kk+g -> (ry = k/3, kx = k%3); column i = (c = i&7, v = i>>3): W1[c][ky = ry - 2v][kx], zero outside
+  constexpr int K1S = 4;
+  float bw1[K1S];
+  int aoff1[K1S];
+#pragma unroll
+  for (int kk = 0; kk < K1S; ++kk) {
+    const int k = 4 * kk + g, ry = k / 3, kx = k % 3, c = i & 7, v = i >> 3, ky = ry - 2 * v;
+    bw1[kk] = (k < 15 && ky >= 0 && ky <= 2) ? p.w1[c * 9 + ky * 3 + kx] : 0.f;
+    aoff1[kk] = k < 15 ? ry * XS + kx : 0;
+  }
+#else
   float bw1[3];
   int aoff1[3];
 #pragma unroll
@@ -137,6 +163,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
     bw1[kk] = (ky >= 0 && ky <= 2) ? p.w1[c * 9 + ky * 3 + kx] : 0.f;
     aoff1[kk] = ry * XS + kx;
   }
+#endif
   float bw2[18];  // conv2: k-step kk -> tap = kk/2, c = 4*(kk%2)+g ; n = i
 #pragma unroll
   for (int kk = 0; kk < 18; ++kk) bw2[kk] = w2s[i * 72 + (4 * (kk & 1) + g) * 9 + (kk >> 1)];
@@ -264,6 +291,62 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
     //    final masks into the index byte;
     //  * the MFMAs of the next pass are issued before the epilogue of this one (two accumulator sets).
     {
+#if SS_CONV1_LOCAL
+      // Round 4: the 2 x 2 max-pool inside ONE lane.  The row-pair form below leaves a lane with two half windows: column pairs in
+      // the lane, the row pair in lane i ^ 8 -- a DPP exchange, two selects and the partner's argmax bits swapped on the scalar unit:
+      // 16 vector + 16 scalar instructions per pooled output, and conv1 was 22 k of a frame's 64 k cycles for 3 k cycles of MFMAs
+      // (profiles/round4 stage timers; f32 MFMAs and the other vector instructions of a SIMD do not overlap).  Here a lane's four
+      // accumulator values ARE one window (M tile = four windows x four positions, N = 8 channels x two row pairs of a 4-row band,
+      // K = 5 x 3 -> 16): 4 MFMAs per 64 outputs instead of 3, and the epilogue is 8 vector + 3 scalar instructions -- the bias rides
+      // in the accumulator's initial value, v_max3 folds the ReLU into the last maximum.
+      constexpr int UC = 4;                       // windows groups per pass: 32 frame columns
+      constexpr int XP = W / 32, passes = (H / 4) * XP;
+      static_assert(W % 32 == 0 && H % 4 == 0, "conv1 pass split");
+      const int c = i & 7, v = i >> 3;
+      const int wvu = __builtin_amdgcn_readfirstlane(wv);
+      const float bias = s_b1[c];
+      const float* xa = xh + ((i >> 1) & 1) * XS + 2 * (i >> 2) + (i & 1);  // A row i = position i & 3 of window i >> 2
+      float* a1w = a1 + c * P1 + (v + 1) * S1 + g + 1;                      // D: window g of channel c, pooled row 2 yq + v
+      uint8_t* i1w = i1s + c * G::I1S + v * W2 + g;
+      auto mm = [&](int ps, f32x4 (&acc)[UC]) {
+        const float* ap = xa + (4 * (ps / XP)) * XS + 32 * (ps % XP);
+        float av[UC][K1S];
+#pragma unroll
+        for (int kk = 0; kk < K1S; ++kk)
+#pragma unroll
+          for (int q = 0; q < UC; ++q) av[q][kk] = (ap + aoff1[kk])[8 * q];
+        SS_SCHED_FENCE();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < UC; ++q) acc[q] = f32x4{bias, bias, bias, bias};
+#pragma unroll
+        for (int kk = 0; kk < K1S; ++kk)
+#pragma unroll
+          for (int q = 0; q < UC; ++q) acc[q] = mfma16(av[q][kk], bw1[kk], acc[q]);
+        __builtin_amdgcn_s_setprio(0);
+        SS_SCHED_FENCE();
+      };
+      auto epi = [&](int ps, const f32x4 (&acc)[UC]) {
+        const int yq = ps / XP, xb = ps % XP;
+        float* aw = a1w + 2 * yq * S1 + 16 * xb;
+        uint8_t* iw = i1w + 2 * yq * W2 + 16 * xb;
+#pragma unroll
+        for (int q = 0; q < UC; ++q) {
+          const float x00 = acc[q][0], x01 = acc[q][1], x10 = acc[q][2], x11 = acc[q][3];  // (row, column) of the window
+          const unsigned long long c0 = __ballot(x01 > x00), c1 = __ballot(x11 > x10);
+          const float m0 = fmaxf(x00, x01), m1 = fmaxf(x10, x11);
+          const unsigned long long t1 = __ballot(m1 > m0);  // strictly: ties go to the first in row-major order
+          const unsigned long long b0 = (t1 & c1) | (~t1 & c0);
+          const float best = fmaxf(fmaxf(m0, m1), 0.f);
+          int hi, bi;
+          unsigned long long carry_out;
+          asm("v_cndmask_b32_e64 %0, 0, 2, %1" : "=v"(hi) : "s"(t1));
+          asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(bi), "=s"(carry_out) : "v"(hi), "s"(b0));
+          aw[4 * q] = best;
+          iw[4 * q] = (uint8_t)bi;
+        }
+      };
+#else
       constexpr int XT = W / 16;
       constexpr int UC = (XT % 4 == 0) ? 4 : (XT % 3 == 0) ? 3 : 2;
       static_assert(XT % UC == 0, "conv1 pass split");
@@ -323,6 +406,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
           iw[8 * q] = (uint8_t)bi;
         }
       };
+#endif
       f32x4 accA[UC], accB[UC];
       if (wvu < passes) {
         mm(wvu, accA);
