@@ -191,7 +191,11 @@ typedef struct ss_gemm_problem {
 int ss_gemm_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats);
 /* ws_floats = the floats the caller allocated at ws: the entry points recompute the layout and return SS_ERR_ARG when it does not fit
  * (a caller that sized ws for another group would otherwise be written past its end, silently). */
-int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, long ws_floats, ss_stream_t stream);
+int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, long ws_floats, int flags, ss_stream_t stream);
+/* flags bit 0: the launch has the chip to itself -> k-major groups run as 192 x 192 output tiles, one 512-thread workgroup per CU,
+ * K slices chosen by the library so that the group fills the chip in one round (`splits` ignored): dG and the layer input are
+ * fetched 2 - 3 x instead of 5 - 6 x and the launch takes 12 - 18 % less time alone on the chip.  Beside a latency-bound kernel on
+ * another stream (the lower layer's BPTT) the 128 x 64 form with three workgroups per CU is the better neighbour: leave the bit 0. */
 /* The same for bf16 operands (config 5; csrc/gemm_bf16.hip): A and B point at bf16 data (k-major, a_kcontig = b_kcontig = 0; lda /
  * ldb / strides in bf16 elements, multiples of 8; K a multiple of 64; n <= 8), C[b] += A[b]^T B[b] in f32.  A group with at least
  * half a chip of 256 x 128 output tiles runs one workgroup per tile over all of K (neighbouring tiles share operand panels in L2);

@@ -65,7 +65,7 @@ SIGNATURES = {
     "ss_gemm_splitk_ws_floats": [_i, _i, _i, _i, _i, _vp],
     "ss_gemm_splitk_reduce": [_vp, _i, _i, _i, _i, _i, _vp, _i, _l, _vp],
     "ss_gemm_splitk_group_ws_floats": [_vp, _i, _vp],
-    "ss_gemm_f32_splitk_group": [_vp, _i, _vp, _l, _vp],
+    "ss_gemm_f32_splitk_group": [_vp, _i, _vp, _l, _i, _vp],
     "ss_gemm_bf16_splitk_group_ws_floats": [_vp, _i, _vp],
     "ss_gemm_bf16_splitk_group": [_vp, _i, _vp, _l, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],

@@ -632,6 +632,225 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup rg
   splitk_reduce_body(rg.it[j], blockIdx.x - rg.first[j]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMMs (round 4): C[M][N] += A^T B with both operands k-major ([k][row]), M x N small (the GRU's 576 x 384,
+// 384 x 192, 192 x 192), K = B T huge.  The 128 x 64 tiles above read dG once per 64 output columns and the layer input once per
+// 128 output rows: 342 MB per launch for 59 MB of operands, and 768 workgroups of 13 k tiles each leave
+// 56 MB of slabs.  Here: 192 x 192 output tiles, 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 48 x 96 = 3 x 6 MFMA tiles
+// (72 accumulator registers), one workgroup per CU (ring of four 24 KB stages), K split so that the workgroups of ALL problems of
+// the group together fill the chip once: 18 tiles x 14 slices at config 2.  dG is then read twice (N = 384) or once, the layer
+// input three times; 36 LDS reads feed 72 MFMAs per k tile (24 / 32 above).  Slabs as before (raw accumulators, coalesced) + one
+// reduce launch.  Same DMA ring, same source-side rotation of the [k][row] image (unit u of k row k holds row unit
+// u - 4 ((k >> 2) & 1) mod 48: the k rows of lane groups g and g + 1 land 16 banks apart).
+namespace wide {
+constexpr int WT = 192, WNT = 512, WNWV = 8;
+constexpr int W_U = WT / 4;                          // 16-byte units per k row
+constexpr int W_PIECES = WT * BK / 4 / 64;           // 1 KB DMA pieces per operand and k tile: 12
+constexpr int W_STAGE = 2 * WT * BK;                 // floats per stage (A image, B image): 24 KB
+constexpr int W_LPW = 2 * W_PIECES / WNWV;           // DMA instructions per wave and k tile: 3
+constexpr int W_Q = 18;                              // accumulator quads per thread (3 x 6)
+constexpr int W_SLAB = WT * WT;                      // floats a workgroup leaves in the workspace
+static_assert(2 * W_PIECES % WNWV == 0, "pieces deal evenly over the waves");
+
+struct WideProblem {
+  const float *A, *B;
+  float* C;
+  int M, N, K, lda, ldb, ldc;
+  RowMap ra, rb;
+  int ksplit, nz, gx, gy, batch;
+  long sA, sB, sC;
+  long ws_off;  // floats in front of this problem's slabs
+};
+struct WideGroup {
+  WideProblem p[GEMM_GROUP_MAX];
+  int first[GEMM_GROUP_MAX + 1];   // GEMM workgroups [first[j], first[j+1]) belong to problem j
+  int rfirst[GEMM_GROUP_MAX + 1];  // reduce workgroups
+  float* ws;
+  int n;
+};
+
+// one wave's three DMA pieces of a k tile: piece q = wave + 8 n of the 24 (A: 0..11, B: 12..23)
+struct WidePieces {
+  const float* src[W_LPW];
+  int q[W_LPW], r[W_LPW];   // k row = q * S + r for a remapped operand (see DmaOperand)
+  int G[W_LPW], S[W_LPW], ld[W_LPW];
+  bool lin[W_LPW];
+  __device__ __forceinline__ void init(const WideProblem& P, const float* A, const float* B, int m0, int n0, int kbeg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < W_LPW; ++n) {
+      const int piece = wave + WNWV * n;
+      const bool isb = piece >= W_PIECES;
+      const int sl = (piece - (isb ? W_PIECES : 0)) * 64 + lane;
+      const int k = sl / W_U, u = sl % W_U;
+      int ru = u - 4 * ((k >> 2) & 1);
+      ru += ru < 0 ? W_U : 0;
+      const RowMap& rm = isb ? P.rb : P.ra;
+      const int nrows = isb ? P.N : P.M, row0 = isb ? n0 : m0;
+      ld[n] = isb ? P.ldb : P.lda;
+      lin[n] = rm.G == 0x7fffffff;
+      G[n] = rm.G; S[n] = rm.S;
+      const int gk = kbeg + k;
+      src[n] = (isb ? B : A) + min(row0 + 4 * ru, nrows - 4) + (long)rm.off * ld[n];
+      q[n] = lin[n] ? 0 : gk / rm.G;
+      r[n] = gk - q[n] * rm.G;
+      if (lin[n]) src[n] += (long)gk * ld[n];
+    }
+  }
+  __device__ __forceinline__ const float* cur(int n) const { return lin[n] ? src[n] : src[n] + ((long)q[n] * S[n] + r[n]) * ld[n]; }
+  __device__ __forceinline__ void issue(unsigned stage_byte) const {
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < W_LPW; ++n) ss_dma16(cur(n), stage_byte + (wave + WNWV * n) * 1024);
+  }
+  __device__ __forceinline__ void advance() {
+#pragma unroll
+    for (int n = 0; n < W_LPW; ++n) {
+      if (lin[n]) src[n] += (long)BK * ld[n];
+      else {
+        r[n] += BK;
+        while (r[n] >= G[n]) { r[n] -= G[n]; ++q[n]; }
+      }
+    }
+  }
+  // ragged last tile (kvalid < 16 k rows left): the same image through registers, zeros past the end
+  __device__ __forceinline__ void tail(float* img, int kvalid) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < W_LPW; ++n) {
+      const int piece = wave + WNWV * n;
+      const int sl = (piece % W_PIECES) * 64 + lane;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (sl / W_U < kvalid) v = *reinterpret_cast<const f32x4*>(cur(n));
+      *reinterpret_cast<f32x4*>(img + piece * 256 + 4 * lane) = v;
+    }
+  }
+};
+
+__global__ __launch_bounds__(WNT) void gemm_wide_group_kernel(WideGroup gg) {
+  extern __shared__ __attribute__((aligned(16))) float dlds[];  // DSTAGES x (A image, B image), at LDS address 0
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+    if (q < gg.n && (int)blockIdx.x >= gg.first[q]) j = q;
+  const WideProblem& P = gg.p[j];
+  const int local = blockIdx.x - gg.first[j];
+  const int bx = local % P.gx, by = (local / P.gx) % P.gy, bz = local / (P.gx * P.gy);
+  const int bi = bz / P.nz, zs = bz - bi * P.nz;
+  const int m0 = by * WT, n0 = bx * WT;
+  const int kbeg = zs * P.ksplit, kend = min(P.K, kbeg + P.ksplit);
+  const int nfull = (kend - kbeg) / BK, rem = (kend - kbeg) - nfull * BK;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1, i = lane & 15, g = lane >> 4;
+
+  WidePieces dp;
+  dp.init(P, P.A + bi * P.sA, P.B + bi * P.sB, m0, n0, kbeg);
+  int offA[3], offB[6];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) {
+    const int m = wm * 48 + mt * 16 + i;
+    offA[mt] = 4 * g * WT + 4 * (((m >> 2) + 4 * (g & 1)) % W_U) + (m & 3);
+  }
+#pragma unroll
+  for (int nt = 0; nt < 6; ++nt) {
+    const int nn = wn * 96 + nt * 16 + i;
+    offB[nt] = WT * BK + 4 * g * WT + 4 * (((nn >> 2) + 4 * (g & 1)) % W_U) + (nn & 3);
+  }
+  f32x4 acc[3][6];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int buf) {
+    dp.issue((unsigned)(buf * W_STAGE * 4));
+    dp.advance();
+  };
+  auto compute = [&](const float* st, int refill) {
+    if (refill >= 0) issue(refill);
+    float a[3][4], b[6][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) a[mt][kk] = st[offA[mt] + kk * WT];
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) b[nt][kk] = st[offB[nt] + kk * WT];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = mfma16(a[mt][kk], b[nt][kk], acc[mt][nt]);
+  };
+#pragma unroll
+  for (int s_ = 0; s_ < DSTAGES - 1; ++s_)
+    if (s_ < nfull) issue(s_);
+  for (int t0 = 0; t0 < nfull; t0 += DSTAGES) {
+#pragma unroll
+    for (int s_ = 0; s_ < DSTAGES; ++s_) {
+      const int t = t0 + s_;
+      if (t < nfull) {
+        if (t + DSTAGES - 2 < nfull) ss_vmcnt_wait<(DSTAGES - 2) * W_LPW>();
+        else ss_vmcnt_wait<0>();
+        ss_raw_barrier();
+        compute(dlds + s_ * W_STAGE, t + DSTAGES - 1 < nfull ? (s_ + DSTAGES - 1) % DSTAGES : -1);
+      }
+    }
+  }
+  if (rem) {
+    __syncthreads();
+    dp.tail(dlds, rem);
+    __syncthreads();
+    compute(dlds, -1);
+  }
+  // raw accumulators as they lie in the registers: 18 coalesced 16-byte stores per thread
+  f32x4* w = reinterpret_cast<f32x4*>(gg.ws + P.ws_off) + (long)local * (W_Q * WNT) + threadIdx.x;
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) w[(mt * 6 + nt) * WNT] = acc[mt][nt];
+}
+
+// C[bi][row][col] += sum over the nz slices: one workgroup per (problem, batch entry, tile, accumulator quad)
+__global__ __launch_bounds__(WNT) void gemm_wide_reduce_kernel(WideGroup gg) {
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+    if (q < gg.n && (int)blockIdx.x >= gg.rfirst[q]) j = q;
+  const WideProblem& P = gg.p[j];
+  const int blk = blockIdx.x - gg.rfirst[j];
+  const int q = blk % W_Q, tile = blk / W_Q;  // tile = (bi * gy + by) * gx + bx
+  const int bx = tile % P.gx, by = (tile / P.gx) % P.gy, bi = tile / (P.gx * P.gy);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1, i = lane & 15, g = lane >> 4;
+  const int mt = q / 6, nt = q % 6;
+  const long tiles = (long)P.gx * P.gy;
+  const f32x4* src = reinterpret_cast<const f32x4*>(gg.ws + P.ws_off) + (((long)bi * P.nz * tiles + by * P.gx + bx) * W_Q + q) * WNT + tid;
+  const long zstride = tiles * W_Q * WNT;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+  int z = 0;
+  for (; z + 8 <= P.nz; z += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(z + u) * zstride];
+    s0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (z + u < P.nz) ? src[(z + u) * zstride] : f32x4{0.f, 0.f, 0.f, 0.f};
+    s0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  const int col = bx * WT + wn * 96 + nt * 16 + i;
+  if (col >= P.N) return;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = by * WT + wm * 48 + mt * 16 + 4 * g + rr;
+    if (row < P.M) P.C[bi * P.sC + (long)row * P.ldc + col] += s0[rr];
+  }
+}
+}  // namespace wide
+
 int splitk_slices(int K, int splits, int* per_out) {
   const int per = ceil_div(ceil_div(K, splits), BK * KSUB) * BK * KSUB;
   if (per_out) *per_out = per;
@@ -751,16 +970,83 @@ static long group_ws_offset(const ss_gemm_problem* pr, int j) {  // floats in fr
   return off;
 }
 
+// The wide-tile form (namespace wide) of a group: K slices chosen here, from the shapes and the chip's CU count alone, so that the
+// workgroups of all problems together fill the chip once (one 512-thread workgroup per CU); `splits` of the records is ignored.
+static const bool ss_gemm_dw_wide = getenv("SS_GEMM_DW_WIDE") == nullptr || atoi(getenv("SS_GEMM_DW_WIDE")) != 0;
+static bool wide_plan(const ss_gemm_problem* pr, int n, wide::WideGroup* out, long* floats) {
+  using namespace wide;
+  long work = 0;
+  for (int j = 0; j < n; ++j) work += (long)ceil_div(pr[j].M, WT) * ceil_div(pr[j].N, WT) * pr[j].batch * pr[j].K;
+  // k rows per workgroup: the chip's share of the work, raised until the workgroups of the group fit the chip in ONE round (a
+  // workgroup holds a CU: 264 of them on 256 CUs took twice as long as 252 -- layer 0 of config 2, first version)
+  long kt = work / ss_device_cus() > 4 * BK ? work / ss_device_cus() : 4 * BK;
+  auto slices = [&](int K, long kt_, int* ksplit) {
+    int nz = (int)((K + kt_ / 2) / kt_);
+    nz = nz < 1 ? 1 : nz;
+    int ks = ceil_div(ceil_div(K, nz), BK) * BK;
+    if (ks < 4 * BK) ks = 4 * BK;
+    if (ksplit) *ksplit = ks;
+    return ceil_div(K, ks);
+  };
+  for (int it = 0; it < 64; ++it) {
+    long wgs = 0;
+    for (int j = 0; j < n; ++j) wgs += (long)ceil_div(pr[j].M, WT) * ceil_div(pr[j].N, WT) * pr[j].batch * slices(pr[j].K, kt, nullptr);
+    if (wgs <= ss_device_cus()) break;
+    kt += kt / 32 + 1;
+  }
+  long off = 0;
+  int first = 0, rfirst = 0;
+  for (int j = 0; j < n; ++j) {
+    const ss_gemm_problem& q = pr[j];
+    WideProblem w;
+    w.A = q.A; w.B = q.B; w.C = q.C;
+    w.M = q.M; w.N = q.N; w.K = q.K; w.lda = q.lda; w.ldb = q.ldb; w.ldc = q.ldc;
+    w.ra = RowMap{q.a_group, q.a_gstride, q.a_off};
+    w.rb = RowMap{q.b_group, q.b_gstride, q.b_off};
+    w.nz = slices(q.K, kt, &w.ksplit);
+    w.gx = ceil_div(q.N, WT); w.gy = ceil_div(q.M, WT); w.batch = q.batch;
+    w.sA = q.stride_a; w.sB = q.stride_b; w.sC = q.stride_c;
+    w.ws_off = off;
+    const int wgs = w.gx * w.gy * w.batch * w.nz;
+    off += (long)wgs * W_SLAB;
+    if (out) {
+      out->p[j] = w;
+      out->first[j] = first; out->rfirst[j] = rfirst;
+    }
+    first += wgs;
+    rfirst += w.gx * w.gy * w.batch * W_Q;
+  }
+  if (out) {
+    out->n = n;
+    for (int j = n; j <= GEMM_GROUP_MAX; ++j) { out->first[j] = first; out->rfirst[j] = rfirst; }
+    for (int j = n; j < GEMM_GROUP_MAX; ++j) out->p[j] = out->p[0];
+  }
+  if (floats) *floats = off;
+  // what the DMA ring and the row clamps need: k-major operands, 16-byte aligned, row counts that are multiples of 4
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  bool ok = ss_gemm_dw_wide && !ss_gemm_no_dma;
+  for (int j = 0; j < n; ++j) {
+    const ss_gemm_problem& q = pr[j];
+    ok = ok && !q.a_kcontig && !q.b_kcontig && al16(q.A) && al16(q.B) && (q.lda & 3) == 0 && (q.ldb & 3) == 0 &&
+         (q.stride_a & 3) == 0 && (q.stride_b & 3) == 0 && q.M >= 4 && (q.M & 3) == 0 && q.N >= 4 && (q.N & 3) == 0;
+  }
+  return ok;
+}
+
 extern "C" int ss_gemm_splitk_group_ws_floats(const ss_gemm_problem* problems, int n, long* floats) {
   SS_REQUIRE(problems && floats && n >= 1 && n <= GEMM_GROUP_MAX, SS_ERR_ARG);
   for (int j = 0; j < n; ++j)
     SS_REQUIRE(problems[j].M > 0 && problems[j].N > 0 && problems[j].K > 0 && problems[j].splits >= 1 && problems[j].batch >= 1,
                SS_ERR_ARG);
-  *floats = group_ws_offset(problems, n);
+  // enough for either form of the launch: which one runs is decided from the operands' alignment at call time
+  long wide_floats = 0;
+  wide_plan(problems, n, nullptr, &wide_floats);
+  const long narrow = group_ws_offset(problems, n);
+  *floats = wide_floats > narrow ? wide_floats : narrow;
   return SS_OK;
 }
 
-extern "C" int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, long ws_floats, ss_stream_t stream) {
+extern "C" int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, float* ws, long ws_floats, int flags, ss_stream_t stream) {
   SS_REQUIRE(problems && ws && n >= 1 && n <= GEMM_GROUP_MAX, SS_ERR_ARG);
   {
     long need = 0;
@@ -769,6 +1055,26 @@ extern "C" int ss_gemm_f32_splitk_group(const ss_gemm_problem* problems, int n, 
     SS_REQUIRE(ws_floats >= need, SS_ERR_ARG);
   }
   SS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, SS_ERR_ARG);
+  {
+    wide::WideGroup wg;
+    if ((flags & 1) && wide_plan(problems, n, &wg, nullptr)) {
+      for (int j = 0; j < n; ++j) SS_REQUIRE(problems[j].C && problems[j].ldc >= problems[j].N, SS_ERR_ARG);
+      wg.ws = ws;
+      static bool attr_set = false;
+      constexpr size_t wide_lds = (size_t)DSTAGES * wide::W_STAGE * sizeof(float);
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wide::gemm_wide_group_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds) != hipSuccess)
+          return SS_ERR_LAUNCH;
+        attr_set = true;
+      }
+      hipStream_t s = static_cast<hipStream_t>(stream);
+      hipLaunchKernelGGL(wide::gemm_wide_group_kernel, dim3((unsigned)wg.first[n]), dim3(wide::WNT), wide_lds, s, wg);
+      if (ss_launch_status() != SS_OK) return SS_ERR_LAUNCH;
+      hipLaunchKernelGGL(wide::gemm_wide_reduce_kernel, dim3((unsigned)wg.rfirst[n]), dim3(wide::WNT), 0, s, wg);
+      return ss_launch_status();
+    }
+  }
   GemmGroup gg;
   ReduceGroup rg;
   gg.n = rg.n = n;

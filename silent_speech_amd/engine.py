@@ -82,6 +82,10 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, accumulate=Fal
 
 
 _SPLITK_TARGET = int(os.environ.get("SS_SPLITK_TARGET", "768"))
+# Layer 0's weight-gradient group runs when no recurrence is left to share the chip with: wide 192 x 192 tiles, one workgroup per
+# CU (ss_gemm_f32_splitk_group flags bit 0).  The upper layers' groups run beside the BPTT kernel of the layer below and keep the
+# 128 x 64 form: measured in the step, the wide form there made the launch 12 % shorter and the step 1 % longer.
+DW_WIDE_ALONE = int(os.environ.get("SS_DW_WIDE_ALONE", "1"))
 
 
 _DX_SPLIT_CAP = int(os.environ.get("SS_DX_SPLITS", "2"))  # K slices of a d layer_in GEMM with few output tiles (1 = off)
@@ -371,7 +375,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             with torch.cuda.stream(side):
                 side.wait_event(ws.ev_fork)
                 L.call("ss_gemm_f32_splitk_group", *L.gemm_group(dw_problems(ws, G, cfg, l, lin, ld_in)), ws.splitk_ws.data_ptr(),
-                       ws.splitk_ws.numel(), L.stream(), tag="gemm_gru_dW")
+                       ws.splitk_ws.numel(), DW_WIDE_ALONE if l == 0 else 0, L.stream(), tag="gemm_gru_dW")
         # the weight-gradient GEMMs of the upper layers start only when this layer's d layer_in GEMM is through: two
         # MFMA-bound GEMMs side by side gain nothing and the one on the critical path loses half its rate; beside the
         # latency-bound recurrence of the layer below they fill idle matrix pipes.  Layer 0 has no recurrence left to

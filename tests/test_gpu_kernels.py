@@ -136,10 +136,12 @@ def test_gemm_splitk_workspace(L, M, N, K, splits, batch):
     assert torch.isnan(ws[need:]).all(), "wrote past the advertised workspace size"
 
 
-@pytest.mark.parametrize("aligned", [True, False])
-def test_gemm_splitk_group(L, aligned):
+@pytest.mark.parametrize("aligned,wide", [(True, 0), (False, 0), (True, 1), (False, 1)])
+def test_gemm_splitk_group(L, aligned, wide):
     """Three split-K problems of different shapes, K and row maps in one grouped launch == each alone (fp64 reference).
-    ``aligned=False`` gives one problem an odd leading dimension: the whole group then takes the problem-by-problem fallback."""
+    ``aligned=False`` gives one problem an odd leading dimension: the whole group then takes the problem-by-problem fallback.
+    ``wide=1``: flags bit 0, the 192 x 192-tile form for launches that have the chip to themselves (ragged last k tile, rows past
+    M / N clamped, both row maps)."""
     g = torch.Generator().manual_seed(11)
     Bc, T = 40, 9  # K slices of >= 64 rows, or the DMA-fed kernel (and with it the grouped launch) is not taken
     Nrows = Bc * T
@@ -169,11 +171,14 @@ def test_gemm_splitk_group(L, aligned):
     need = L.gemm_group_ws_floats(probs)
     ws = torch.full((need + 8,), float("nan"), device="cuda")
     arr, n = L.gemm_group(probs)
-    L.call("ss_gemm_f32_splitk_group", arr, n, ws.data_ptr(), ws.numel(), L.stream())
+    L.call("ss_gemm_f32_splitk_group", arr, n, ws.data_ptr(), ws.numel(), wide, L.stream())
     sync()
     for j in range(3):
         assert_close(f"group problem {j}", outs[j], refs[j], atol=3e-4, rtol=1e-5)
     assert torch.isnan(ws[need:]).all(), "wrote past the advertised workspace size"
+    # a scratch buffer that is too short is refused, not overrun
+    with pytest.raises(RuntimeError):
+        L.call("ss_gemm_f32_splitk_group", arr, n, ws.data_ptr(), need - 1, wide, L.stream())
 
 
 @pytest.mark.parametrize("M,N,K,ldb_extra", [(7680, 384, 576, 0), (300, 32, 200, 84), (130, 70, 50, 3)])
