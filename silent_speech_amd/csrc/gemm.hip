@@ -669,6 +669,31 @@ struct WideGroup {
   int n;
 };
 
+// The k loop of both wide kernels: all eight waves in lockstep -- wait for the own DMA pieces of tile t, barrier, refill of the
+// buffer tile t - 1 left, fragments of tile t, 72 MFMAs.  MEASURED AND NOT USED: the bf16 ring kernel's ping-pong (waves 4..7 one
+// barrier behind waves 0..3, one half reading fragments / issuing DMA while the other multiplies; two barriers per tile, hazards
+// worked out and the tests green): layer 1's weight gradients 112.8 -> 130.7 us, layer 0's 82.8 -> 94.9, the input projections
+// 0.1045 -> 0.1082 ms per step.  With f32 MFMAs the half that reads is starved by the half that multiplies (a saturated
+// v_mfma_f32_16x16x4_f32 stream leaves the SIMD's other wave one vector instruction per ~180 cycles), so its
+// "read phase" stretches over the partner's whole MFMA burst instead of hiding under it; in lockstep both halves read with
+// nothing to contend with and then share the pipe.
+#define WIDE_K_LOOP                                                                                                      \
+  {                                                                                                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < DSTAGES - 1; ++s_) if (s_ < nfull) issue(s_);                                \
+    for (int t0 = 0; t0 < nfull; t0 += DSTAGES) {                                                                        \
+      _Pragma("unroll") for (int s_ = 0; s_ < DSTAGES; ++s_) {                                                           \
+        const int t = t0 + s_;                                                                                           \
+        if (t < nfull) {                                                                                                 \
+          if (t + DSTAGES - 2 < nfull) ss_vmcnt_wait<(DSTAGES - 2) * W_LPW>(); else ss_vmcnt_wait<0>();                  \
+          ss_raw_barrier();                                                                                              \
+          if (t + DSTAGES - 1 < nfull) issue((s_ + DSTAGES - 1) % DSTAGES);                                              \
+          read(dlds + s_ * W_STAGE);                                                                                     \
+          mma();                                                                                                         \
+        }                                                                                                                \
+      }                                                                                                                  \
+    }                                                                                                                    \
+  }
+
 // one wave's three DMA pieces of a k tile: piece q = wave + 8 n of the 24 (A: 0..11, B: 12..23)
 struct WidePieces {
   const float* src[W_LPW];
@@ -766,9 +791,8 @@ __global__ __launch_bounds__(WNT) void gemm_wide_group_kernel(WideGroup gg) {
     dp.issue((unsigned)(buf * W_STAGE * 4));
     dp.advance();
   };
-  auto compute = [&](const float* st, int refill) {
-    if (refill >= 0) issue(refill);
-    float a[3][4], b[6][4];
+  float a[3][4], b[6][4];
+  auto read = [&](const float* st) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -776,6 +800,8 @@ __global__ __launch_bounds__(WNT) void gemm_wide_group_kernel(WideGroup gg) {
 #pragma unroll
       for (int nt = 0; nt < 6; ++nt) b[nt][kk] = st[offB[nt] + kk * WT];
     }
+  };
+  auto mma = [&]() {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -783,26 +809,13 @@ __global__ __launch_bounds__(WNT) void gemm_wide_group_kernel(WideGroup gg) {
 #pragma unroll
         for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = mfma16(a[mt][kk], b[nt][kk], acc[mt][nt]);
   };
-#pragma unroll
-  for (int s_ = 0; s_ < DSTAGES - 1; ++s_)
-    if (s_ < nfull) issue(s_);
-  for (int t0 = 0; t0 < nfull; t0 += DSTAGES) {
-#pragma unroll
-    for (int s_ = 0; s_ < DSTAGES; ++s_) {
-      const int t = t0 + s_;
-      if (t < nfull) {
-        if (t + DSTAGES - 2 < nfull) ss_vmcnt_wait<(DSTAGES - 2) * W_LPW>();
-        else ss_vmcnt_wait<0>();
-        ss_raw_barrier();
-        compute(dlds + s_ * W_STAGE, t + DSTAGES - 1 < nfull ? (s_ + DSTAGES - 1) % DSTAGES : -1);
-      }
-    }
-  }
+  WIDE_K_LOOP
   if (rem) {
     __syncthreads();
     dp.tail(dlds, rem);
     __syncthreads();
-    compute(dlds, -1);
+    read(dlds);
+    mma();
   }
   // raw accumulators as they lie in the registers: 18 coalesced 16-byte stores per thread
   f32x4* w = reinterpret_cast<f32x4*>(gg.ws + P.ws_off) + (long)local * (W_Q * WNT) + threadIdx.x;
@@ -847,6 +860,140 @@ __global__ __launch_bounds__(WNT) void gemm_wide_reduce_kernel(WideGroup gg) {
   for (int rr = 0; rr < 4; ++rr) {
     const int row = by * WT + wm * 48 + mt * 16 + 4 * g + rr;
     if (row < P.M) P.C[bi * P.sC + (long)row * P.ldc + col] += s0[rr];
+  }
+}
+
+// ---- the same tile for the GRU input projections: C[M][N] = A[M][K] B[N][K]^T + bias, both operands [row][k] (k contiguous), M = B T
+// rows.  128 x 64 tiles made 1 080 workgroups of the 7 680 x 576 x 2-direction problem -- 1.4 rounds of the chip at three per CU --
+// with 24 LDS reads per 32 MFMAs; 192 x 192 tiles make 240 workgroups, ONE round at one per CU, and a lane's four k-steps of an
+// operand row are one ds_read_b128 (9 LDS reads per 72 MFMAs).  [row][16 k] images, unit s of row r holds k unit s ^ kc_swz(r)
+// (the source-side swizzle of the DMA kernels above); the output tile leaves through the ring's LDS in two 96-column halves so
+// that a row is written as 384 contiguous bytes.
+struct WideKcParams {
+  const float *A, *B, *bias;
+  float* C;
+  int M, N, K, lda, ldb, ldc, gx, gy;
+  long sA, sB, sC, sBias;
+};
+struct WidePiecesKc {
+  const float* src[W_LPW];
+  __device__ __forceinline__ void init(const WideKcParams& P, const float* A, const float* B, int m0, int n0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < W_LPW; ++n) {
+      const int piece = wave + WNWV * n;
+      const bool isb = piece >= W_PIECES;
+      const int sl = (piece - (isb ? W_PIECES : 0)) * 64 + lane;  // 16-byte slot of the [row][16 k] image
+      const int rr = sl >> 2, ku = (sl & 3) ^ kc_swz(rr);
+      const int nrows = isb ? P.N : P.M, row0 = isb ? n0 : m0;
+      const int gr = min(row0 + rr, nrows - 1);  // rows past the end feed accumulators nobody stores
+      src[n] = (isb ? B + (long)gr * P.ldb : A + (long)gr * P.lda) + 4 * ku;
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned stage_byte) const {
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < W_LPW; ++n) ss_dma16(src[n], stage_byte + (wave + WNWV * n) * 1024);
+  }
+  __device__ __forceinline__ void advance() {
+#pragma unroll
+    for (int n = 0; n < W_LPW; ++n) src[n] += BK;
+  }
+  __device__ __forceinline__ void tail(float* img, int kvalid) const {  // ragged last tile through registers, zeros past K
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < W_LPW; ++n) {
+      const int piece = wave + WNWV * n;
+      const int sl = (piece % W_PIECES) * 64 + lane;
+      const int ku = (sl & 3) ^ kc_swz(sl >> 2);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * ku + e < kvalid) v[e] = src[n][e];
+      *reinterpret_cast<f32x4*>(img + piece * 256 + 4 * lane) = v;
+    }
+  }
+};
+
+__global__ __launch_bounds__(WNT) void gemm_wide_kc_kernel(WideKcParams P) {
+  extern __shared__ __attribute__((aligned(16))) float dlds[];
+  const int bx = blockIdx.x % P.gx, by = blockIdx.x / P.gx, bi = blockIdx.y;
+  const int m0 = by * WT, n0 = bx * WT;
+  const int nfull = P.K / BK, rem = P.K - nfull * BK;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1, i = lane & 15, g = lane >> 4;
+  WidePiecesKc dp;
+  dp.init(P, P.A + bi * P.sA, P.B + bi * P.sB, m0, n0);
+  int offA[3], offB[6];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) offA[mt] = (wm * 48 + mt * 16 + i) * BK + 4 * (g ^ kc_swz(i));
+#pragma unroll
+  for (int nt = 0; nt < 6; ++nt) offB[nt] = WT * BK + (wn * 96 + nt * 16 + i) * BK + 4 * (g ^ kc_swz(i));
+  f32x4 acc[3][6];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issue = [&](int buf) {
+    dp.issue((unsigned)(buf * W_STAGE * 4));
+    dp.advance();
+  };
+  f32x4 a[3], b[6];
+  auto read = [&](const float* st) {
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(st + offA[mt]);
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(st + offB[nt]);
+  };
+  auto mma = [&]() {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = mfma16(a[mt][kk], b[nt][kk], acc[mt][nt]);
+  };
+  WIDE_K_LOOP
+  if (rem) {
+    __syncthreads();
+    dp.tail(dlds, rem);
+    __syncthreads();
+    read(dlds);
+    mma();
+  }
+  // output tile through LDS, one 96-column half (the waves with wn == h) at a time: rows leave as 24 x 16-byte stores
+  constexpr int LDS_C = 96 + 4;
+  static_assert(WT * LDS_C <= DSTAGES * W_STAGE, "half an output tile is staged in the k-tile ring");
+  float* Cb = P.C + bi * P.sC;
+  const float* bias = P.bias ? P.bias + bi * P.sBias : nullptr;
+  const bool vec_ok = (P.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();  // the last k tile (h = 0) / the previous half's rows (h = 1) have been read by everybody
+    if (wn == h) {
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+          const int col = nt * 16 + i, gc = n0 + h * 96 + col;
+          const float bv = (bias && gc < P.N) ? bias[gc] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dlds[(wm * 48 + mt * 16 + 4 * g + r) * LDS_C + col] = acc[mt][nt][r] + bv;
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < WT * 24; q += WNT) {
+      const int row = q / 24, c4 = 4 * (q % 24);
+      const int gr = m0 + row, gc = n0 + h * 96 + c4;
+      if (gr < P.M && gc < P.N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&dlds[row * LDS_C + c4]);
+        float* dst = Cb + (long)gr * P.ldc + gc;
+        if (vec_ok && gc + 4 <= P.N) *reinterpret_cast<f32x4*>(dst) = v;
+        else
+          for (int e = 0; e < 4; ++e)
+            if (gc + e < P.N) dst[e] = v[e];
+      }
+    }
   }
 }
 }  // namespace wide
@@ -946,6 +1093,31 @@ extern "C" int ss_gemm_f32_batched(int a_kcontig, int b_kcontig, int M, int N, i
     }
     p.kcat = batch;
     grid.z = p.nz;
+  }
+  // [row][k] x [row][k] with enough 192 x 192 output tiles to fill most of the chip in one round, plain store (+ bias): the
+  // wide-tile kernel (the GRU input projections; SS_GEMM_WIDE_KC=0: diagnostic)
+  static const bool wide_kc_on = getenv("SS_GEMM_WIDE_KC") == nullptr || atoi(getenv("SS_GEMM_WIDE_KC")) != 0;
+  if (dma_ok && wide_kc_on && a_kcontig && b_kcontig && !(flags & 31) && splits == 1 && p.ra.G == 0x7fffffff && p.ra.off == 0 &&
+      p.rb.G == 0x7fffffff && p.rb.off == 0 && (K & 3) == 0) {
+    const long tiles = (long)ceil_div(M, wide::WT) * ceil_div(N, wide::WT) * batch;
+    const int cus = ss_device_cus();
+    const long rounds = (tiles + cus - 1) / cus;
+    if (tiles * 10 >= rounds * cus * 8 && N >= 96) {  // the last round at least 80 % full
+      wide::WideKcParams w;
+      w.A = A; w.B = B; w.bias = bias; w.C = C; w.M = M; w.N = N; w.K = K; w.lda = lda; w.ldb = ldb; w.ldc = ldc;
+      w.gx = ceil_div(N, wide::WT); w.gy = ceil_div(M, wide::WT);
+      w.sA = stride_a; w.sB = stride_b; w.sC = stride_c; w.sBias = stride_bias;
+      constexpr size_t wide_lds = (size_t)DSTAGES * wide::W_STAGE * sizeof(float);
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wide::gemm_wide_kc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)wide_lds) != hipSuccess)
+          return SS_ERR_LAUNCH;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(wide::gemm_wide_kc_kernel, dim3((unsigned)(w.gx * w.gy), (unsigned)batch), dim3(wide::WNT), wide_lds, s, w);
+      return ss_launch_status();
+    }
   }
   if (dma_ok) {
     constexpr size_t lds_bytes = (size_t)DSTAGES * D_STAGE * sizeof(float);

@@ -87,6 +87,29 @@ def test_gemm_layouts(L, a_kc, b_kc, M, N, K, pad):
         assert torch.all(c_d[:, N:] == 7.0), "wrote outside the N columns"
 
 
+@pytest.mark.parametrize("M,N,K,batch,ldc_pad", [(7680, 576, 384, 2, 0), (7680, 576, 116, 2, 0), (1000, 200, 116, 20, 0),
+                                                 (1000, 200, 40, 20, 3), (23040, 576, 180, 2, 0)])
+def test_gemm_input_projection_wide_tiles(L, M, N, K, batch, ldc_pad):
+    """The GRU input projections (C = A B^T + bias, both operands [row][k], a batch of two directions sharing A) on the 192 x 192
+    wide-tile kernel: config 2's shapes, ragged K (116 = 7 x 16 + 4, 40), rows / columns past the last tile, an output whose
+    leading dimension rules out 16-byte stores, the shipped shape (T = 90, D = 180)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(batch, N, K, generator=g)
+    bias = torch.randn(batch, N, generator=g)
+    ldc = N + ldc_pad
+    a_d, b_d, bias_d = dev(A), dev(Bm), dev(bias)
+    c_d = torch.full((batch, M, ldc), 7.0, device="cuda")
+    L.call("ss_gemm_f32_batched", 1, 1, M, N, K, a_d.data_ptr(), K, INT_MAX, 0, 0, b_d.data_ptr(), K, INT_MAX, 0, 0, c_d.data_ptr(),
+           ldc, bias_d.data_ptr(), None, 0, 1, batch, 0, N * K, M * ldc, N, 0, L.stream())
+    sync()
+    for b in sorted({0, batch - 1, batch // 2}):
+        ref = (A.double() @ Bm[b].double().t() + bias[b].double()).float()
+        assert_close(f"input projection, batch entry {b}", c_d[b, :, :N], ref, atol=2e-5 * K ** 0.5, rtol=1e-5)
+    if ldc_pad:
+        assert torch.all(c_d[:, :, N:] == 7.0), "wrote outside the N columns"
+
+
 def test_gemm_accumulate_relu_splitk_rowmap(L):
     g = torch.Generator().manual_seed(5)
     # accumulate + relu
