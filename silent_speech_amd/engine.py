@@ -330,22 +330,28 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
            2 * H, MID, C, p_drop, seed, 7 << 40, ws.d_mid.data_ptr(), ws.d_out.data_ptr(),
            G["head.0.weight"].data_ptr(), G["head.0.bias"].data_ptr(), G["pool.score.weight"].data_ptr(),
            G["pool.score.bias"].data_ptr(), ws.tail_part.data_ptr(), s)
-    # ... while the two Linear weight gradients (batched over the clips) go to the side stream
+    # ... while the two Linear weight gradients (batched over the clips) go to the side stream.  The fork event is recorded here,
+    # the side stream's launches are ENQUEUED behind the top layer's BPTT launch (head_side_work, called in the loop below): the
+    # host needs ~30 us for these seven launches and the main queue sat empty meanwhile (15 us between tail_bwd and the BPTT
+    # kernel in the kernel trace, tools/step_gaps.py; 6 us of it is the event's barrier packet and stays)
     side = ws.side if USE_SIDE_STREAM else torch.cuda.current_stream()
     ws.ev_fork.record()
-    with torch.cuda.stream(side):
-        side.wait_event(ws.ev_fork)
-        # the atomically summed destinations of the d layer_in GEMMs: cleared here, off the critical path, and first --
-        # the top layer's d layer_in GEMM waits for them
-        zero_buffers(ws.d_lower[1:] + ([ws.dZ] if cfg.use_roi else []))
-        ws.ev_zero.record()
-        # LayerNorm gamma / beta and score-weight gradients: column sums of the rows the tail kernel left per clip
-        for k_, name_ in enumerate(("head.0.weight", "head.0.bias", "pool.score.weight")):
-            L.call("ss_colsum_f32", _addr(ws.tail_part, k_ * 2 * H), B, 2 * H, 3 * 2 * H, G[name_].data_ptr(), L.stream())
-        gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, ws.mid_drop.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
-             accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
-        gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
-             2 * H, accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
+
+    def head_side_work():
+        with torch.cuda.stream(side):
+            side.wait_event(ws.ev_fork)
+            # the atomically summed destinations of the d layer_in GEMMs: cleared here, off the critical path, and first --
+            # the top layer's d layer_in GEMM waits for them
+            zero_buffers(ws.d_lower[1:] + ([ws.dZ] if cfg.use_roi else []))
+            ws.ev_zero.record()
+            # LayerNorm gamma / beta and score-weight gradients: column sums of the rows the tail kernel left per clip
+            for k_, name_ in enumerate(("head.0.weight", "head.0.bias", "pool.score.weight")):
+                L.call("ss_colsum_f32", _addr(ws.tail_part, k_ * 2 * H), B, 2 * H, 3 * 2 * H, G[name_].data_ptr(), L.stream())
+            gemm(0, 0, C, MID, B, d_logits.data_ptr(), C, ws.mid_drop.data_ptr(), MID, G["head.4.weight"].data_ptr(), MID,
+                 accumulate=True, atomic=True, a_colsum=G["head.4.bias"].data_ptr())
+            gemm(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(),
+                 2 * H, accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
+
     # ---- GRU layers, top down
     use_drop = train and cfg.gru_dropout > 0.0
     zero_waited = False
@@ -360,6 +366,8 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
                0.0 if (top_layer or not use_drop) else cfg.gru_dropout, seed, (l + 1) << 40,
                G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
                G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), L.ptr(ws.gru_sync), s)
+        if top_layer:
+            head_side_work()
         if l == 0:
             if cfg.use_roi:
                 lin, ld_in = ws.Z.data_ptr(), cfg.in_dim

@@ -319,13 +319,19 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
         gemm_f32(0, 0, MID, 2 * H, B, ws.d_mid.data_ptr(), MID, ws.ln.data_ptr(), 2 * H, G["head.1.weight"].data_ptr(), 2 * H,
                  accumulate=True, atomic=True, a_colsum=G["head.1.bias"].data_ptr())
 
+    # the fork event is recorded here, the side stream's launches are enqueued behind the top layer's BPTT launch (below): the host
+    # needs tens of microseconds for them and the main queue sat empty meanwhile (engine.backward, tools/step_gaps.py)
     if USE_SIDE_STREAM:
         ws.ev_fork.record()
-        with torch.cuda.stream(ws.side):
-            ws.side.wait_event(ws.ev_fork)
+
+    def head_side_work():
+        if USE_SIDE_STREAM:
+            with torch.cuda.stream(ws.side):
+                ws.side.wait_event(ws.ev_fork)
+                head_grads()
+        else:
             head_grads()
-    else:
-        head_grads()
+
     zero_waited = False
     dw_pending = []
     use_drop = train and cfg.gru_dropout > 0.0
@@ -339,6 +345,8 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg, ws: Wo
                (l + 1) << 40, G[f"gru.bias_ih_l{l}"].data_ptr(), G[f"gru.bias_hh_l{l}"].data_ptr(),
                G[f"gru.bias_ih_l{l}_reverse"].data_ptr(), G[f"gru.bias_hh_l{l}_reverse"].data_ptr(), ws.gru_ws.data_ptr(),
                L.ptr(ws.gru_sync), L.nbytes(ws.gru_sync), s)
+        if top_layer:
+            head_side_work()
         Kp = ws.kp[l]
         lin = (ws.lin_bf0 if l == 0 else ws.lin_bf[l]).data_ptr()  # what the forward pass multiplied W_ih with (dropped out or not)
         dg = ws.dG_bf[l].data_ptr()
