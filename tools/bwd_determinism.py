@@ -17,7 +17,8 @@ def main():
     torch.manual_seed(0)
     m = ss.BiGRUClassifier(84, 5, use_roi=True).to(dev).train()
     X = torch.randn(B, T, 84, device=dev)
-    R = torch.randint(0, 256, (B, T, 64, 64), device=dev, dtype=torch.uint8)
+    hh, ww = (int(v) for v in os.environ.get("AB_ROI", "64,64").split(","))  # 48,96 = the reference's ROI
+    R = torch.randint(0, 256, (B, T, hh, ww), device=dev, dtype=torch.uint8)
     lengths = torch.full((B,), T, device=dev)
     y = torch.randint(0, 5, (B,), device=dev)
     names = [n for n, _ in m.named_parameters() if n.startswith("roi_cnn")]
