@@ -64,6 +64,26 @@ int ss_feature_fuse_stream(const float* lm, const int32_t* stream_ids, const uin
                            double band_hi, float* prev_lm, uint8_t* has_prev, float* X, int ldx, float* center,
                            double* fourth, uint8_t* kept, ss_stream_t stream);
 
+/* ---- a4 + a5 for ANY ROI size (csrc/roi_cnn_generic.hip): the building blocks of the layer-by-layer form the host sequences for
+ * frame sizes outside the fused kernels' set (ss_roi_cnn_stash_size returns SS_ERR_UNSUPPORTED for them): every 3x3 convolution is
+ * ss_im2col3x3 + ss_gemm_f32_batched against nn.Conv2d's weight as it stands ((Cout, C, 3, 3) = [n][k], k = c*9 + ky*3 + kx).
+ *   ss_roi_norm    R (N, HW) u8 -> xn (N, HW) f32 = (u/255 - mu)/sd (train_model_official.py:286-291; standardize 0: u/255);
+ *                  stats (N, 2) = mu, sd or NULL
+ *   ss_im2col3x3   src (N, C, H, W) planar -> col (N H W, ld_col >= 9 C), zero padding at the borders and in columns [9 C, ld_col)
+ *   ss_relu_pool2  y (N H W, C) pixel-major pre-activation -> a (N, C, H/2, W/2) = maxpool(relu(y)), idx = winner of the 2x2 window
+ *                  (0..3 row-major, the first on ties)
+ *   ss_relu_mean   y (N P, C) -> feat (N, C) = mean over the P pixels of relu(y); mask (N P, C) = y > 0 (NULL: not written)
+ *   ss_mask_scale  dy (N P, C) = mask ? dfeat[n][c] / P : 0
+ *   ss_col2im3x3   dcol (N H W, ld_col) -> d (N, C, H, W): the transposed convolution's gather
+ *   ss_pool2_bwd   da, a, idx (N, C, H2, W2) -> dy (N 2H2 2W2, C) pixel-major: the winner gets da where a > 0, zeros elsewhere */
+int ss_roi_norm(const uint8_t* R, int N, int HW, int standardize, float* xn, float* stats, ss_stream_t stream);
+int ss_im2col3x3(const float* src, int N, int C, int H, int W, float* col, int ld_col, ss_stream_t stream);
+int ss_relu_pool2(const float* y, int N, int C, int H, int W, float* a, uint8_t* idx, ss_stream_t stream);
+int ss_relu_mean(const float* y, int N, int P, int C, float* feat, uint8_t* mask, ss_stream_t stream);
+int ss_mask_scale(const uint8_t* mask, const float* dfeat, int N, int P, int C, float* dy, ss_stream_t stream);
+int ss_col2im3x3(const float* dcol, int ld_col, int N, int C, int H, int W, float* d, ss_stream_t stream);
+int ss_pool2_bwd(const float* da, const float* a, const uint8_t* idx, int N, int C, int H2, int W2, float* dy, ss_stream_t stream);
+
 /* ---- a2: ROI crop rectangle ---------------------------------------------------------------
  * replaces the index arithmetic of crop_roi (record_landmarks_official.py:106-114, variant 0) and
  * crop_roi_gray (live_infer_official.py:172-181, variant 1).  Bit-exact integers.

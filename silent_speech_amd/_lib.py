@@ -27,6 +27,13 @@ SIGNATURES = {
     "ss_status_string": [_i],
     "ss_feature_fuse": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "ss_feature_fuse_stream": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "ss_roi_norm": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "ss_im2col3x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp],
+    "ss_relu_pool2": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "ss_relu_mean": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "ss_mask_scale": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "ss_col2im3x3": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "ss_pool2_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ss_roi_crop_idx": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ss_roi_cnn_fwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i, _vp],
     "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_vp, _vp],

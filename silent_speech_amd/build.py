@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libss_hotpath.so")
-SOURCES = ["features.hip", "batch.hip", "stream.hip", "crop_resize.hip", "roi_cnn.hip", "roi_cnn_bwd.hip", "gemm.hip", "gru.hip", "pool_head.hip", "tail.hip", "optim.hip", "gemm_bf16.hip", "gru_bf16.hip", "cnn_bf16.hip", "cnn_bf16_bwd.hip"]
+SOURCES = ["features.hip", "batch.hip", "stream.hip", "crop_resize.hip", "roi_cnn.hip", "roi_cnn_bwd.hip", "roi_cnn_generic.hip", "gemm.hip", "gru.hip", "pool_head.hip", "tail.hip", "optim.hip", "gemm_bf16.hip", "gru_bf16.hip", "cnn_bf16.hip", "cnn_bf16_bwd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
 
 

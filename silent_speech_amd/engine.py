@@ -195,6 +195,13 @@ class Workspace:
         self.ev_cnn_fwd = torch.cuda.Event() if train else None  # recorded after the ROI-CNN forward (micro-batch stagger)
         self.stagger = False  # set by the trainer when another micro-batch waits for ev_cnn_fwd
         self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
+        # ROI sizes the fused, LDS-resident CNN kernels are not built for run layer by layer (cnn_generic.py)
+        self.cnn_generic = None
+        if cfg.use_roi:
+            from . import cnn_generic
+
+            if not cnn_generic.fused_supported(*roi_hw):
+                self.cnn_generic = cnn_generic.GenericCnn(N, roi_hw[0], roi_hw[1], device, train)
         self.gi = [torch.empty(2, N, 3 * H, **f32) for _ in range(cfg.gru_layers)]
         self.out = [torch.empty(N, 2 * H, **f32) for _ in range(cfg.gru_layers)]
         self.attn = torch.empty(B, T, **f32)
@@ -227,7 +234,7 @@ class Workspace:
             self.d_ln = torch.empty(B, 2 * H, **f32)
             self.d_pooled = torch.empty(B, 2 * H, **f32)
             self.dZ = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
-            if cfg.use_roi:
+            if cfg.use_roi and self.cnn_generic is None:
                 Hh, Ww = roi_hw
                 # every size comes from the library (the kernels' own LDS images, kept as they are) and goes back to it with
                 # each launch, where the forward and the backward object compare it with the layout they were compiled with
@@ -261,13 +268,16 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
         ws_Z = ws.Z
         if not x_in_place:  # (the trainer's prologue kernel has already put X there)
             L.call("ss_copy_rows_f32", X.data_ptr(), cfg.x_dim, ws_Z.data_ptr(), cfg.in_dim, N, cfg.x_dim, s)
-        cw = [P[k].data_ptr() for k in ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight",
-                                        "roi_cnn.net.3.bias", "roi_cnn.net.6.weight", "roi_cnn.net.6.bias",
-                                        "roi_cnn.fc.weight", "roi_cnn.fc.bias")]
-        st = ([ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
-               ws.st_m3.data_ptr(), ws.st_feat.data_ptr()] if stash else [None] * 6)
-        L.call("ss_roi_cnn_fwd_stash", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
-               _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, ws.cnn_sizes.ptr if stash else None, s)
+        if ws.cnn_generic is not None:  # an ROI size outside the fused kernels' set: layer by layer (cnn_generic.py)
+            ws.cnn_generic.forward(P, R, cfg.roi_standardize, cfg.roi_emb, _addr(ws_Z, cfg.x_dim), cfg.in_dim, stash)
+        else:
+            cw = [P[k].data_ptr() for k in ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight",
+                                            "roi_cnn.net.3.bias", "roi_cnn.net.6.weight", "roi_cnn.net.6.bias",
+                                            "roi_cnn.fc.weight", "roi_cnn.fc.bias")]
+            st = ([ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
+                   ws.st_m3.data_ptr(), ws.st_feat.data_ptr()] if stash else [None] * 6)
+            L.call("ss_roi_cnn_fwd_stash", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
+                   _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, ws.cnn_sizes.ptr if stash else None, s)
         if ws.train and ws.stagger:  # an event record is a barrier packet on this stream (~6 us): only when somebody waits for it
             ws.ev_cnn_fwd.record()
         layer_in, ld_in = ws_Z.data_ptr(), cfg.in_dim
@@ -434,10 +444,13 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             side_joined = True
         names = ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight", "roi_cnn.net.3.bias",
                  "roi_cnn.net.6.weight", "roi_cnn.net.6.bias", "roi_cnn.fc.weight", "roi_cnn.fc.bias")
-        L.call("ss_roi_cnn_bwd", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
-               cfg.roi_emb, ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
-               ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), ws.cnn_sizes.ptr, _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
-               *[G[k].data_ptr() for k in names], s)
+        if ws.cnn_generic is not None:
+            ws.cnn_generic.backward(P, G, cfg.roi_emb, _addr(ws.dZ, cfg.x_dim), cfg.in_dim)
+        else:
+            L.call("ss_roi_cnn_bwd", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
+                   cfg.roi_emb, ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
+                   ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), ws.cnn_sizes.ptr, _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
+                   *[G[k].data_ptr() for k in names], s)
     # join the side stream: the caller's next kernels (all-reduce, clip, Adam) read every gradient
     if USE_SIDE_STREAM and not side_joined:
         ws.ev_join.record(ws.side)

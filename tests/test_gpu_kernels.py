@@ -159,6 +159,20 @@ def test_gemm_splitk_workspace(L, M, N, K, splits, batch):
     assert torch.isnan(ws[need:]).all(), "wrote past the advertised workspace size"
 
 
+@pytest.mark.parametrize("rows,cols,lda", [(300000, 8, 8), (131072, 16, 16), (70001, 24, 24), (50000, 24, 40), (777, 384, 1152)])
+def test_colsum(L, rows, cols, lda):
+    """out[c] += sum_r A[r][c]: the tall-and-narrow packed form (flat stream, the per-pixel gradients of the layer-by-layer CNN)
+    and the general strided one."""
+    g = torch.Generator().manual_seed(rows + cols)
+    A = torch.randn(rows, lda, generator=g)
+    out0 = torch.randn(cols, generator=g)
+    a_d, o_d = dev(A), dev(out0)
+    L.call("ss_colsum_f32", a_d.data_ptr(), rows, cols, lda, o_d.data_ptr(), L.stream())
+    sync()
+    ref = (out0.double() + A[:, :cols].double().sum(0)).float()
+    assert_close("colsum", o_d, ref, atol=2e-5 * rows ** 0.5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("aligned,wide", [(True, 0), (False, 0), (True, 1), (False, 1)])
 def test_gemm_splitk_group(L, aligned, wide):
     """Three split-K problems of different shapes, K and row maps in one grouped launch == each alone (fp64 reference).

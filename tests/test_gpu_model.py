@@ -435,6 +435,59 @@ def test_micro_batch_streams_match_oracle(ss):
         assert float((a - b).abs().max()) <= atol, k
 
 
+@pytest.mark.parametrize("roi_hw,chunk_rows", [((96, 96), None), ((40, 56), None), ((40, 56), 5000), ((20, 12), None)])
+def test_any_roi_size_runs_layer_by_layer(ss, roi_hw, chunk_rows, monkeypatch):
+    """ROI sizes outside the fused kernels' set (64x64, 48x96, 32x32) -- the reference takes whatever ROI_H x ROI_W its constants
+    say, SURVEY section 4 lists 96x96 among the parity variants -- run layer by layer (cnn_generic.py: im2col + GEMM, csrc/
+    roi_cnn_generic.hip): logits, every gradient and one fused train step against the oracle; ``chunk_rows`` forces several frame
+    chunks (incl. a ragged last one)."""
+    from silent_speech_amd import cnn_generic
+
+    if chunk_rows:
+        monkeypatch.setattr(cnn_generic, "MAX_GEMM_ROWS", chunk_rows)
+    B, T = 3, 5
+    sd = W.make_state_dict(12, 84, 5, True)
+    X, Lh, R, y = W.make_inputs(12, B, T, 84, 5, roi_hw, lengths=[5, 3, 1])
+    # a constant frame takes the std clamp.  Only the all-zero one is a parity target at these sizes: for a constant u > 0 the
+    # reference's float32 mean of H W copies of fl(u/255) is exact when H W is a power of two (64 x 64) and off by rounding
+    # otherwise, and the clamp divides that rounding noise by 1e-6 -- the kernels (integer sums: exactly 0) are then the more
+    # accurate side of a comparison that means nothing
+    R[0, 0] = 0
+    m = ss.BiGRUClassifier(84, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    logits = m(X.cuda(), Lh.cuda(), R.cuda())
+    ref = MR.forward(sd, X, Lh, R)
+    assert float((logits.detach().cpu() - ref).abs().max()) < TIGHT
+    assert any(w.cnn_generic is not None for w in m._ws_cache.values()), "the fused kernels took a shape they are not built for"
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda(), label_smoothing=0.05)
+    loss.backward()
+    l_ref, _, grads = MR.loss_and_grads(sd, X, Lh, R, y)
+    assert abs(float(loss) - float(l_ref)) < 2e-5
+    for k, p in m.named_parameters():
+        got, want = p.grad.cpu(), grads[k]
+        if k == "pool.score.bias":
+            assert float(got.abs().max()) < 1e-6
+            continue
+        scale = max(float(want.abs().max()), 1e-4)
+        bad = (got - want).abs() > 2e-4 * scale + 2e-3 * want.abs()
+        assert not bad.any(), f"{k}: max err {float((got - want).abs().max()):.3e} vs scale {scale:.3e}"
+    # the fused trainer takes the same path
+    m2 = ss.BiGRUClassifier(84, 5, use_roi=True)
+    m2.load_state_dict(sd)
+    m2.cuda().train()
+    tr = ss.Trainer(m2, dropout=False)
+    l2, _ = tr.step(X.cuda(), Lh.cuda(), R.cuda(), y.cuda())
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    l2_ref, _, _, _ = MR.train_step(sd2, {}, X, Lh, R, y, impl="explicit")
+    assert abs(float(l2) - float(l2_ref)) < 2e-5
+    with torch.no_grad():
+        after = m2.eval()(X.cuda(), Lh.cuda(), R.cuda()).cpu()
+    assert float((after - MR.forward(sd2, X, Lh, R)).abs().max()) < 1e-3
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        ss.BiGRUClassifier(84, 5, use_roi=True).cuda()(X.cuda(), Lh.cuda(), torch.zeros(B, T, 30, 44, dtype=torch.uint8).cuda())
+
+
 def test_full_size_properties(ss):
     """BASELINE config 2 at full size (B=256): properties that need no oracle run."""
     B, T = 256, 30
