@@ -501,7 +501,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
-    ap.add_argument("--mode", choices=["train", "infer", "assemble", "stream", "crop"], default="train",
+    ap.add_argument("--mode", choices=["train", "infer", "assemble", "stream", "crop", "live"], default="train",
                     help="train = the headline metric; infer = BASELINE config 4 (T=60, B=4096 windows, forward-only, hipGraph)")
     ap.add_argument("--micro-batches", type=int, default=1, help="slices of the per-GPU batch kept in flight on separate streams")
     ap.add_argument("--config", type=int, choices=[2, 5], default=2,
@@ -645,6 +645,46 @@ def main():
                           "data": "synthetic", "frames_ingested_per_sec": round(2 * args.steps * S / el, 1),
                           "config": {"workload": "SURVEY 8f-4: %d streams x T=%d, one frame per stream and tick, prediction every "
                                                  "2nd tick, landmark + %dx%d ROI CNN + BiGRU forward" % (S, Ts, roi, roi)}}))
+        return
+    if args.mode == "live":
+        # the live chain as one device entry point (live_infer_official.py:264-296 per stream + the sliding-window rule): landmarks and
+        # 640x480 BGR camera frames resident in HBM -> width gate -> feature fuse with per-stream velocity state -> crop box -> gray +
+        # INTER_AREA resize -> ring push -> one forward over the streams that are due (every 2nd tick)
+        from silent_speech_amd import features as Fm
+
+        S, Ts = (1024, 60) if (args.batch, args.frames) == (256, 30) else (args.batch, args.frames)
+        Kl = len(Fm.FIXED_IDXS_88)
+        Dl = 2 * Kl + 4
+        hh, ww, roi_hw = 480, 640, (48, 96)
+        model = ss.BiGRUClassifier(Dl, C, use_roi=True).to(dev).eval()
+        srv = ss.StreamServer(model, S, Ts, roi_hw=roi_hw, device=dev)
+        srv.attach_front_end(Fm.FIXED_IDXS_88, (ww, hh), variant="live")
+        g = torch.Generator(device=dev).manual_seed(7)
+        lmk = torch.rand(S, Kl, 2, device=dev, generator=g) * 0.2 + 0.4
+        al, ar = Fm.anchor_positions(Fm.FIXED_IDXS_88)[:2]
+        lmk[:, al] = torch.tensor([0.42, 0.61], device=dev)   # mouth corners 0.16 x 640 = 102 px apart: inside the 60-150 px band
+        lmk[:, ar] = torch.tensor([0.58, 0.61], device=dev)
+        lmk[::16, ar, 0] = 0.45                                # every 16th stream too far away: dropped by the gate
+        frames = torch.randint(0, 256, (S, hh, ww, 3), device=dev, dtype=torch.uint8, generator=g)
+        ids = list(range(S))
+        for _ in range(Ts + (Ts % 2)):
+            srv.push_landmarks(ids, lmk, frames)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_pred = n_kept = 0
+        for _ in range(2 * args.steps):
+            kept, got = srv.push_landmarks(ids, lmk, frames)
+            n_kept += int(kept.sum())
+            n_pred += 0 if got is None else len(got[0])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        print(json.dumps({"metric": "camera frames/sec through the live chain (%d streams: gate + features + crop + gray/resize + ring + "
+                                    "forward every 2nd tick on %d-frame windows)" % (S, Ts),
+                          "value": round(2 * args.steps * S / el, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": 0,
+                          "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True, "dtype": "f32 / u8", "data": "synthetic",
+                          "windows_per_sec": round(n_pred / el, 1), "frames_kept_per_sec": round(n_kept / el, 1),
+                          "config": {"workload": "live_infer_official.py:264-296 for %d streams per tick, 640x480 BGR frames and 88 landmarks "
+                                                 "resident in HBM, ROI 48x96, D=%d, T=%d" % (S, Dl, Ts)}}))
         return
     if args.mode == "assemble":
         # a training batch gathered out of a clip store that lives in HBM (noise, frame drop, pad / trim)
