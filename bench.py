@@ -678,11 +678,17 @@ def main():
             n_pred += 0 if got is None else len(got[0])
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(2 * args.steps):
+            srv.front(ids, lmk, frames)       # gate + features + crop + resize alone (state advances, rings untouched)
+        torch.cuda.synchronize()
+        front_ms = 1000 * (time.perf_counter() - t0) / (2 * args.steps)
         print(json.dumps({"metric": "camera frames/sec through the live chain (%d streams: gate + features + crop + gray/resize + ring + "
                                     "forward every 2nd tick on %d-frame windows)" % (S, Ts),
                           "value": round(2 * args.steps * S / el, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": 0,
                           "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True, "dtype": "f32 / u8", "data": "synthetic",
                           "windows_per_sec": round(n_pred / el, 1), "frames_kept_per_sec": round(n_kept / el, 1),
+                          "front_end_ms_per_tick": round(front_ms, 3),
                           "config": {"workload": "live_infer_official.py:264-296 for %d streams per tick, 640x480 BGR frames and 88 landmarks "
                                                  "resident in HBM, ROI 48x96, D=%d, T=%d" % (S, Dl, Ts)}}))
         return
