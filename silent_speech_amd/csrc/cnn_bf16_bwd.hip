@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   // This lane's operand addresses of its k steps (two pixels each: rows q4 and q4 + 4 of the lane's 8-pixel group) depend on
   // nothing but the lane and the k step -- the dy and input images are band-local -- so they are made ONCE: the loop below had
   // ~110 vector instructions of pixel -> (row, column) -> address arithmetic per k step beside its 20 - 30 MFMAs, and these
-  // kernels are bound by the vector issue port
+  // kernels are bound by the vector issue port (docs/LAB_NOTES.md 8c)
   // (only where a wave has few k steps per band -- layer 2: three; with nine (layer 3) or five (layer 4) offset sets the register
   // allocation spilled)
   constexpr int NCHW = (NCH + WK - 1) / WK;

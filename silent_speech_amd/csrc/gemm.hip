@@ -674,7 +674,7 @@ struct WideGroup {
 // barrier behind waves 0..3, one half reading fragments / issuing DMA while the other multiplies; two barriers per tile, hazards
 // worked out and the tests green): layer 1's weight gradients 112.8 -> 130.7 us, layer 0's 82.8 -> 94.9, the input projections
 // 0.1045 -> 0.1082 ms per step.  With f32 MFMAs the half that reads is starved by the half that multiplies (a saturated
-// v_mfma_f32_16x16x4_f32 stream leaves the SIMD's other wave one vector instruction per ~180 cycles), so its
+// v_mfma_f32_16x16x4_f32 stream leaves the SIMD's other wave one vector instruction per ~180 cycles, docs/LAB_NOTES.md 8c-2 (6)), so its
 // "read phase" stretches over the partner's whole MFMA burst instead of hiding under it; in lockstep both halves read with
 // nothing to contend with and then share the pipe.
 #define WIDE_K_LOOP                                                                                                      \

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of one kernel of a hipcc -S listing, per basic block: how many matrix, vector, scalar, LDS and
 memory instructions a block issues.  The CNN kernels are bound by instruction ISSUE (f32 MFMA and VALU take turns on a SIMD:
-DESIGN.md 8c-2 (6)), so the per-frame count of non-MFMA instructions is the quantity to drive down; blocks are listed in
+docs/LAB_NOTES.md 8c-2 (6)), so the per-frame count of non-MFMA instructions is the quantity to drive down; blocks are listed in
 program order with their first line, which is enough to match them to the stages of the source.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o /tmp/k.s silent_speech_amd/csrc/roi_cnn.hip
