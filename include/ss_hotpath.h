@@ -150,6 +150,29 @@ int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const
                    const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
                    float* g_wfc, float* g_bfc, ss_stream_t stream);
 
+/* ---- padded batches: only the frames that belong to a clip ---------------------------------
+ * The reference pads every clip to T frames and runs TinyROICNN over all B*T of them (train_model_official.py:286-297) although
+ * pack_padded_sequence (:300) drops rows t >= lengths[b] before the recurrence: their embeddings never reach the logits and
+ * their gradient is exactly zero.  ss_roi_active_frames lists the rows that count -- frames[0] = how many, frames[1 ...] = the
+ * row numbers b*T + t with t < min(max(lengths[b], 0), T), ascending; frames needs 1 + B*T ints of device memory -- and, when
+ * emb is given, clears emb[row*ld_emb + 0 .. emb_cols) of every other row (pass Z + x_dim: the input-projection GEMM still
+ * reads those rows).  ss_roi_cnn_fwd_frames / ss_roi_cnn_bwd_frames are ss_roi_cnn_fwd_stash / ss_roi_cnn_bwd walking only the
+ * listed frames (frames == NULL: all N); `out` rows and stash slots stay indexed by the frame number, so the two launches of a
+ * step must be given the same list.  Logits and gradients are those of the full walk. */
+int ss_roi_active_frames(const int32_t* lengths, int B, int T, int* frames, float* emb, int ld_emb, int emb_cols,
+                         ss_stream_t stream);
+int ss_roi_cnn_fwd_frames(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
+                          const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
+                          const float* bfc, int E, float* out, int ld_out, float* st_a1, uint8_t* st_i1,
+                          float* st_a2, uint8_t* st_i2, uint8_t* st_m3, float* st_feat, const int* stash_sizes,
+                          const int* frames, ss_stream_t stream);
+int ss_roi_cnn_bwd_frames(const uint8_t* R, int N, int H, int W, int standardize, const float* w1, const float* b1,
+                          const float* w2, const float* b2, const float* w3, const float* b3, const float* wfc,
+                          const float* bfc, int E, const float* st_a1, const uint8_t* st_i1, const float* st_a2,
+                          const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat, const int* stash_sizes,
+                          const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_w3,
+                          float* g_b3, float* g_wfc, float* g_bfc, const int* frames, ss_stream_t stream);
+
 /* ---- dense contraction used by a7/a9 and their gradients -----------------------------------
  * C[M,N] (+)= opA[M,K] * opB[K,N] (+ bias[N]) (then ReLU), exact-f32 MFMA.
  * a_kcontig = 1: A is stored [M][K] (lda = row stride); 0: stored [K][M].
@@ -189,10 +212,11 @@ int ss_gemm_splitk_reduce(const float* ws, int M, int N, int K, int splits, int 
 /* What a training step does before its first real kernel, in one launch: grads[0:n_grads] = 0 (the flat gradient bucket of
  * optimizer.zero_grad, train_model_official.py:433), scalars[0:n_scalars] = 0 and correct[0] = 0 (loss / sum of squares /
  * hit counter; correct may be NULL), lengths32[b] = lengths64[b] (NULL: skipped), Z[r][0:cols] = X[r][0:cols] for `rows`
- * rows (the landmark half of torch.cat((X, roi_emb)), train_model_official.py:297; X NULL: skipped). */
+ * rows (the landmark half of torch.cat((X, roi_emb)), train_model_official.py:297; X NULL: skipped); frames (may be NULL; needs
+ * lengths64, X and rows = B*T): what ss_roi_active_frames does, from the int64 lengths, clearing Z[row][cols .. cols + emb_cols). */
 int ss_train_prologue(float* grads, long n_grads, float* scalars, int n_scalars, int32_t* correct,
                       const int64_t* lengths64, int32_t* lengths32, int B, const float* X, int ld_x, float* Z, int ld_z,
-                      int rows, int cols, ss_stream_t stream);
+                      int rows, int cols, int* frames, int emb_cols, ss_stream_t stream);
 
 /* Several split-K problems C_j (ldc_j, stride_c_j between the batch members) += op(A_j) op(B_j) in ONE GEMM launch plus ONE
  * reduce launch (the three weight-gradient GEMMs of a GRU layer; every launch boundary on a stream costs the tail of one

@@ -38,6 +38,9 @@ SIGNATURES = {
     "ss_roi_cnn_fwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i, _vp],
     "ss_roi_cnn_fwd_stash": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_vp, _vp],
     "ss_roi_cnn_set_max_workgroups": [_i],
+    "ss_roi_active_frames": [_vp, _i, _i, _vp, _vp, _i, _i, _vp],
+    "ss_roi_cnn_fwd_frames": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i, _vp, _i] + [_vp] * 6 + [_vp, _vp, _vp],
+    "ss_roi_cnn_bwd_frames": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_vp, _vp, _i] + [_vp] * 8 + [_vp, _vp],
     "ss_roi_cnn_stash_size": [_i, _i, _vp],
     "ss_roi_cnn_bwd": [_vp, _i, _i, _i, _i] + [_vp] * 8 + [_i] + [_vp] * 6 + [_vp, _vp, _i] + [_vp] * 8 + [_vp],
     "ss_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
@@ -77,7 +80,7 @@ SIGNATURES = {
     "ss_gemm_bf16_splitk_group": [_vp, _i, _vp, _l, _vp],
     "ss_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
     "ss_zero_f32x2": [_vp, _l, _vp, _l, _vp],
-    "ss_train_prologue": [_vp, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
+    "ss_train_prologue": [_vp, _l, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
     "ss_batch_gather_f32": [_vp, _i, _vp, _l, _vp, _vp, _f, _u64, _vp, _vp],
     "ss_batch_gather_u8": [_vp, _i, _vp, _l, _vp, _vp],
     "ss_crop_gray_resize": [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp],

@@ -68,6 +68,42 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
   }
 }
 
+// The rows (b, t) of a padded batch that belong to a clip: frames[0] = how many, frames[1 ...] = their numbers b*T + t in ascending
+// order; `emb` columns [0, E) of every OTHER row are cleared (the ROI CNN skips those frames -- the packed recurrence never reads
+// their rows, pack_padded_sequence at train_model_official.py:300, but the input-projection GEMM does and must find numbers there).
+// Block `blk` of `nblk` takes a contiguous range of clips; what lies in front of it is summed by the block itself (B loads).
+template <class LenT>
+__device__ void active_frames_block(const LenT* __restrict__ len, int B, int T, int* __restrict__ frames, float* __restrict__ emb,
+                                    int ld, int E, int blk, int nblk) {
+  __shared__ int s_part[4];
+  const int chunk = (B + nblk - 1) / nblk, b0 = blk * chunk, b1 = min(B, b0 + chunk);
+  if (b0 >= B) return;
+  const int tid = threadIdx.x;
+  int part = 0;
+  for (int b = tid; b < b0; b += 256) part += min(max((int)len[b], 0), T);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if ((tid & 63) == 0) s_part[tid >> 6] = part;
+  __syncthreads();
+  int base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  for (int b = b0; b < b1; ++b) {
+    const int l = min(max((int)len[b], 0), T);
+    for (int t = tid; t < T; t += 256) {
+      const int row = b * T + t;
+      if (t < l) frames[1 + base + t] = row;
+      else if (emb)
+        for (int e = 0; e < E; ++e) emb[(long)row * ld + e] = 0.f;
+    }
+    base += l;
+  }
+  if (b1 == B && tid == 0) frames[0] = base;
+}
+
+__global__ __launch_bounds__(256) void active_frames_kernel(const int32_t* __restrict__ len, int B, int T, int* __restrict__ frames,
+                                                            float* __restrict__ emb, int ld, int E) {
+  active_frames_block(len, B, T, frames, emb, ld, E, blockIdx.x, gridDim.x);
+}
+
 // Everything a training step does before its first real kernel, in ONE launch (six tiny launches cost ~6 us each on the
 // step's critical path): clear the gradient bucket, clear the loss / sum-of-squares scalars and the hit counter, narrow the
 // int64 lengths to the int32 the kernels read, and copy the landmark features into their columns of the GRU input.
@@ -77,6 +113,7 @@ struct ProloguePar {
   int32_t* correct;
   const int64_t* len64; int32_t* len32; int B;
   const float* X; int ld_x; float* Z; int ld_z; int rows, cols;
+  int* frames; int E;  // the list of frames that belong to a clip (active_frames_block), from the int64 lengths; null: skipped
 };
 __global__ __launch_bounds__(256) void train_prologue_kernel(ProloguePar a) {
   const long tid = (long)blockIdx.x * 256 + threadIdx.x, nthreads = (long)gridDim.x * 256;
@@ -97,6 +134,7 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(ProloguePar a) {
     if (a.len64)
       for (int b = threadIdx.x; b < a.B; b += 256) a.len32[b] = (int32_t)a.len64[b];
   }
+  if (a.frames) active_frames_block(a.len64, a.B, a.rows / a.B, a.frames, a.Z + a.cols, a.ld_z, a.E, blockIdx.x, gridDim.x);
 }
 
 // clears two float buffers (16-byte aligned) in one launch: the atomically summed destinations of the d layer_in GEMMs
@@ -237,15 +275,17 @@ extern "C" int ss_copy_rows_f32(const float* src, int ld_src, float* dst, int ld
 
 extern "C" int ss_train_prologue(float* grads, long n_grads, float* scalars, int n_scalars, int32_t* correct,
                                  const int64_t* lengths64, int32_t* lengths32, int B, const float* X, int ld_x, float* Z,
-                                 int ld_z, int rows, int cols, ss_stream_t stream) {
+                                 int ld_z, int rows, int cols, int* frames, int emb_cols, ss_stream_t stream) {
   SS_REQUIRE(grads && n_grads > 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0, SS_ERR_ARG);
   SS_REQUIRE(n_scalars >= 0 && n_scalars <= 256 && (n_scalars == 0 || scalars), SS_ERR_ARG);
   SS_REQUIRE(!lengths64 || (lengths32 && B > 0), SS_ERR_ARG);
   SS_REQUIRE(!X || (Z && rows > 0 && cols > 0 && ld_x >= cols && ld_z >= cols), SS_ERR_ARG);
+  SS_REQUIRE(!frames || (lengths64 && X && emb_cols >= 0 && ld_z >= cols + emb_cols && rows % B == 0), SS_ERR_ARG);
   ProloguePar a;
   a.grads = grads; a.n_grads = n_grads; a.scal = scalars; a.n_scal = n_scalars; a.correct = correct;
   a.len64 = lengths64; a.len32 = lengths32; a.B = B;
   a.X = X; a.ld_x = ld_x; a.Z = Z; a.ld_z = ld_z; a.rows = rows; a.cols = cols;
+  a.frames = frames; a.E = emb_cols;
   long work = (n_grads >> 2) > (X ? (long)rows * cols : 0) ? (n_grads >> 2) : (long)rows * cols;
   int blocks = (int)((work + 255) / 256);
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
@@ -281,7 +321,18 @@ extern "C" int ss_colsum_f32(const float* A, int rows, int cols, int lda, float*
   return ss_launch_status();
 }
 
-extern "C" int ss_abi_version(void) { return 2; }
+extern "C" int ss_roi_active_frames(const int32_t* lengths, int B, int T, int* frames, float* emb, int ld_emb, int emb_cols,
+                                    ss_stream_t stream) {
+  SS_REQUIRE(lengths && frames && B > 0 && T > 0, SS_ERR_ARG);
+  SS_REQUIRE((long)B * T < (1L << 31), SS_ERR_UNSUPPORTED);
+  SS_REQUIRE(!emb || (emb_cols > 0 && ld_emb >= emb_cols), SS_ERR_ARG);
+  const int blocks = B < 256 ? B : 256;
+  hipLaunchKernelGGL(active_frames_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), lengths, B, T, frames, emb,
+                     ld_emb, emb_cols);
+  return ss_launch_status();
+}
+
+extern "C" int ss_abi_version(void) { return 3; }
 
 extern "C" const char* ss_status_string(int status) {
   switch (status) {

@@ -63,6 +63,7 @@ struct CnnFwdParams {
   uint8_t* st_i2;   // [N][H4][W4][16]  pixel-major: the backward pass consumes it next to its pixel-major da2
   uint8_t* st_m3;   // [N][P][32]  pixel-major, channels 24..31 unused: the backward turns 16 bytes into 16 floats of one pixel
   float* st_feat;   // [N][ST_FEAT]  24 averaged conv3 features, 24 counts of positive conv3 outputs (for d b3), mean, std
+  const int* frames;  // null, or [0] = how many frames to walk, [1 ...] their numbers (ss_roi_active_frames): padded frames are skipped
 };
 
 // conv1 with lane-local pool windows (round 4, below) reads the frame with lanes that walk a 2 x 2 window x 4 windows: a row
@@ -199,14 +200,22 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
       if (q * 16 < HW) px[k] = reinterpret_cast<const uint4*>(p.R + (long)n * HW)[q];
     }
   };
-  if ((int)blockIdx.x < p.N) load_frame(blockIdx.x);
+  // the frames this launch walks: all N, or the listed ones (rows of a clip's padding never reach the packed recurrence)
+  const int n_walk = p.frames ? min(p.frames[0], p.N) : p.N;
+  auto frame_at = [&](int it) { return p.frames ? (int)min((unsigned)p.frames[1 + it], (unsigned)(p.N - 1)) : it; };
+  // frame numbers are read two frames ahead (a scalar load that misses would otherwise be waited for inside a stage)
+  int n = (int)blockIdx.x < n_walk ? frame_at(blockIdx.x) : -1;
+  int n_next = (int)(blockIdx.x + gridDim.x) < n_walk ? frame_at(blockIdx.x + gridDim.x) : -1, n_after = -1;
+  if (n >= 0) load_frame(n);
   // (Round 3 experiment: the second workgroup of every CU started 16 k / 32 k / 49 k cycles late, so that its vector-heavy stages
   // -- statistics, conv1 -- would meet the first one's MFMA-heavy ones -- conv2, conv3 -- instead of its own kind: 471.8 / 469.7 /
   // 473.2 us per launch against 462.6, i.e. the sleep itself and nothing else.  The two workgroups of a CU do not get in each
   // other's way whatever their phase: each is bound by its own chain of reads, MFMAs and barriers, not by a shared pipe.)
   STAMP_DECL;
 
-  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+  for (int it = blockIdx.x; it < n_walk; it += gridDim.x, n = n_next, n_next = n_after) {
+    const int it2 = it + 2 * (int)gridDim.x;
+    n_after = it2 < n_walk ? frame_at(it2) : -1;
     STAMP(15);
     // ---------------- stage 0: statistics + normalise
     unsigned su = 0, sq = 0;
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
       xh[cell] = 0.f;
     }
     // prefetch the next frame's bytes while this one is computed
-    if (n + (int)gridDim.x < p.N) load_frame(n + gridDim.x);
+    if (n_next >= 0) load_frame(n_next);
     __syncthreads();
     STAMP(0);
 
@@ -619,12 +628,12 @@ int launch_fwd(const CnnFwdParams& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int standardize, const float* w1,
-                                    const float* b1, const float* w2, const float* b2, const float* w3,
-                                    const float* b3, const float* wfc, const float* bfc, int E, float* out,
-                                    int ld_out, float* st_a1, uint8_t* st_i1, float* st_a2, uint8_t* st_i2,
-                                    uint8_t* st_m3, float* st_feat, const int* stash_sizes,
-                                    ss_stream_t stream) {
+extern "C" int ss_roi_cnn_fwd_frames(const uint8_t* R, int N, int H, int W, int standardize, const float* w1,
+                                     const float* b1, const float* w2, const float* b2, const float* w3,
+                                     const float* b3, const float* wfc, const float* bfc, int E, float* out,
+                                     int ld_out, float* st_a1, uint8_t* st_i1, float* st_a2, uint8_t* st_i2,
+                                     uint8_t* st_m3, float* st_feat, const int* stash_sizes, const int* frames,
+                                     ss_stream_t stream) {
   SS_REQUIRE(R && w1 && b1 && w2 && b2 && w3 && b3 && wfc && bfc && out, SS_ERR_ARG);
   SS_REQUIRE(N > 0 && E > 0 && ld_out >= E, SS_ERR_ARG);
   SS_REQUIRE(E <= 64, SS_ERR_UNSUPPORTED);
@@ -636,6 +645,7 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.wfc = wfc; p.bfc = bfc;
   p.E = E; p.out = out; p.ld_out = ld_out;
   p.st_a1 = st_a1; p.st_i1 = st_i1; p.st_a2 = st_a2; p.st_i2 = st_i2; p.st_m3 = st_m3; p.st_feat = st_feat;
+  p.frames = frames;
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define SS_DISPATCH(HH, WW)                                                                                      \
   if (H == HH && W == WW) {                                                                                     \
@@ -646,6 +656,16 @@ extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int s
   SS_CNN_SHAPES(SS_DISPATCH)
 #undef SS_DISPATCH
   return SS_ERR_UNSUPPORTED;
+}
+
+extern "C" int ss_roi_cnn_fwd_stash(const uint8_t* R, int N, int H, int W, int standardize, const float* w1,
+                                    const float* b1, const float* w2, const float* b2, const float* w3,
+                                    const float* b3, const float* wfc, const float* bfc, int E, float* out,
+                                    int ld_out, float* st_a1, uint8_t* st_i1, float* st_a2, uint8_t* st_i2,
+                                    uint8_t* st_m3, float* st_feat, const int* stash_sizes,
+                                    ss_stream_t stream) {
+  return ss_roi_cnn_fwd_frames(R, N, H, W, standardize, w1, b1, w2, b2, w3, b3, wfc, bfc, E, out, ld_out, st_a1, st_i1, st_a2,
+                               st_i2, st_m3, st_feat, stash_sizes, nullptr, stream);
 }
 
 extern "C" int ss_roi_cnn_stash_size(int H, int W, int* sizes) {

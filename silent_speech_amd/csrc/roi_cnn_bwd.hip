@@ -106,6 +106,7 @@ struct CnnBwdParams {
   const float* d_out;
   int ld_dout;
   float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *g_wfc, *g_bfc;
+  const int* frames;  // null, or [0] = how many frames to walk, [1 ...] their numbers (ss_roi_active_frames): padded frames are skipped
 };
 
 // S1's A rows are (tap, n) pairs: dW3[n][c][tap] = sum_q dy3[n][q - tap] * a2[c][q] with the B operand a2[c][q] shared by
@@ -163,6 +164,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   STAMP_ENTRY;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = BwdLds<G>;
+  // the frames this launch walks: all N, or the listed ones (a clip's padding frames have d feat == 0 and add nothing)
+  const int n_walk = p.frames ? min(p.frames[0], p.N) : p.N;
+  auto frame_at = [&](int it) { return p.frames ? (int)min((unsigned)p.frames[1 + it], (unsigned)(p.N - 1)) : it; };
+  if ((int)blockIdx.x >= n_walk) return;  // (the grid is sized for N: a workgroup without frames has nothing to add)
   constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H, XS = LL::XSB;
   constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, W2H = LL::W2H;
   constexpr int NCH = (HW / 8 + NT - 1) / NT;     // 8-byte pixel chunks per thread (every thread of a 64x64 frame has one)
@@ -460,9 +465,13 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     front_table();
     front_gb3();
   };
-  if ((int)blockIdx.x < p.N) {  // the first frame's inputs and front, outside the pipeline
-    prefetch_frame(blockIdx.x);
-    if (FAST) misc_dma(blockIdx.x);
+  // frame numbers are read two frames ahead: a scalar load that misses costs ~500 cycles, and the wait for it (lgkmcnt, shared with
+  // LDS) would otherwise sit in the middle of a stage (measured: 1 % of a launch)
+  int n = frame_at(blockIdx.x);
+  int n_next = (int)(blockIdx.x + gridDim.x) < n_walk ? frame_at(blockIdx.x + gridDim.x) : -1;
+  {  // the first frame's inputs and front, outside the pipeline
+    prefetch_frame(n);
+    if (FAST) misc_dma(n);
     ss_dma_wait();
     __syncthreads();
     if (FAST) {
@@ -478,7 +487,10 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     __syncthreads();
   }
 
-  for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+  int n_after = -1;
+  for (int it = blockIdx.x; it < n_walk; it += gridDim.x, n = n_next, n_next = n_after) {
+    const int it2 = it + 2 * (int)gridDim.x;
+    n_after = it2 < n_walk ? frame_at(it2) : -1;
     STAMP(15);
     // ---------------- frame top: d feat, the dy3 image and the grey-level table of this frame were made during S5 of the
     // previous one (top1 / top2); what is left are two copies out of the second staging area, needed at the phase switch
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // waited for before S3.  a1h held da1 of the previous frame, dead since barrier E
     auto a1_dma = [&](int part, int nparts) {
       // FAST: the next frame's d_out row / features / statistics are requested here (d feat is made inside S3)
-      if (FAST && part == 0 && n + (int)gridDim.x < p.N) misc_dma(n + gridDim.x);
+      if (FAST && part == 0 && n_next >= 0) misc_dma(n_next);
       constexpr int BYTES = 8 * P1 * 4, A1_PIECES = (BYTES + 1023) / 1024;
       constexpr int I1_BYTES = 8 * I1S, I1_PIECES = I1_BY_DMA ? (I1_BYTES + 1023) / 1024 : 0;  // the pool-1 argmax image rides along
       const char* src = reinterpret_cast<const char*>(p.st_a1 + (long)n * 8 * P1);
@@ -684,7 +696,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
       // FAST: d feat of the NEXT frame (its d_out row landed before barrier D; s_dfeat of THIS frame was last read in S5 of
       // the previous one, the new value is read in S5 of this one, two barriers on)
-      if (FAST && n + (int)gridDim.x < p.N) front_dfeat();
+      if (FAST && n_next >= 0) front_dfeat();
     };
     // ---------------- S3: dW2.  A wave owns whole rows of the pooled-1 grid: one A base and five B bases per wave,
     // everything else is an immediate offset (VALU work between MFMAs is not hidden by them).  The two waves of a SIMD
@@ -839,7 +851,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       constexpr int PPR = W2 / 4 / KP, NP = rows * PPR;
       constexpr int FRONT = NP - (NP + 3) / 4;  // pass after which the next frame's front runs (the DMA has ~3/4 of S5 to land)
       constexpr int FRONT_A = NP / 2;           // FAST: waves 0 .. NWV/2 - 1 run theirs here
-      const bool has_next = n + (int)gridDim.x < p.N;
+      const bool has_next = n_next >= 0;
       // fully unrolled, the next pass's reads issued before this pass's selects and MFMAs (see S3)
       float d[2][KP], xv[2][KP];
       int ix[2][KP];
@@ -848,7 +860,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         if (ps + 1 < NP) {
           const int nx = ps + 1, r = nx / PPR, xq = KP * (nx % PPR), buf = nx & 1;
           // dy2 / dy3 areas are dead (S4 is through): the next frame's inputs are requested with the first pass
-          if (nx == 0 && has_next) prefetch_frame(n + gridDim.x);
+          if (nx == 0 && has_next) prefetch_frame(n_next);
 #pragma unroll
           for (int u = 0; u < KP; ++u) {
             d[buf][u] = dp[r * S1 + (xq + u) * 4];
@@ -1017,12 +1029,13 @@ int launch_bwd(const CnnBwdParams& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const float* w1,
-                              const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                              const float* wfc, const float* bfc, int E, const float* st_a1, const uint8_t* st_i1,
-                              const float* st_a2, const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat,
-                              const int* stash_sizes, const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
-                              float* g_w3, float* g_b3, float* g_wfc, float* g_bfc, ss_stream_t stream) {
+extern "C" int ss_roi_cnn_bwd_frames(const uint8_t* R, int N, int H, int W, int standardize, const float* w1,
+                                     const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                                     const float* wfc, const float* bfc, int E, const float* st_a1, const uint8_t* st_i1,
+                                     const float* st_a2, const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat,
+                                     const int* stash_sizes, const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2,
+                                     float* g_b2, float* g_w3, float* g_b3, float* g_wfc, float* g_bfc, const int* frames,
+                                     ss_stream_t stream) {
   (void)w1; (void)b1; (void)b2; (void)b3; (void)bfc;  // the stashed activations already contain their effect
   SS_REQUIRE(R && w2 && w3 && wfc && st_a1 && st_i1 && st_a2 && st_i2 && st_m3 && st_feat && stash_sizes && d_out, SS_ERR_ARG);
   SS_REQUIRE(g_w1 && g_b1 && g_w2 && g_b2 && g_w3 && g_b3 && g_wfc && g_bfc, SS_ERR_ARG);
@@ -1033,6 +1046,7 @@ extern "C" int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standar
   p.st_a1 = st_a1; p.st_i1 = st_i1; p.st_a2 = st_a2; p.st_i2 = st_i2; p.st_m3 = st_m3; p.st_feat = st_feat;
   p.d_out = d_out; p.ld_dout = ld_dout;
   p.g_w1 = g_w1; p.g_b1 = g_b1; p.g_w2 = g_w2; p.g_b2 = g_b2; p.g_w3 = g_w3; p.g_b3 = g_b3; p.g_wfc = g_wfc; p.g_bfc = g_bfc;
+  p.frames = frames;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the stash must have been laid out by a forward kernel compiled against the same Geom as this file
 #define SS_DISPATCH(HH, WW)                                                                             \
@@ -1044,4 +1058,15 @@ extern "C" int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standar
   SS_CNN_SHAPES(SS_DISPATCH)
 #undef SS_DISPATCH
   return SS_ERR_UNSUPPORTED;
+}
+
+extern "C" int ss_roi_cnn_bwd(const uint8_t* R, int N, int H, int W, int standardize, const float* w1,
+                              const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                              const float* wfc, const float* bfc, int E, const float* st_a1, const uint8_t* st_i1,
+                              const float* st_a2, const uint8_t* st_i2, const uint8_t* st_m3, const float* st_feat,
+                              const int* stash_sizes, const float* d_out, int ld_dout, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
+                              float* g_w3, float* g_b3, float* g_wfc, float* g_bfc, ss_stream_t stream) {
+  return ss_roi_cnn_bwd_frames(R, N, H, W, standardize, w1, b1, w2, b2, w3, b3, wfc, bfc, E, st_a1, st_i1, st_a2, st_i2, st_m3,
+                               st_feat, stash_sizes, d_out, ld_dout, g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_wfc, g_bfc, nullptr,
+                               stream);
 }

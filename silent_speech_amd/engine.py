@@ -86,6 +86,9 @@ _SPLITK_TARGET = int(os.environ.get("SS_SPLITK_TARGET", "768"))
 # CU (ss_gemm_f32_splitk_group flags bit 0).  The upper layers' groups run beside the BPTT kernel of the layer below and keep the
 # 128 x 64 form: measured in the step, the wide form there made the launch 12 % shorter and the step 1 % longer.
 DW_WIDE_ALONE = int(os.environ.get("SS_DW_WIDE_ALONE", "1"))
+# The fused ROI-CNN kernels walk only the frames inside their clips (rows t >= lengths[b] of a padded batch never reach the packed
+# recurrence and carry no gradient): a batch that is 40 % padding costs 40 % less CNN time.  0 = every frame, as the reference does.
+SKIP_PADDED_FRAMES = os.environ.get("SS_CNN_SKIP_PADDING", "1") != "0"
 
 
 _DX_SPLIT_CAP = int(os.environ.get("SS_DX_SPLITS", "2"))  # K slices of a d layer_in GEMM with few output tiles (1 = off)
@@ -246,6 +249,9 @@ class Workspace:
                 self.st_i2 = torch.empty(N, n_i2, **u8)     # (H/4, W/4, 16)
                 self.st_m3 = torch.empty(N, n_m3, **u8)     # (H/4 * W/4, 32)
                 self.st_feat = torch.empty(N, n_feat, **f32)  # 24 features, 24 counts, mean, std, pad
+        # [0] = how many rows (b, t) lie inside their clip, [1 ...] = those rows: the fused CNN kernels walk only them
+        self.frames = (torch.empty(1 + N, device=device, dtype=torch.int32)
+                       if cfg.use_roi and self.cnn_generic is None and SKIP_PADDED_FRAMES else None)
 
 
 def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Tensor, R: Optional[torch.Tensor], *,
@@ -276,8 +282,12 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
                                             "roi_cnn.fc.weight", "roi_cnn.fc.bias")]
             st = ([ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
                    ws.st_m3.data_ptr(), ws.st_feat.data_ptr()] if stash else [None] * 6)
-            L.call("ss_roi_cnn_fwd_stash", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
-                   _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, ws.cnn_sizes.ptr if stash else None, s)
+            if ws.frames is not None and not x_in_place:  # (the trainer's prologue kernel has listed them already)
+                L.call("ss_roi_active_frames", ws.lengths.data_ptr(), B, T, ws.frames.data_ptr(), _addr(ws_Z, cfg.x_dim), cfg.in_dim,
+                       cfg.roi_emb, s)
+            L.call("ss_roi_cnn_fwd_frames", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
+                   _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, ws.cnn_sizes.ptr if stash else None, L.ptr(ws.frames), s,
+                   tag="ss_roi_cnn_fwd_stash")  # (the timing tag names the kernel, which is the same with or without a list)
         if ws.train and ws.stagger:  # an event record is a barrier packet on this stream (~6 us): only when somebody waits for it
             ws.ev_cnn_fwd.record()
         layer_in, ld_in = ws_Z.data_ptr(), cfg.in_dim
@@ -447,10 +457,10 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
         if ws.cnn_generic is not None:
             ws.cnn_generic.backward(P, G, cfg.roi_emb, _addr(ws.dZ, cfg.x_dim), cfg.in_dim)
         else:
-            L.call("ss_roi_cnn_bwd", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
+            L.call("ss_roi_cnn_bwd_frames", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
                    cfg.roi_emb, ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
                    ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), ws.cnn_sizes.ptr, _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
-                   *[G[k].data_ptr() for k in names], s)
+                   *[G[k].data_ptr() for k in names], L.ptr(ws.frames), s, tag="ss_roi_cnn_bwd")
     # join the side stream: the caller's next kernels (all-reduce, clip, Adam) read every gradient
     if USE_SIDE_STREAM and not side_joined:
         ws.ev_join.record(ws.side)

@@ -125,7 +125,8 @@ class Trainer:
             T = X.shape[1]
             L.call("ss_train_prologue", model.flat_grads.data_ptr(), model.flat_grads.numel(), self.scal.data_ptr(), 2,
                    self.correct.data_ptr(), lengths.data_ptr(), ws.lengths.data_ptr(), B,
-                   X.data_ptr() if cfg.use_roi else None, cfg.x_dim, L.ptr(ws.Z), cfg.in_dim, B * T, cfg.x_dim, L.stream())
+                   X.data_ptr() if cfg.use_roi else None, cfg.x_dim, L.ptr(ws.Z), cfg.in_dim, B * T, cfg.x_dim,
+                   L.ptr(getattr(ws, "frames", None)), cfg.roi_emb if cfg.use_roi else 0, L.stream())
         else:
             model.flat_grads.zero_()
             self.scal.zero_()

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/ss_hotpath.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.ss_abi_version() == 2
+    assert lib.ss_abi_version() == 3
     assert lib.ss_status_string(-3) == b"unsupported shape"
 
 

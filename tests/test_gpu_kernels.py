@@ -632,6 +632,88 @@ def test_roi_cnn_fwd(L, H, W, standardize):
     assert torch.all(out[:, :8] == -3.0)
 
 
+@pytest.mark.parametrize("B,T", [(7, 12), (300, 5), (1, 1), (4096, 3)])
+def test_active_frames_list_and_cleared_rows(L, B, T):
+    """ss_roi_active_frames: rows b*T + t with t < min(max(len, 0), T), ascending, their count in front; the embedding columns of
+    every other row cleared, nothing else touched (reference: pack_padded_sequence drops those rows, train_model_official.py:300)."""
+    g = torch.Generator().manual_seed(B * 31 + T)
+    lengths = torch.randint(-1, T + 3, (B,), generator=g, dtype=torch.int32)  # incl. 0, negative and longer than T
+    lengths[0] = T
+    want = [b * T + t for b in range(B) for t in range(min(max(int(lengths[b]), 0), T))]
+    ld, x_dim, E = 13, 5, 6
+    Z = torch.full((B * T, ld), 7.0, device="cuda")
+    frames = torch.full((1 + B * T,), -5, device="cuda", dtype=torch.int32)
+    L.call("ss_roi_active_frames", dev(lengths).data_ptr(), B, T, frames.data_ptr(), Z.data_ptr() + 4 * x_dim, ld, E, L.stream())
+    sync()
+    got = frames.cpu().tolist()
+    assert got[0] == len(want) and got[1:1 + len(want)] == want
+    assert all(v == -5 for v in got[1 + len(want):]), "entries behind the list are not the kernel's to write"
+    keep = torch.zeros(B * T, dtype=torch.bool)
+    keep[torch.tensor(want, dtype=torch.long)] = True
+    Zc = Z.cpu()
+    assert torch.all(Zc[keep] == 7.0)
+    assert torch.all(Zc[~keep][:, x_dim:x_dim + E] == 0.0)
+    assert torch.all(Zc[~keep][:, :x_dim] == 7.0) and torch.all(Zc[~keep][:, x_dim + E:] == 7.0)
+    # the list alone (no embedding matrix to clear)
+    frames2 = torch.zeros_like(frames)
+    L.call("ss_roi_active_frames", dev(lengths).data_ptr(), B, T, frames2.data_ptr(), None, 0, 0, L.stream())
+    sync()
+    assert frames2.cpu().tolist()[:1 + len(want)] == got[:1 + len(want)]
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (48, 96), (32, 32)])
+def test_roi_cnn_listed_frames_equal_the_full_walk(L, H, W):
+    """ss_roi_cnn_fwd_frames / _bwd_frames on a list of frames: the listed rows of `out` are bit-equal to the full walk's, the
+    others untouched; the gradients are those of the full walk with d_out == 0 on the frames left out (what the padding rows of
+    a batch carry); an empty list adds nothing; a capped grid (several frames per workgroup: the prefetch pipeline) agrees."""
+    N = 90 if (H, W) == (64, 64) else 23
+    sd = _cnn_sd(5)
+    R_d = dev(_cnn_frames(N, H, W, 8))
+    P = [dev(sd[k]) for k in CNN_KEYS]
+    sizes = L.cnn_stash_sizes(H, W)
+    n_a1, n_a2, n_i1, n_i2, n_m3, n_feat = sizes
+    g = torch.Generator().manual_seed(77)
+    pick = torch.rand(N, generator=g) < 0.6
+    pick[0], pick[N - 1] = True, False
+    listed = torch.nonzero(pick).flatten().to(torch.int32)
+    frames = dev(torch.cat([torch.tensor([len(listed)], dtype=torch.int32), listed,
+                            torch.full((N - len(listed),), 10 ** 6, dtype=torch.int32)]))  # the tail must not be read
+    d_out = torch.randn(N, 32, generator=g)
+    d_masked = dev(d_out * pick[:, None])
+
+    def stash():
+        return [torch.zeros(N, n_a1, device="cuda"), torch.zeros(N, n_i1, device="cuda", dtype=torch.uint8),
+                torch.zeros(N, n_a2, device="cuda"), torch.zeros(N, n_i2, device="cuda", dtype=torch.uint8),
+                torch.zeros(N, n_m3, device="cuda", dtype=torch.uint8), torch.zeros(N, n_feat, device="cuda")]
+
+    def run(fr, d, cap=0):
+        out = torch.full((N, 32), -3.0, device="cuda")
+        st = stash()
+        G = [torch.zeros_like(p) for p in P]
+        L.call("ss_roi_cnn_set_max_workgroups", cap)
+        try:
+            L.call("ss_roi_cnn_fwd_frames", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, out.data_ptr(), 32,
+                   *[s.data_ptr() for s in st], sizes.ptr, L.ptr(fr), L.stream())
+            L.call("ss_roi_cnn_bwd_frames", R_d.data_ptr(), N, H, W, 1, *[p.data_ptr() for p in P], 32, *[s.data_ptr() for s in st],
+                   sizes.ptr, d.data_ptr(), 32, *[gg.data_ptr() for gg in G], L.ptr(fr), L.stream())
+        finally:
+            L.call("ss_roi_cnn_set_max_workgroups", 0)
+        sync()
+        return out, G
+
+    out_full, G_full = run(None, d_masked)
+    for cap in (0, 3):
+        out_l, G_l = run(frames, dev(d_out), cap)  # d_out of the frames left out is never read
+        assert torch.equal(out_l[pick.cuda()], out_full[pick.cuda()])
+        assert torch.all(out_l[~pick.cuda()] == -3.0)
+        for k, a, b in zip(CNN_KEYS, G_l, G_full):
+            scale = max(float(b.abs().max()), 1e-6)
+            assert float((a - b).abs().max()) < 2e-5 * scale, (k, cap, float((a - b).abs().max()), scale)
+    empty = dev(torch.zeros(1 + N, dtype=torch.int32))
+    out_e, G_e = run(empty, dev(d_out))
+    assert torch.all(out_e == -3.0) and all(float(gg.abs().max()) == 0.0 for gg in G_e)
+
+
 @pytest.mark.parametrize("H,W", [(64, 64), (48, 96), (32, 32)])
 def test_roi_cnn_stash_and_bwd(L, H, W):
     N = 270 if (H, W) == (64, 64) else 11

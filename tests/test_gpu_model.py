@@ -435,6 +435,51 @@ def test_micro_batch_streams_match_oracle(ss):
         assert float((a - b).abs().max()) <= atol, k
 
 
+@pytest.mark.parametrize("roi_hw", [(64, 64), (48, 96)])
+def test_padding_frames_are_skipped_without_changing_a_number(ss, roi_hw, monkeypatch):
+    """A ragged batch with the CNN walking only the frames inside their clips (the default) against the same batch with every
+    padded frame computed as the reference does (SS_CNN_SKIP_PADDING=0): logits bit-equal -- a clip's rows are the same numbers,
+    the padding rows never reach the packed recurrence --, gradients equal up to the order of the sums, and a fused train step
+    sees the same loss and gradient norm.  Autograd path (its own list launch) and trainer path (the list comes from the prologue)."""
+    from silent_speech_amd import engine as E
+
+    B, T = 19, 11
+    X, Lh, R, y = W.make_inputs(41, B, T, 84, 5, roi_hw, lengths=[T, 1, 2, 7] + [3 + (5 * b) % 8 for b in range(B - 4)])
+    sd = W.make_state_dict(9, 84, 5, True, gru_layers=2)
+    Xd, Ld, Rd, yd = X.cuda(), Lh.cuda(), R.cuda(), y.cuda()
+    res = {}
+    for skip in (True, False):
+        monkeypatch.setattr(E, "SKIP_PADDED_FRAMES", skip)
+        m = ss.BiGRUClassifier(84, 5, use_roi=True, gru_layers=2)
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        logits = m(Xd, Ld, Rd)
+        torch.nn.functional.cross_entropy(logits, yd, label_smoothing=0.05).backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        m.zero_grad()
+        tr = ss.Trainer(m, dropout=False)
+        loss, _ = tr.step(Xd, Ld, Rd, yd)
+        for slot in (("autograd", 0), 0):  # the autograd forward lists the frames with its own launch, the trainer's prologue does it
+            ws = m._workspace(Xd, Rd, train=True, slot=slot)
+            assert (ws.frames is not None) == skip
+            if skip:
+                assert int(ws.frames[0]) == int(Lh.sum()) and int(ws.frames[1:1 + int(Lh.sum())].diff().min()) > 0
+        res[skip] = (logits.detach().clone(), grads, float(loss), float(tr.grad_norm()))
+    assert torch.equal(res[True][0], res[False][0])
+    assert abs(res[True][2] - res[False][2]) < 1e-6
+    for k in res[True][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6), k
+    assert abs(res[True][3] - res[False][3]) < 1e-5 * res[False][3]  # (Adam's first step is sign-like: parameters are not compared)
+    # and against the oracle, which computes every frame
+    _, _, ref = MR.loss_and_grads(sd, X, Lh, R, y)
+    for k, gg in res[True][1].items():
+        if k == "pool.score.bias":
+            continue
+        scale = max(float(ref[k].abs().max()), 1e-4)
+        assert float((gg.cpu() - ref[k]).abs().max()) < 2e-4 * scale + 2e-3 * float(ref[k].abs().max()), k
+
+
 @pytest.mark.parametrize("roi_hw,chunk_rows", [((96, 96), None), ((40, 56), None), ((40, 56), 5000), ((20, 12), None)])
 def test_any_roi_size_runs_layer_by_layer(ss, roi_hw, chunk_rows, monkeypatch):
     """ROI sizes outside the fused kernels' set (64x64, 48x96, 32x32) -- the reference takes whatever ROI_H x ROI_W its constants
