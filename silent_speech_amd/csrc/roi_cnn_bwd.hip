@@ -159,15 +159,19 @@ __device__ __forceinline__ void s1_rows(const float* dy3h, const float* a2h, int
   }
 }
 
-template <class G>
+// LISTED: the frames are p.frames[1 ...] (a clip's padding frames have d feat == 0 and add nothing: they are not walked);
+// otherwise frame `it` is frame number `it`.  Two kernels because the indirection is not free in THIS one: with five more scalar
+// values alive through a frame (list pointer, count, three frame numbers) it spills 48 instead of 38 scalar registers and a launch
+// over all frames took 692 instead of 682 us, 924 instead of 917 at 48 x 96 (A/B on one box, gpurun_out/r4_fr_ab2.log; both walks
+// inlined into one kernel behind a branch on the count were worse: 689 and 949, r4_fr_ab3.log).  The host picks (engine.py).
+template <class G, bool LISTED>
 __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   STAMP_ENTRY;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using LL = BwdLds<G>;
-  // the frames this launch walks: all N, or the listed ones (a clip's padding frames have d feat == 0 and add nothing)
-  const int n_walk = p.frames ? min(p.frames[0], p.N) : p.N;
-  auto frame_at = [&](int it) { return p.frames ? (int)min((unsigned)p.frames[1 + it], (unsigned)(p.N - 1)) : it; };
-  if ((int)blockIdx.x >= n_walk) return;  // (the grid is sized for N: a workgroup without frames has nothing to add)
+  const int n_walk = LISTED ? min(p.frames[0], p.N) : p.N;
+  auto frame_at = [&](int it) { return LISTED ? (int)min((unsigned)p.frames[1 + it], (unsigned)(p.N - 1)) : it; };
+  if (LISTED && (int)blockIdx.x >= n_walk) return;  // (the grid is sized for N: a workgroup without frames has nothing to add)
   constexpr int P = G::P, HW2 = G::HW2, HW = G::HW, H = G::H, XS = LL::XSB;
   constexpr int W = G::W, W2 = G::W2, W4 = G::W4, H2 = G::H2, S1 = G::S1, S2 = G::S2, P1 = G::P1, P2 = G::P2, W2H = LL::W2H;
   constexpr int NCH = (HW / 8 + NT - 1) / NT;     // 8-byte pixel chunks per thread (every thread of a 64x64 frame has one)
@@ -468,8 +472,15 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
   // frame numbers are read two frames ahead: a scalar load that misses costs ~500 cycles, and the wait for it (lgkmcnt, shared with
   // LDS) would otherwise sit in the middle of a stage (measured: 1 % of a launch)
   int n = frame_at(blockIdx.x);
-  int n_next = (int)(blockIdx.x + gridDim.x) < n_walk ? frame_at(blockIdx.x + gridDim.x) : -1;
-  {  // the first frame's inputs and front, outside the pipeline
+  int n_next = LISTED && (int)(blockIdx.x + gridDim.x) < n_walk ? frame_at(blockIdx.x + gridDim.x) : -1, n_after = -1;
+  // (without a list the next frame's number is n + gridDim.x wherever it is needed, and nothing is carried from frame to frame)
+  auto has_next = [&]() { return LISTED ? n_next >= 0 : n + (int)gridDim.x < p.N; };
+  auto next_frame = [&]() { return LISTED ? n_next : n + (int)gridDim.x; };
+  auto advance = [&]() {
+    if constexpr (LISTED) { n = n_next; n_next = n_after; }
+    else n += gridDim.x;
+  };
+  if (LISTED || (int)blockIdx.x < p.N) {  // the first frame's inputs and front, outside the pipeline
     prefetch_frame(n);
     if (FAST) misc_dma(n);
     ss_dma_wait();
@@ -487,10 +498,11 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     __syncthreads();
   }
 
-  int n_after = -1;
-  for (int it = blockIdx.x; it < n_walk; it += gridDim.x, n = n_next, n_next = n_after) {
-    const int it2 = it + 2 * (int)gridDim.x;
-    n_after = it2 < n_walk ? frame_at(it2) : -1;
+  for (int it = blockIdx.x; it < n_walk; it += gridDim.x, advance()) {
+    if constexpr (LISTED) {
+      const int it2 = it + 2 * (int)gridDim.x;
+      n_after = it2 < n_walk ? frame_at(it2) : -1;
+    }
     STAMP(15);
     // ---------------- frame top: d feat, the dy3 image and the grey-level table of this frame were made during S5 of the
     // previous one (top1 / top2); what is left are two copies out of the second staging area, needed at the phase switch
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
     // waited for before S3.  a1h held da1 of the previous frame, dead since barrier E
     auto a1_dma = [&](int part, int nparts) {
       // FAST: the next frame's d_out row / features / statistics are requested here (d feat is made inside S3)
-      if (FAST && part == 0 && n_next >= 0) misc_dma(n_next);
+      if (FAST && part == 0 && has_next()) misc_dma(next_frame());
       constexpr int BYTES = 8 * P1 * 4, A1_PIECES = (BYTES + 1023) / 1024;
       constexpr int I1_BYTES = 8 * I1S, I1_PIECES = I1_BY_DMA ? (I1_BYTES + 1023) / 1024 : 0;  // the pool-1 argmax image rides along
       const char* src = reinterpret_cast<const char*>(p.st_a1 + (long)n * 8 * P1);
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       }
       // FAST: d feat of the NEXT frame (its d_out row landed before barrier D; s_dfeat of THIS frame was last read in S5 of
       // the previous one, the new value is read in S5 of this one, two barriers on)
-      if (FAST && n_next >= 0) front_dfeat();
+      if (FAST && has_next()) front_dfeat();
     };
     // ---------------- S3: dW2.  A wave owns whole rows of the pooled-1 grid: one A base and five B bases per wave,
     // everything else is an immediate offset (VALU work between MFMAs is not hidden by them).  The two waves of a SIMD
@@ -851,7 +863,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
       constexpr int PPR = W2 / 4 / KP, NP = rows * PPR;
       constexpr int FRONT = NP - (NP + 3) / 4;  // pass after which the next frame's front runs (the DMA has ~3/4 of S5 to land)
       constexpr int FRONT_A = NP / 2;           // FAST: waves 0 .. NWV/2 - 1 run theirs here
-      const bool has_next = n_next >= 0;
+      const bool more = has_next();
       // fully unrolled, the next pass's reads issued before this pass's selects and MFMAs (see S3)
       float d[2][KP], xv[2][KP];
       int ix[2][KP];
@@ -860,7 +872,7 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         if (ps + 1 < NP) {
           const int nx = ps + 1, r = nx / PPR, xq = KP * (nx % PPR), buf = nx & 1;
           // dy2 / dy3 areas are dead (S4 is through): the next frame's inputs are requested with the first pass
-          if (nx == 0 && has_next) prefetch_frame(n_next);
+          if (nx == 0 && more) prefetch_frame(next_frame());
 #pragma unroll
           for (int u = 0; u < KP; ++u) {
             d[buf][u] = dp[r * S1 + (xq + u) * 4];
@@ -887,9 +899,9 @@ __global__ __launch_bounds__(NT) void roi_cnn_bwd_kernel(CnnBwdParams p) {
         }
         SS_SCHED_FENCE();
         if (FAST) {  // the two waves of a SIMD (w, w + NWV / 2) take different passes
-          if (ps == FRONT_A - 1 && has_next && wvu < NWV / 2) front_own();
-          if (ps == FRONT - 1 && has_next && wvu >= NWV / 2) front_own();
-        } else if (ps == FRONT - 1 && has_next) {  // (wave-uniform; the reads of pass FRONT are already in flight)
+          if (ps == FRONT_A - 1 && more && wvu < NWV / 2) front_own();
+          if (ps == FRONT - 1 && more && wvu >= NWV / 2) front_own();
+        } else if (ps == FRONT - 1 && more) {  // (wave-uniform; the reads of pass FRONT are already in flight)
           ss_dma_wait();
           __syncthreads();  // F1: every wave's pieces of the next frame have landed
           uint4 m3w[NM3];
@@ -1016,14 +1028,15 @@ int launch_bwd(const CnnBwdParams& p, hipStream_t s) {
   static_assert(G::P % (4 * NWV) == 0 && G::HW2 % (4 * NWV) == 0 && 24 * G::P <= 16 * NT, "unsupported ROI size");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_cnn_bwd_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return SS_ERR_LAUNCH;
+    for (const void* fn : {reinterpret_cast<const void*>(roi_cnn_bwd_kernel<G, false>),
+                           reinterpret_cast<const void*>(roi_cnn_bwd_kernel<G, true>)})
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SS_ERR_LAUNCH;
     attr_set = true;
   }
   const int cap = ss_cnn_max_wgs > 0 ? ss_cnn_max_wgs : ss_device_cus();
   const int grid = p.N < cap ? p.N : cap;
-  hipLaunchKernelGGL(roi_cnn_bwd_kernel<G>, dim3(grid), dim3(NT), lds_bytes, s, p);
+  if (p.frames) hipLaunchKernelGGL((roi_cnn_bwd_kernel<G, true>), dim3(grid), dim3(NT), lds_bytes, s, p);
+  else hipLaunchKernelGGL((roi_cnn_bwd_kernel<G, false>), dim3(grid), dim3(NT), lds_bytes, s, p);
   return ss_launch_status();
 }
 

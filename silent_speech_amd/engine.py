@@ -252,6 +252,14 @@ class Workspace:
         # [0] = how many rows (b, t) lie inside their clip, [1 ...] = those rows: the fused CNN kernels walk only them
         self.frames = (torch.empty(1 + N, device=device, dtype=torch.int32)
                        if cfg.use_roi and self.cnn_generic is None and SKIP_PADDED_FRAMES else None)
+        # The backward kernel pays 1 % for the list (roi_cnn_bwd.hip: 48 instead of 38 spilled scalar registers), so a training
+        # workspace keeps the count of the last batch it has SEEN FINISH in pinned memory -- an 8-byte copy on the side stream,
+        # never waited for -- and a step that follows a batch of full clips launches the kernels without the list.  A wrong guess
+        # walks the padding frames as the reference does: slower, never different.  walk_listed = this step's choice (the
+        # forward makes it, the backward follows: the stash slots of frames the forward skipped are not there to read).
+        self.frames_seen = (torch.full((1,), -1, dtype=torch.int32).pin_memory()
+                            if self.frames is not None and train else None)
+        self.walk_listed = self.frames is not None
 
 
 def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Tensor, R: Optional[torch.Tensor], *,
@@ -285,8 +293,10 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
             if ws.frames is not None and not x_in_place:  # (the trainer's prologue kernel has listed them already)
                 L.call("ss_roi_active_frames", ws.lengths.data_ptr(), B, T, ws.frames.data_ptr(), _addr(ws_Z, cfg.x_dim), cfg.in_dim,
                        cfg.roi_emb, s)
+            ws.walk_listed = ws.frames is not None and not (stash and int(ws.frames_seen[0]) == N)
             L.call("ss_roi_cnn_fwd_frames", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *cw, cfg.roi_emb,
-                   _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, ws.cnn_sizes.ptr if stash else None, L.ptr(ws.frames), s,
+                   _addr(ws_Z, cfg.x_dim), cfg.in_dim, *st, ws.cnn_sizes.ptr if stash else None,
+                   L.ptr(ws.frames) if ws.walk_listed else None, s,
                    tag="ss_roi_cnn_fwd_stash")  # (the timing tag names the kernel, which is the same with or without a list)
         if ws.train and ws.stagger:  # an event record is a barrier packet on this stream (~6 us): only when somebody waits for it
             ws.ev_cnn_fwd.record()
@@ -364,6 +374,8 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             # the top layer's d layer_in GEMM waits for them
             zero_buffers(ws.d_lower[1:] + ([ws.dZ] if cfg.use_roi else []))
             ws.ev_zero.record()
+            if ws.frames_seen is not None:  # how many frames of this batch lay inside a clip: read by a later step's forward
+                ws.frames_seen.copy_(ws.frames[:1], non_blocking=True)
             # LayerNorm gamma / beta and score-weight gradients: column sums of the rows the tail kernel left per clip
             for k_, name_ in enumerate(("head.0.weight", "head.0.bias", "pool.score.weight")):
                 L.call("ss_colsum_f32", _addr(ws.tail_part, k_ * 2 * H), B, 2 * H, 3 * 2 * H, G[name_].data_ptr(), L.stream())
@@ -460,7 +472,7 @@ def backward(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], cfg: Config
             L.call("ss_roi_cnn_bwd_frames", R.data_ptr(), N, Hh, Ww, int(cfg.roi_standardize), *[P[k].data_ptr() for k in names],
                    cfg.roi_emb, ws.st_a1.data_ptr(), ws.st_i1.data_ptr(), ws.st_a2.data_ptr(), ws.st_i2.data_ptr(),
                    ws.st_m3.data_ptr(), ws.st_feat.data_ptr(), ws.cnn_sizes.ptr, _addr(ws.dZ, cfg.x_dim), cfg.in_dim,
-                   *[G[k].data_ptr() for k in names], L.ptr(ws.frames), s, tag="ss_roi_cnn_bwd")
+                   *[G[k].data_ptr() for k in names], L.ptr(ws.frames) if ws.walk_listed else None, s, tag="ss_roi_cnn_bwd")
     # join the side stream: the caller's next kernels (all-reduce, clip, Adam) read every gradient
     if USE_SIDE_STREAM and not side_joined:
         ws.ev_join.record(ws.side)

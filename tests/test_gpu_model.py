@@ -480,6 +480,42 @@ def test_padding_frames_are_skipped_without_changing_a_number(ss, roi_hw, monkey
         assert float((gg.cpu() - ref[k]).abs().max()) < 2e-4 * scale + 2e-3 * float(ref[k].abs().max()), k
 
 
+def test_a_batch_of_full_clips_is_followed_by_kernels_without_the_frame_list(ss, monkeypatch):
+    """The backward kernel pays 1 % for walking a list, so a training workspace remembers (pinned memory, an 8-byte copy on the
+    side stream, never waited for) how many frames of the last batch it saw finish lay inside a clip; a step that follows a batch
+    of full clips launches forward and backward without the list.  The guess can be stale by a step in either direction --
+    then the padding frames are computed as the reference computes them.  Same losses as a model that never uses the list."""
+    from silent_speech_amd import engine as E
+
+    B, T, hw = 17, 9, (64, 64)
+    Xf, Lf, Rf, yf = W.make_inputs(3, B, T, 84, 5, hw, lengths=[T] * B)
+    Xr, Lr, Rr, yr = W.make_inputs(4, B, T, 84, 5, hw, lengths=[T] + [1 + (3 * b) % T for b in range(B - 1)])
+    sd = W.make_state_dict(2, 84, 5, True, gru_layers=2)
+    seq = [(Xf, Lf, Rf, yf), (Xf, Lf, Rf, yf), (Xr, Lr, Rr, yr), (Xr, Lr, Rr, yr), (Xf, Lf, Rf, yf), (Xf, Lf, Rf, yf)]
+    want_listed = [True, False, False, True, True, False]  # (every step is synchronised here, so the guess is exactly one step old)
+    losses = {}
+    for skip in (True, False):
+        monkeypatch.setattr(E, "SKIP_PADDED_FRAMES", skip)
+        m = ss.BiGRUClassifier(84, 5, use_roi=True, gru_layers=2)
+        m.load_state_dict(sd)
+        tr = ss.Trainer(m.cuda().train(), dropout=False)
+        out = []
+        for k, (X, Lh, R, y) in enumerate(seq):
+            loss, _ = tr.step(X.cuda(), Lh.cuda(), R.cuda(), y.cuda())
+            torch.cuda.synchronize()
+            ws = m._workspace(X.cuda(), R.cuda(), train=True, slot=0)
+            if skip:
+                assert ws.walk_listed == want_listed[k], (k, ws.walk_listed)
+                assert int(ws.frames_seen[0]) == int(Lh.sum()) == int(ws.frames[0])
+            else:
+                assert ws.frames is None and not ws.walk_listed
+            out.append(float(loss))
+        losses[skip] = out
+    for a, b in zip(losses[True], losses[False]):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (losses[True], losses[False])
+    assert abs(losses[True][0] - losses[False][0]) < 1e-6
+
+
 @pytest.mark.parametrize("roi_hw,chunk_rows", [((96, 96), None), ((40, 56), None), ((40, 56), 5000), ((20, 12), None)])
 def test_any_roi_size_runs_layer_by_layer(ss, roi_hw, chunk_rows, monkeypatch):
     """ROI sizes outside the fused kernels' set (64x64, 48x96, 32x32) -- the reference takes whatever ROI_H x ROI_W its constants
