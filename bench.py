@@ -227,7 +227,10 @@ def pmc_lookup(path, stems):
     match (two instantiations of one template in a file is a lookup that needs a sharper stem, not an average)."""
     if not path or not os.path.exists(path):
         return None
-    hits = [d for name, d in json.load(open(path))["kernels"].items() if all(st in name for st in stems)]
+    want = [st for st in stems if not st.startswith("!")]
+    never = [st[1:] for st in stems if st.startswith("!")]  # "!text": the name must NOT contain text
+    hits = [d for name, d in json.load(open(path))["kernels"].items()
+            if all(st in name for st in want) and not any(st in name for st in never)]
     return hits[0] if len(hits) == 1 else None
 
 
@@ -237,6 +240,10 @@ def kernel_stems(tag, roi_hw=None):
     st = list(KERNEL_STEMS.get(tag, [tag]))
     if tag in ("ss_roi_cnn_bwd", "ss_roi_cnn_fwd_stash") and roi_hw is not None:
         st.append("Geom<%d, %d>" % tuple(roi_hw))
+    if tag == "ss_roi_cnn_bwd":
+        # two kernels since round 4: <Geom, true> walks a frame list (ragged batches, and the first step of any run), <Geom, false>
+        # all frames -- the one the full clips of every bench workload run
+        st.append("!, true>")
     return st
 
 

@@ -62,3 +62,9 @@ def test_ambiguous_stem_is_not_averaged(tmp_path):
     p.write_text(json.dumps({"kernels": {"void k<1>(P)": {"v": 1}, "void k<2>(P)": {"v": 2}}}))
     assert b.pmc_lookup(str(p), ["void k<"]) is None
     assert b.pmc_lookup(str(p), ["k<2>"]) == {"v": 2}
+    assert b.pmc_lookup(str(p), ["void k<", "!<1>"]) == {"v": 2}  # "!text": names that contain text are out
+    # the backward ROI kernel exists with and without a frame list since round 4; the bench's full clips run the one without
+    q = tmp_path / "y.json"
+    q.write_text(json.dumps({"kernels": {"void roi_cnn_bwd_kernel<Geom<64, 64>, false>(CnnBwdParams)": {"v": 1},
+                                         "void roi_cnn_bwd_kernel<Geom<64, 64>, true>(CnnBwdParams)": {"v": 2}}}))
+    assert b.pmc_lookup(str(q), b.kernel_stems("ss_roi_cnn_bwd", (64, 64))) == {"v": 1}
