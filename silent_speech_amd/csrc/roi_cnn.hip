@@ -75,6 +75,14 @@ struct CnnFwdParams {
 #ifndef SS_CONV1_LOCAL
 #define SS_CONV1_LOCAL 0
 #endif
+// Diagnostic (-DSS_FWD_STOP=k, tools/fwd_stage_pmc.py): a frame ends behind stage k, so that the difference between two builds'
+// hardware counters is one stage's share (LDS bank conflicts per stage: rocprofv3 has no per-stage view of a persistent kernel).
+#ifdef SS_FWD_STOP
+#define STAGE_END(k) if (SS_FWD_STOP == (k)) continue
+#else
+#define STAGE_END(k)
+#endif
+
 template <class G>
 constexpr int fwd_xs() { return SS_CONV1_LOCAL ? G::XS + (8 - G::XS % 32 + 32) % 32 : G::XS; }
 
@@ -289,6 +297,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
     if (n_next >= 0) load_frame(n_next);
     __syncthreads();
     STAMP(0);
+    STAGE_END(0);
 
     // ---------------- stage 1: conv1 (MFMA) + ReLU + pool -> a1 (haloed), argmax bytes.
     // The pooling epilogue is the stage's cost (the forward kernel issues 3.3 other vector instructions per MFMA, most of
@@ -434,6 +443,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
     }
     __syncthreads();
     STAMP(1);
+    STAGE_END(1);
     if (stash) {  // pool-1 argmaxes first: conv2 is about to write the pooled-2 map over them
       for (int q = tid; q < G::I1S / 2; q += NT)
         reinterpret_cast<uint4*>(p.st_i1 + (long)n * 8 * G::I1S)[q] = reinterpret_cast<const uint4*>(i1s)[q];
@@ -512,6 +522,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     STAMP(2);
+    STAGE_END(2);
     if (stash) {
       f32x4* dst = reinterpret_cast<f32x4*>(p.st_a2 + (long)n * 16 * P2);
       for (int q = tid; q < 4 * P2; q += NT) dst[q] = reinterpret_cast<const f32x4*>(a2)[q];
@@ -582,6 +593,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 3) void roi_cnn_fwd_kernel(CnnF
     }
     __syncthreads();
     STAMP(4);
+    STAGE_END(4);
     if (stash)
       for (int q = tid; q < 2 * P; q += NT)
         reinterpret_cast<uint4*>(p.st_m3 + (long)n * 32 * P)[q] = reinterpret_cast<const uint4*>(m3s)[q];
