@@ -464,6 +464,39 @@ def ragged(lengths, T, frac, spec):
     return out
 
 
+def padded_block(ss, L, dev, B, T, K, roi, C, X, R, y, steps=20, warmup=5):
+    """The headline's workload with clips of unequal length, as a recorded data set has them (the reference pads every clip to T
+    frames, train_model_official.py:93-172): lengths uniform in [0.3 T, T].  Timed twice on the same inputs: the fused ROI-CNN
+    kernels walking only the frames inside their clips (the default), and every one of the B*T frames as the reference computes
+    them (SS_CNN_SKIP_PADDING=0).  Same logits and gradients either way (tests/test_gpu_model.py); not the headline."""
+    from silent_speech_amd import engine as E
+
+    spec = spec_for(2, B, T, K, roi, C)
+    lengths = ragged(torch.full((B,), T, device=dev, dtype=torch.int64), T, 0.3, spec)
+    res = {"lengths": spec["ragged"], "unit": "clips/s", "steps": steps, "warmup": warmup}
+    keep = E.SKIP_PADDED_FRAMES
+    try:
+        for name, skip in (("frames_inside_clips_only", True), ("every_frame", False)):
+            E.SKIP_PADDED_FRAMES = skip  # (read when a workspace is built: each model below builds its own)
+            torch.manual_seed(0)
+            model = ss.BiGRUClassifier(spec["D"], C, use_roi=True).to(dev).train()
+            trainer = ss.Trainer(model)
+            for _ in range(warmup):
+                trainer.step(X, lengths, R, y)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                trainer.step(X, lengths, R, y)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            res[name] = {"value": round(B * steps / el, 1), "ms_per_step": round(1000 * el / steps, 3)}
+            del trainer, model
+            torch.cuda.empty_cache()
+    finally:
+        E.SKIP_PADDED_FRAMES = keep
+    return res
+
+
 def shipped_blocks(ss, L, dev, world, rank, args, dist_on):
     """The configuration the reference actually runs: BATCH_SIZE 16 (as shipped) and 256 clips of MAX_T = 90 frames, 88 landmarks
     (D = 180), ROI 96 wide x 48 high, 10 words."""
@@ -536,6 +569,7 @@ def main():
     ap.add_argument("--config", type=int, choices=[2, 5], default=2,
                     help="2 = the headline (f32, 64x64 ROI, H=192, 5 words); 5 = BASELINE config 5 (bf16 MFMA, 96x96 ROI, CNN "
                          "16/32/64/96, H=512, 100 words)")
+    ap.add_argument("--no-padded", action="store_true", help="skip the padded-batches block of the default run")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 (hipGraph serving) block of the default run")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (bf16, 96x96 ROI, H=512) block of the default run")
     ap.add_argument("--no-shipped", action="store_true", help="skip the block at the reference's shipped configuration")
@@ -786,6 +820,8 @@ def main():
     if solo and args.config == 2 and not args.no_config4:
         torch.cuda.empty_cache()
         out["config4"] = config4_block(ss, dev, D, C, roi, 20, 3)
+    if solo and args.config == 2 and args.min_len_frac >= 1.0 and not args.no_padded:
+        out["padded_batches"] = padded_block(ss, L, dev, B, T, K, roi, C, X, R, y)
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, D, C, args.config)
         if "config5" in out:

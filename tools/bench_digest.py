@@ -29,3 +29,5 @@ if cb:
     for k in ("config5", "shipped"):
         if k in d and "cpu_baseline" in d[k]:
             print("cpu", k, d[k]["cpu_baseline"]["value"])
+if "padded_batches" in d:
+    print("padded batches:", d["padded_batches"])
