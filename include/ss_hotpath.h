@@ -294,6 +294,9 @@ int ss_batch_gather_u8(const uint8_t* src, int frame_bytes, const int32_t* frame
 int ss_ring_push(float* ring_x, uint8_t* ring_r, int n_streams, int max_t, int D, int frame_bytes,
                  const int32_t* stream_ids, int n, const float* feats, const uint8_t* rois, int32_t* head, int32_t* count,
                  int32_t* frames_seen, ss_stream_t stream);
+/* a camera frame in which no face was found, for n DISTINCT streams: frames_seen runs on (live_feed.py:173 counts every camera
+ * frame, and the prediction rule :201 tests that count), the ring keeps what it holds (:179-185 ``continue``) */
+int ss_ring_tick(const int32_t* stream_ids, int n, int32_t* frames_seen, ss_stream_t stream);
 int ss_ring_window_map(const int32_t* stream_ids, int n, int max_t, const int32_t* head, const int32_t* count,
                        int32_t* frame_map, int64_t* lengths, ss_stream_t stream);
 int ss_mouth_openness(const float* lm, int n, int K, int mode, int i_top, int i_bot, int i_eye_l, int i_eye_r,

@@ -3,11 +3,13 @@
 Follows /root/reference/inactive/live_feed.py:155 (``deque(maxlen=max_t)``), :163-164 (``PRED_EVERY = 2``,
 ``WARMUP_MIN = min(10, max_t)``), :201-207 (predict when ``len(buf) >= WARMUP_MIN and frame_idx % PRED_EVERY == 0`` on the
 buffer zero-padded to ``(max_t, D)``) and /root/reference/important_landmarks.py:57-61, :136-144 (EMA with
-``EMA_ALPHA = 0.25``, open/close hysteresis at 0.02 / 0.02).  The reference runs this per camera inside its capture loop,
-which cannot be called: the LOOPS (ring / deque, EMA + hysteresis, clip gating) are restatements (PARITY UNPINNED); the
-SIGNALS they consume are pinned -- ``openness_eye_span``, ``openness_y_range``, ``face_to_xvec`` and ``feat83_and_openness`` are
-held to what the reference's own ``dist2d`` / ``compute_openness`` / ``face_to_xvec`` / ``extract_83_and_openness`` returned on
-seeded faces (tests/golden/serving.npz, made by tests/golden/make_golden.py:gen_serving) -- and the model forward is pinned
+``EMA_ALPHA = 0.25``, open/close hysteresis at 0.02 / 0.02).  The reference runs this per camera inside its capture loops, which cannot be called.  PINNED all the same (round 4): the
+statements of those loops were taken out of the parsed scripts and executed frame by frame on seeded traces
+(tests/golden/make_golden.py:gen_serving_loops -> tests/golden/serving_loops.npz), and the three restatements here -- ``StreamRef``'s
+EMA + hysteresis, ``ClipGateRef``, ``StreamRef``'s window rule incl. camera frames without a face (``tick``) -- are held to what the
+reference's statements produced (tests/test_oracle_golden.py).  The SIGNALS they consume are pinned too -- ``openness_eye_span``,
+``openness_y_range``, ``face_to_xvec`` and ``feat83_and_openness`` against the reference's own ``dist2d`` / ``compute_openness`` /
+``face_to_xvec`` / ``extract_83_and_openness`` on seeded faces (tests/golden/serving.npz) -- and the model forward is pinned
 through oracle/model_ref.py.
 
 ``openness_eye_span`` / ``openness_y_range`` restate important_landmarks.py:64-67, 131-133 and
@@ -32,6 +34,10 @@ class StreamRef:
         self.frame_idx = 0
         self.ema = 0.0  # ``mouth_ema = 0.0``: a Python float (float64), important_landmarks.py:109
         self.open = False
+
+    def tick(self) -> None:
+        """A camera frame without a face: live_feed.py:173 has counted it, :179-185 ``continue`` in front of the buffer."""
+        self.frame_idx += 1
 
     def push(self, feat: np.ndarray, roi: Optional[np.ndarray] = None, openness: Optional[float] = None) -> Optional[Dict]:
         """One frame; returns the zero-padded window when this stream is due for a prediction."""

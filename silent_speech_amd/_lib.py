@@ -84,6 +84,7 @@ SIGNATURES = {
     "ss_batch_gather_f32": [_vp, _i, _vp, _l, _vp, _vp, _f, _u64, _vp, _vp],
     "ss_batch_gather_u8": [_vp, _i, _vp, _l, _vp, _vp],
     "ss_crop_gray_resize": [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp],
+    "ss_ring_tick": [_vp, _i, _vp, _vp],
     "ss_ring_push": [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ss_ring_window_map": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ss_mouth_openness": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],

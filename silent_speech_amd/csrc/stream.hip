@@ -154,7 +154,20 @@ __global__ __launch_bounds__(256) void clip_gate_kernel(const int32_t* __restric
   }
 }
 
+// a camera frame without a face: the frame counter runs on, the buffer keeps what it holds (inactive/live_feed.py:173, 179-185)
+__global__ void ring_tick_kernel(const int32_t* __restrict__ ids, int n, int32_t* __restrict__ frames_seen) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) frames_seen[ids[k]] += 1;
+}
+
 }  // namespace
+
+extern "C" int ss_ring_tick(const int32_t* stream_ids, int n, int32_t* frames_seen, ss_stream_t stream) {
+  SS_REQUIRE(stream_ids && frames_seen && n > 0, SS_ERR_ARG);
+  hipLaunchKernelGGL(ring_tick_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), stream_ids, n,
+                     frames_seen);
+  return ss_launch_status();
+}
 
 extern "C" int ss_ring_push(float* ring_x, uint8_t* ring_r, int n_streams, int max_t, int D, int frame_bytes,
                             const int32_t* stream_ids, int n, const float* feats, const uint8_t* rois, int32_t* head,

@@ -159,6 +159,18 @@ class StreamServer:
             logits = self.model(X, T, R if self.model.use_roi else None)
         return due, logits, T
 
+    def skip(self, stream_ids: Sequence[int]) -> None:
+        """A camera frame without a face for each of the given streams: their frame counters run on -- the reference's rule
+        "every PRED_EVERY-th CAMERA frame" (inactive/live_feed.py:173, 201) counts those frames too --, nothing is buffered, nobody
+        predicts (:179-185 ``continue``)."""
+        ids = np.asarray(stream_ids, np.int32)
+        if len(ids) == 0:
+            return
+        if len(set(ids.tolist())) != len(ids):
+            raise ValueError("one frame per stream and tick")
+        L.call("ss_ring_tick", torch.from_numpy(ids).to(self.device).data_ptr(), len(ids), self.frames_seen.data_ptr(), L.stream())
+        self._seen[ids] += 1
+
     def attach_front_end(self, idxs: Sequence[int], frame_wh, variant: str = "live", band=(None, None)) -> "LiveFrontEnd":
         """Landmarks + camera frames in, instead of ready-made feature rows: see ``push_landmarks``."""
         if 2 * len(idxs) + 4 != self.D:

@@ -379,7 +379,7 @@ def _functions_of(path, wanted, constants=()):
     for node in tree.body:
         if isinstance(node, (ast.Import, ast.ImportFrom)):
             keep.append(node)
-        elif isinstance(node, ast.FunctionDef) and node.name in wanted:
+        elif isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in wanted:
             keep.append(node)
         elif isinstance(node, ast.Assign) and all(isinstance(t, ast.Name) and t.id in constants for t in node.targets):
             keep.append(node)
@@ -450,6 +450,210 @@ def gen_serving():
     print("wrote serving: openness_eye[:4]", out["openness_eye"][:4], "openness83[:4]", out["openness83"][:4])
 
 
+def _statements_between(path, first, last, drop=None, list_has=None):
+    """A run of CONSECUTIVE statements of one statement list anywhere in a reference script -- from the first statement for which
+    ``first(node)`` holds through the first one at or behind it for which ``last(node)`` holds -- compiled as they stand.  This is how
+    the state machines that live inline in the scripts' capture loops (``while True: ok, frame = cap.read() ...``) are run here:
+    the loop cannot be called, its statements can be executed in a namespace that holds the loop's variables.  ``drop(node)``
+    removes statements from the run (the overlay drawing calls between them); ``list_has`` picks the statement list when ``first``
+    matches in several.  Nothing of the source is kept: the fixture holds the numbers the statements produced."""
+    import ast
+
+    tree = ast.parse(open(path).read(), filename=path)
+    for node in ast.walk(tree):
+        for field in ("body", "orelse", "finalbody"):
+            stmts = getattr(node, field, None)
+            if not isinstance(stmts, list) or (list_has is not None and not any(list_has(st) for st in stmts)):
+                continue
+            for i, st in enumerate(stmts):
+                if first(st):
+                    for j in range(i, len(stmts)):
+                        if last(stmts[j]):
+                            run = [x for x in stmts[i:j + 1] if drop is None or not drop(x)]
+                            return compile(ast.Module(body=run, type_ignores=[]), path, "exec"), len(run)
+    raise AssertionError("statements not found in " + path)
+
+
+def _ast_preds():
+    import ast
+
+    def names(t):
+        return {n.id for n in ast.walk(t) if isinstance(n, ast.Name)}
+
+    def assigns(*ids):  # an assignment whose targets are exactly these names (``a = b = 0`` has two, ``a, b = f()`` one tuple)
+        return lambda n: isinstance(n, ast.Assign) and set().union(*[names(t) for t in n.targets]) == set(ids)
+
+    def aug(name):
+        return lambda n: isinstance(n, ast.AugAssign) and isinstance(n.target, ast.Name) and n.target.id == name
+
+    def if_on(*ids):  # an ``if`` whose test mentions all of these names
+        return lambda n: isinstance(n, ast.If) and set(ids) <= names(n.test)
+
+    def cv2_call(n):
+        return isinstance(n, ast.Expr) and isinstance(n.value, ast.Call) and "cv2" in names(n.value.func)
+
+    return assigns, aug, if_on, cv2_call
+
+
+def gen_serving_loops():
+    """The serving STATE MACHINES, run from the reference's own statements (round 4 pinned the signals, these are the
+    loops around them).  Each lives inline in a capture loop, so the statements are taken out of the parsed script
+    (``_statements_between``) and executed frame by frame in a namespace holding the loop's variables:
+
+    * important_landmarks.py:130-144 -- lip gap / eye span, the EMA ``mouth_ema`` (a Python float) and the open / close
+      hysteresis; trace with values a few ulps on either side of both thresholds;
+    * inactive/live_test_5.py:229-272 (+ the NO FACE branch :293-301) -- openness-gated clip segmentation: above / below
+      counters, START_N / END_N / MAX_CLIP, clips shorter than 6 frames dropped; the clip the prediction is made from;
+    * inactive/live_feed.py:173, 197-207 -- the sliding window: frame counter, ``deque(maxlen=max_t)``, WARMUP_MIN / PRED_EVERY,
+      the zero-padded window handed to the model (stored as the source frame of every row)."""
+    import collections
+
+    import important_landmarks as il
+    import live_test_5 as lt5
+
+    assigns, aug, if_on, cv2_call = _ast_preds()
+    rs = np.random.RandomState(2024)
+    out = {}
+
+    class P:
+        __slots__ = ("x", "y")
+
+        def __init__(self, x, y):
+            self.x, self.y = float(x), float(y)
+
+    # ---- (1) EMA + hysteresis
+    code, n1 = _statements_between(os.path.join(REF, "important_landmarks.py"), assigns("lip_gap"), if_on("mouth_state_open"))
+    assert n1 == 5, n1  # lip_gap, eye_span, openness, mouth_ema, the hysteresis ``if``
+    F = 360
+    pts = np.zeros((F, 4, 2), np.float32)  # top, bottom, left eye corner, right eye corner
+    pts[:, 0] = (0.5, 0.60)
+    pts[:, 2] = np.array([0.38, 0.40], np.float32) + rs.normal(0, 0.004, (F, 2)).astype(np.float32)
+    pts[:, 3] = np.array([0.63, 0.41], np.float32) + rs.normal(0, 0.004, (F, 2)).astype(np.float32)
+    gap = np.abs(np.cumsum(rs.normal(0, 0.0016, F))).astype(np.float32) % np.float32(0.012)  # wanders through both thresholds
+    ns = dict(vars(il))
+    ns.update(mouth_ema=0.0, mouth_state_open=False)
+    ema, state, opn = [], [], []
+    for f in range(F):
+        if f % 9 == 4:  # aim the EMA at a threshold: the float32 landmark nearest the solution leaves it ulps to one side or the other
+            thr = il.OPEN_THR if not ns["mouth_state_open"] else il.CLOSE_THR
+            span = float(np.hypot(float(pts[f, 2, 0]) - float(pts[f, 3, 0]), float(pts[f, 2, 1]) - float(pts[f, 3, 1]))) + 1e-6
+            want = (thr - (1 - il.EMA_ALPHA) * ns["mouth_ema"]) / il.EMA_ALPHA * span
+            if 0.0 <= want < 0.2:
+                gap[f] = np.float32(want) if f % 2 else np.nextafter(np.float32(want), np.float32(1))
+        pts[f, 1] = (0.5, np.float32(0.60) + gap[f])
+        face = {il.MOUTH_TOP: P(*pts[f, 0]), il.MOUTH_BOTTOM: P(*pts[f, 1]), il.LEFT_EYE_CORNER: P(*pts[f, 2]),
+                il.RIGHT_EYE_CORNER: P(*pts[f, 3])}
+        ns["face"] = face
+        exec(code, ns)
+        ema.append(ns["mouth_ema"]); state.append(bool(ns["mouth_state_open"])); opn.append(ns["openness"])
+    out.update(gate_pts=pts, gate_idx=np.asarray([il.MOUTH_TOP, il.MOUTH_BOTTOM, il.LEFT_EYE_CORNER, il.RIGHT_EYE_CORNER], np.int32),
+               gate_ema=np.asarray(ema, np.float64), gate_open=np.asarray(state, np.uint8), gate_openness=np.asarray(opn, np.float64),
+               gate_consts=np.asarray([il.EMA_ALPHA, il.OPEN_THR, il.CLOSE_THR], np.float64))
+    near = np.abs(np.asarray(ema) - il.OPEN_THR) < 1e-12
+    print("gate: %d frames, %d flips, %d EMA values within 1e-12 of a threshold" % (F, int(np.abs(np.diff(out["gate_open"].astype(int))).sum()), int(near.sum())))
+
+    # ---- (2) openness-gated clips
+    path = os.path.join(REF, "inactive", "live_test_5.py")
+    code, n2 = _statements_between(path, assigns("openv"), if_on("speaking"), drop=cv2_call)
+    assert n2 == 3, n2  # openv, the counters' ``if``, the ``if not speaking`` state machine (with the prediction inside)
+    code_noface, n2b = _statements_between(path, assigns("speaking"), assigns("hold"), drop=cv2_call, list_has=assigns("above_ct", "below_ct"))
+    assert n2b == 6, n2b
+    idxs = [int(i) for i in lt5_landmark_idxs()]
+    K = len(idxs)
+    torch.manual_seed(5)
+    ns = dict(vars(lt5))
+    D_NPZ = 2 * K + 1
+    ns.update(idxs=idxs, D_NPZ=D_NPZ, D_IN=2 * D_NPZ, dev="cpu", labels=["hello", "yes", "no", "please", "thanks"],
+              model=lt5.MLP(in_dim=2 * D_NPZ, num_classes=5).eval(),
+              speaking=False, above_ct=0, below_ct=0, clip_buf=[], last_pred=None, last_conf=0.0, hold=0)
+    F = 420
+    lm = rs.uniform(0.3, 0.7, size=(F, K, 2)).astype(np.float32)
+    # the openness is the y range of the K landmarks: squeeze them into a band whose height follows a script of talk / silence
+    plan, f = [], 0
+    for talk, quiet in ((2, 4), (3, 6), (9, 3), (4, 5), (12, 7), (70, 8), (6, 2), (3, 1), (3, 9), (25, 4), (8, 6), (5, 5), (30, 5)):
+        plan += [1] * talk + [0] * quiet
+    plan = (plan * 3)[:F]
+    noface = np.zeros(F, bool)
+    noface[[57, 58, 150, 301]] = True  # one of them in the middle of a clip
+    height = np.where(np.asarray(plan) > 0, rs.uniform(0.19, 0.3, F), rs.uniform(0.05, 0.17, F))
+    height[[20, 90]] = lt5.OPEN_THRESH  # exactly on the threshold: ``>`` is strict
+    ylo = rs.uniform(0.3, 0.4, F)
+    lm[:, :, 1] = (ylo[:, None] + rs.uniform(0, 1, (F, K)) * height[:, None]).astype(np.float32)
+    lm[:, 0, 1] = ylo.astype(np.float32)
+    lm[:, 1, 1] = (ylo + height).astype(np.float32)
+    rec = collections.defaultdict(list)
+    for f in range(F):
+        ns["hold"] = 0
+        if noface[f]:
+            exec(code_noface, ns)
+            rec["openv"].append(0.0); rec["emit_len"].append(0); rec["emit_sum"].append(0.0)
+        else:
+            face = [None] * 478
+            for k, i in enumerate(idxs):
+                face[i] = P(*lm[f, k])
+            ns["face"] = face
+            before = ns["clip_buf"]
+            exec(code, ns)
+            rec["openv"].append(ns["openv"])
+            done = ns["hold"] == lt5.HOLD_FRAMES  # the prediction ran: the clip had >= 6 frames
+            clip = before if ns["clip_buf"] is before else ns["clip_buf"]
+            rec["emit_len"].append(len(ns["Xclip"]) if done else 0)
+            rec["emit_sum"].append(float(np.asarray(ns["Xclip"], np.float64).sum()) if done else 0.0)
+            del clip
+        rec["speaking"].append(bool(ns["speaking"])); rec["above"].append(ns["above_ct"]); rec["below"].append(ns["below_ct"])
+        rec["buf_len"].append(len(ns["clip_buf"]))
+    out.update(clip_lm=lm, clip_idxs=np.asarray(idxs, np.int32), clip_noface=noface, clip_openv=np.asarray(rec["openv"], np.float64),
+               clip_speaking=np.asarray(rec["speaking"], np.uint8), clip_above=np.asarray(rec["above"], np.int32),
+               clip_below=np.asarray(rec["below"], np.int32), clip_buf_len=np.asarray(rec["buf_len"], np.int32),
+               clip_emit_len=np.asarray(rec["emit_len"], np.int32), clip_emit_sum=np.asarray(rec["emit_sum"], np.float64),
+               clip_consts=np.asarray([lt5.OPEN_THRESH, lt5.START_N, lt5.END_N, lt5.MAX_CLIP], np.float64))
+    el = out["clip_emit_len"]
+    print("clips: %d frames, %d clips emitted (lengths %s), %d at MAX_CLIP" % (F, int((el > 0).sum()), sorted(set(el[el > 0].tolist())), int((el == lt5.MAX_CLIP).sum())))
+
+    # ---- (3) the sliding window of live_feed.py
+    path = os.path.join(REF, "inactive", "live_feed.py")
+    lf = _functions_of(path, ["extract_83_and_openness", "softmax_np", "GRUWordClassifier"],
+                       ["LOWER_LIPS", "UPPER_LIPS", "LIP_ORDER", "PRED_EVERY"])
+    max_t = 24
+    ns = dict(lf)
+    torch.manual_seed(6)
+    ns.update(max_t=max_t, input_dim=83, DEVICE="cpu", id_to_label={i: "w%d" % i for i in range(7)}, frame_idx=0,
+              buf=collections.deque(maxlen=max_t), model=lf["GRUWordClassifier"](input_dim=83, hidden=128, num_classes=7).eval(),
+              last_label="...", last_conf=0.0)
+    exec(_statements_between(path, assigns("WARMUP_MIN"), assigns("WARMUP_MIN"))[0], ns)
+    tick = _statements_between(path, aug("frame_idx"), aug("frame_idx"))[0]
+    code, n3 = _statements_between(path, assigns("feat", "open_val"), if_on("WARMUP_MIN", "PRED_EVERY"))
+    assert n3 == 3, n3  # feat / open_val, buf.append, the prediction ``if``
+    used = sorted(set(lf["LIP_ORDER"]) | {0, 17, 13, 14, 61, 291})
+    F = 90
+    pts = rs.uniform(0.3, 0.7, size=(F, len(used), 2)).astype(np.float32)
+    noface = np.zeros(F, bool)
+    noface[[3, 4, 17, 40, 41, 42, 77]] = True
+    src = -np.ones((F, max_t), np.int32)  # for a frame that predicted: which frame every window row came from (-1: zero padding)
+    feats, logits = np.zeros((F, 83), np.float32), np.zeros((F, 7), np.float32)
+    with torch.no_grad():
+        for f in range(F):
+            exec(tick, ns)
+            if noface[f]:  # :179-185: ``continue`` in front of the buffer
+                continue
+            full = np.zeros((478, 2), np.float32)
+            full[used] = pts[f]
+            ns["landmarks_xy"] = full
+            ns.pop("X", None)
+            exec(code, ns)
+            feats[f] = ns["feat"]
+            if "X" in ns:
+                for r in range(max_t):
+                    hit = np.flatnonzero((feats[: f + 1] == ns["X"][r]).all(1) & ~noface[: f + 1])
+                    src[f, r] = hit[-1] if len(hit) and ns["X"][r].any() else -1
+                logits[f] = ns["logits"]
+    out.update(win_pts=pts, win_used=np.asarray(used, np.int32), win_noface=noface, win_src=src, win_feats=feats, win_logits=logits,
+               win_consts=np.asarray([max_t, ns["WARMUP_MIN"], ns["PRED_EVERY"]], np.int32))
+    print("window: %d frames, %d predictions, first at frame %d" % (F, int((src[:, 0] >= 0).sum()), int(np.argmax(src[:, 0] >= 0))))
+    np.savez_compressed(os.path.join(HERE, "serving_loops.npz"), **out)
+    print("wrote serving_loops")
+
+
 def lt5_landmark_idxs():
     """inactive/live_test_5.py reads its landmark indices from a recorded clip's ``idxs`` (:78-84); the synthetic clip here uses
     the 40 lip landmarks of the official recorder (record_landmarks_official.py:30-44 order does not matter to either function)."""
@@ -466,6 +670,7 @@ def main():
     only = set(sys.argv[1:])  # python make_golden.py [case names]: regenerate only those model cases
     if only == {"serving"}:
         gen_serving()
+        gen_serving_loops()
         return
     for i, case in enumerate(MODEL_CASES):
         if not only or case[0] in only:
@@ -479,6 +684,7 @@ def main():
     gen_harness(tmo)
     gen_loader(live)
     gen_serving()
+    gen_serving_loops()
 
 
 if __name__ == "__main__":

@@ -908,6 +908,85 @@ def test_mouth_openness_against_the_reference_functions(ss, golden_dir):
     assert np.array_equal(mouth_openness(lm, "width_norm", (13, 14, 61, 291)).cpu().numpy(), d["openness83"])
 
 
+def test_serving_kernels_against_the_references_own_loop_statements(ss, golden_dir):
+    """SURVEY 8f-4, pinned end to end: tests/golden/serving_loops.npz holds what the reference's OWN statements -- taken out of
+    its capture loops and executed frame by frame (make_golden.py:gen_serving_loops) -- did on three traces.  The kernels are
+    fed the same traces: (1) ``ss_mouth_openness`` + ``ss_mouth_gate``: the EMA to an ulp (the openness kernel's root is
+    correctly rounded, the reference's ``** 0.5`` is not always), every open / close decision identical; (2)
+    ``ss_mouth_openness`` (y range) + ``ClipGateServer``: speaking state, counters, which frames end a clip and its length,
+    identical, the clip's rows bit-equal; (3) ``StreamServer.push`` / ``skip``: which camera frames predict and the
+    zero-padded window handed to the model, identical."""
+    import os
+
+    from silent_speech_amd import _lib as L
+    from silent_speech_amd.serving import mouth_openness
+
+    d = np.load(os.path.join(golden_dir, "serving_loops.npz"))
+    # ---- (1) EMA + hysteresis, important_landmarks.py:130-144
+    F = len(d["gate_pts"])
+    alpha, thr_open, thr_close = (float(v) for v in d["gate_consts"])
+    op = mouth_openness(torch.from_numpy(d["gate_pts"]).cuda(), "eye_span", (0, 1, 2, 3))
+    want_op = d["gate_openness"]
+    assert np.all(np.abs(op.cpu().numpy() - want_op) <= 2.3e-16 * np.abs(want_op))
+    ids = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ema = torch.zeros(1, device="cuda", dtype=torch.float64)
+    st = torch.zeros(1, device="cuda", dtype=torch.uint8)
+    got_ema, got_open = np.zeros(F), np.zeros(F, np.uint8)
+    for f in range(F):
+        L.call("ss_mouth_gate", ids.data_ptr(), 1, op[f:f + 1].data_ptr(), alpha, thr_open, thr_close, ema.data_ptr(), st.data_ptr(), L.stream())
+        got_ema[f], got_open[f] = float(ema[0]), int(st[0])
+    assert np.all(np.abs(got_ema - d["gate_ema"]) <= 4.5e-16 * np.abs(d["gate_ema"]))
+    assert np.array_equal(got_open, d["gate_open"])
+
+    # ---- (2) openness-gated clips, inactive/live_test_5.py:229-272 and :293-301
+    from oracle import stream_ref as SR
+
+    lm = torch.from_numpy(d["clip_lm"]).cuda()
+    openv = mouth_openness(lm, "y_range")
+    face_rows = ~d["clip_noface"]
+    assert np.array_equal(openv.cpu().numpy()[face_rows], d["clip_openv"][face_rows])
+    idxs = [int(i) for i in d["clip_idxs"]]
+    Dx = 2 * len(idxs) + 1
+    m = ss.BiGRUClassifier(Dx, 5, use_roi=False)
+    m.cuda().eval()
+    thr, start_n, end_n, max_clip = float(d["clip_consts"][0]), *(int(v) for v in d["clip_consts"][1:])
+    srv = ss.serving.ClipGateServer(m, 1, open_thresh=thr, start_n=start_n, end_n=end_n, max_clip=max_clip)
+    for f in range(len(d["clip_lm"])):
+        face = {i: (float(x), float(y)) for i, (x, y) in zip(idxs, d["clip_lm"][f])}
+        xvec = SR.face_to_xvec(face, idxs, True)  # (pinned by serving.npz; the gate takes whatever rows it is given)
+        row, emit, res = srv.push([0], torch.from_numpy(xvec[None]), openv[f:f + 1],
+                                  face_present=torch.tensor([0 if d["clip_noface"][f] else 1], dtype=torch.uint8))
+        stt = srv.state[0].cpu().numpy()
+        assert (bool(stt[0]), int(stt[1]), int(stt[2])) == (bool(d["clip_speaking"][f]), int(d["clip_above"][f]), int(d["clip_below"][f])), f
+        assert int(emit[0]) == int(d["clip_emit_len"][f]), f
+        if int(emit[0]):
+            clip = srv.clip_x[0, :int(emit[0])].cpu().numpy().astype(np.float64)
+            assert abs(float(clip.sum()) - float(d["clip_emit_sum"][f])) < 1e-9 and res is not None and int(res[2][0]) == int(emit[0])
+        else:
+            assert res is None
+    assert int((d["clip_emit_len"] > 0).sum()) >= 8
+
+    # ---- (3) the sliding window, inactive/live_feed.py:173, 197-207
+    max_t, warm, every = (int(v) for v in d["win_consts"])
+    m83 = ss.BiGRUClassifier(83, 7, use_roi=False)
+    m83.cuda().eval()
+    win = ss.StreamServer(m83, 1, max_t, pred_every=every, warmup_min=warm)
+    feats = torch.from_numpy(d["win_feats"]).cuda()
+    for f in range(len(d["win_feats"])):
+        src = d["win_src"][f]
+        if d["win_noface"][f]:
+            win.skip([0])
+            continue
+        got = win.push([0], feats[f:f + 1])
+        assert (got is not None) == bool(src[0] >= 0), f
+        if got is not None:
+            X, T, _ = win.windows(np.asarray([0]))
+            want = np.zeros((max_t, 83), np.float32)
+            want[src >= 0] = d["win_feats"][src[src >= 0]]
+            assert int(T[0]) == int((src >= 0).sum()) and np.array_equal(X[0].cpu().numpy(), want), f
+    assert int(win.frames_seen[0]) == len(d["win_feats"])  # every camera frame counted, with or without a face
+
+
 def test_clip_gate_server_matches_the_restated_state_machine(ss):
     """inactive/live_test_5.py:233-272 batched over 9 streams: random open/close traces (runs of open frames of random
     length, values within an ulp of OPEN_THRESH, missing faces, clips cut at MAX_CLIP) give the same appends, the same
