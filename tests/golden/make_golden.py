@@ -654,6 +654,70 @@ def gen_serving_loops():
     print("wrote serving_loops")
 
 
+def gen_live_loop(live):
+    """The per-frame body of the OFFICIAL live script (live_infer_official.py:272-296), run from its own statements: mouth width,
+    the 60-150 px distance gate, ``extract_feature`` with the ``prev_xy`` it carries, the buffer append, and ``prev_xy = None`` when
+    a frame of a recording falls outside the band.  ``use_roi`` is off in the namespace (``crop_roi_gray`` needs OpenCV; the crop
+    BOX is pinned by crop.npz); pressing "r" is restated by its two assignments (:334-336: buffers emptied, ``prev_xy = None``)."""
+    import ast
+
+    assigns, aug, if_on, cv2_call = _ast_preds()
+    draws = lambda n: cv2_call(n) or (isinstance(n, ast.If) and "DRAW_POINTS" in {x.id for x in ast.walk(n.test) if isinstance(x, ast.Name)})
+    code, n = _statements_between(os.path.join(REF, "live_infer_official.py"), assigns("mw"), if_on("recording", "in_range"), drop=draws)
+    assert n == 3, n  # mw, in_range, ``if recording and in_range: ... else: ...``
+
+    class P:
+        __slots__ = ("x", "y")
+
+        def __init__(self, x, y):
+            self.x, self.y = float(x), float(y)
+
+    rs = np.random.RandomState(31)
+    idxs = [int(i) for i in live.FIXED_IDXS]
+    K, w, h, F = len(idxs), 640, 480, 260
+    pos = {i: k for k, i in enumerate(idxs)}
+    base = rs.uniform(0.35, 0.65, size=(K, 2)).astype(np.float32)
+    lm = (base[None] + rs.normal(0, 0.004, (F, K, 2))).astype(np.float32)
+    # mouth corners: a horizontal distance that wanders in and out of the band, sits just inside / outside both edges, and leaves
+    # for single frames
+    width_px = 105 + 60 * np.sin(np.arange(F) / 9.0) + rs.normal(0, 2, F)
+    width_px[[40, 41]] = [59.99, 60.01]
+    width_px[[90, 91]] = [150.01, 149.99]
+    width_px[[120, 160, 161, 200]] = [30.0, 400.0, 20.0, 155.0]
+    for f in range(F):
+        lm[f, pos[live.LEFT_CORNER]] = (0.5 - width_px[f] / (2 * w), 0.61)
+        lm[f, pos[live.RIGHT_CORNER]] = (0.5 + width_px[f] / (2 * w), 0.61)
+    recording = np.ones(F, bool)
+    recording[:12] = False
+    recording[130:150] = False
+    ns = dict(vars(live))
+    ns.update(use_roi=False, recording=False, bufX=[], bufR=[], prev_xy=None, w=w, h=h)
+    mw, in_range, appended, has_prev = np.zeros(F), np.zeros(F, bool), np.zeros(F, bool), np.zeros(F, bool)
+    feats = np.zeros((F, 2 * K + 4), np.float32)
+    for f in range(F):
+        if recording[f] and not ns["recording"]:  # "r" pressed: :334-336
+            ns["bufX"], ns["bufR"] = [], []
+            ns["prev_xy"] = None
+        ns["recording"] = bool(recording[f])
+        face = [None] * 478
+        for i, k in pos.items():
+            face[i] = P(*lm[f, k])
+        ns["face"] = face
+        n_before = len(ns["bufX"])
+        exec(code, ns)
+        mw[f], in_range[f] = ns["mw"], ns["in_range"]
+        appended[f] = len(ns["bufX"]) == n_before + 1
+        if appended[f]:
+            feats[f] = ns["bufX"][-1]
+        has_prev[f] = ns["prev_xy"] is not None
+    assert feats.dtype == np.float32
+    np.savez_compressed(os.path.join(HERE, "live_loop.npz"), lm=lm, idxs=np.asarray(idxs, np.int32), wh=np.asarray([w, h], np.int32),
+                        recording=recording, mouth_w=mw, in_range=in_range, appended=appended, has_prev=has_prev, feats=feats,
+                        band=np.asarray([live.MOUTH_W_MIN_PX, live.MOUTH_W_MAX_PX], np.float64))
+    print("wrote live_loop: %d frames, %d appended, %d out of band while recording, %d resets of prev_xy" % (
+        F, int(appended.sum()), int((recording & ~in_range).sum()), int((np.diff(has_prev.astype(int)) < 0).sum())))
+
+
 def lt5_landmark_idxs():
     """inactive/live_test_5.py reads its landmark indices from a recorded clip's ``idxs`` (:78-84); the synthetic clip here uses
     the 40 lip landmarks of the official recorder (record_landmarks_official.py:30-44 order does not matter to either function)."""
@@ -671,6 +735,7 @@ def main():
     if only == {"serving"}:
         gen_serving()
         gen_serving_loops()
+        gen_live_loop(live)
         return
     for i, case in enumerate(MODEL_CASES):
         if not only or case[0] in only:
@@ -685,6 +750,7 @@ def main():
     gen_loader(live)
     gen_serving()
     gen_serving_loops()
+    gen_live_loop(live)
 
 
 if __name__ == "__main__":

@@ -908,6 +908,43 @@ def test_mouth_openness_against_the_reference_functions(ss, golden_dir):
     assert np.array_equal(mouth_openness(lm, "width_norm", (13, 14, 61, 291)).cpu().numpy(), d["openness83"])
 
 
+def test_live_front_end_against_the_references_own_loop_statements(ss, golden_dir):
+    """tests/golden/live_loop.npz = what the reference's own statements of live_infer_official.py:272-296 did on a 260-frame trace
+    (mouth width through and across both band edges, recording switched off and on).  ``LiveFrontEnd`` (``ss_feature_fuse_stream``,
+    the state of ``prev_xy`` in HBM) on the same trace: the same frames kept, velocity exactly 0 wherever the reference had
+    ``prev_xy is None``, feature rows within the feature kernel's tolerance of the reference's."""
+    import os
+
+    from silent_speech_amd import features as Fm
+    from silent_speech_amd.serving import LiveFrontEnd
+
+    d = np.load(os.path.join(golden_dir, "live_loop.npz"))
+    idxs = [int(i) for i in d["idxs"]]
+    w, h = (int(v) for v in d["wh"])
+    K = len(idxs)
+    fe = LiveFrontEnd(1, idxs, (w, h), roi_hw=None, variant="live")
+    lm = torch.from_numpy(d["lm"]).cuda()
+    was_rec, n_zero_vel = False, 0
+    for f in range(len(d["lm"])):
+        rec = bool(d["recording"][f])
+        if rec and not was_rec:
+            fe.reset([0])  # "r" pressed: live_infer_official.py:334-336
+        was_rec = rec
+        kept, X, _ = fe([0], lm[f:f + 1], None, recording=torch.tensor([1 if rec else 0], dtype=torch.uint8))
+        # the front end reports the band decision; the caller appends when it is recording (the reference's ``recording and in_range``)
+        assert bool(kept[0]) == (bool(d["in_range"][f]) and rec) == bool(d["appended"][f]), f
+        assert bool(fe.has_prev[0]) == bool(d["has_prev"][f]), f
+        if d["appended"][f]:
+            got, ref = X[0].cpu().numpy(), d["feats"][f]
+            np.testing.assert_allclose(got[: 2 * K], ref[: 2 * K], rtol=0, atol=2e-7)
+            np.testing.assert_allclose(got[2 * K:], ref[2 * K:], rtol=5e-7, atol=2e-7)
+            assert got[2 * K + 2] == ref[2 * K + 2]  # the mouth width itself: bit for bit (live variant)
+            if ref[2 * K] == 0.0:
+                assert got[2 * K] == 0.0
+                n_zero_vel += 1
+    assert n_zero_vel >= 10 and int(d["appended"].sum()) > 100
+
+
 def test_serving_kernels_against_the_references_own_loop_statements(ss, golden_dir):
     """SURVEY 8f-4, pinned end to end: tests/golden/serving_loops.npz holds what the reference's OWN statements -- taken out of
     its capture loops and executed frame by frame (make_golden.py:gen_serving_loops) -- did on three traces.  The kernels are
