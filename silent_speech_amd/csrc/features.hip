@@ -169,7 +169,9 @@ __global__ __launch_bounds__(FF_WAVES * 64) void feature_fuse_stream_kernel(Feat
     for (int q = lane; q < 2 * K + 4; q += 64) xr[q] = 0.f;
     if (lane == 0) {
       p.kept[i] = 0;
-      if (rec) p.has_prev[sid] = 0;  // ``if recording: prev_xy = None``
+      // live_infer_official.py:294-296 ``else: if recording: prev_xy = None``; the recorder clears it on EVERY frame that is not
+      // appended, recording or not (record_landmarks_official.py:199-201 ``else: prev_xy = None``)
+      if (rec || p.variant == 0) p.has_prev[sid] = 0;
       p.center[2 * i] = c.cx;
       p.center[2 * i + 1] = c.cy;
       p.fourth[i] = p.variant == 0 ? __dadd_rn(c.mw, 1e-6) : c.mw;

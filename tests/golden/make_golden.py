@@ -654,16 +654,18 @@ def gen_serving_loops():
     print("wrote serving_loops")
 
 
-def gen_live_loop(live):
+def gen_live_loop(live, script="live_infer_official.py", roi_flag="use_roi", out_name="live_loop.npz"):
     """The per-frame body of the OFFICIAL live script (live_infer_official.py:272-296), run from its own statements: mouth width,
     the 60-150 px distance gate, ``extract_feature`` with the ``prev_xy`` it carries, the buffer append, and ``prev_xy = None`` when
     a frame of a recording falls outside the band.  ``use_roi`` is off in the namespace (``crop_roi_gray`` needs OpenCV; the crop
-    BOX is pinned by crop.npz); pressing "r" is restated by its two assignments (:334-336: buffers emptied, ``prev_xy = None``)."""
+    BOX is pinned by crop.npz); pressing "r" is restated by its two assignments (:334-336: buffers emptied, ``prev_xy = None``).
+    Called a second time for the RECORDER's loop (record_landmarks_official.py:182-201: the same shape, float64 mouth width, and
+    ``prev_xy = None`` on every frame that is not appended, recording or not; ``SAVE_ROI`` off for the same reason)."""
     import ast
 
     assigns, aug, if_on, cv2_call = _ast_preds()
     draws = lambda n: cv2_call(n) or (isinstance(n, ast.If) and "DRAW_POINTS" in {x.id for x in ast.walk(n.test) if isinstance(x, ast.Name)})
-    code, n = _statements_between(os.path.join(REF, "live_infer_official.py"), assigns("mw"), if_on("recording", "in_range"), drop=draws)
+    code, n = _statements_between(os.path.join(REF, script), assigns("mw"), if_on("recording", "in_range"), drop=draws)
     assert n == 3, n  # mw, in_range, ``if recording and in_range: ... else: ...``
 
     class P:
@@ -691,14 +693,14 @@ def gen_live_loop(live):
     recording[:12] = False
     recording[130:150] = False
     ns = dict(vars(live))
-    ns.update(use_roi=False, recording=False, bufX=[], bufR=[], prev_xy=None, w=w, h=h)
+    ns.update({roi_flag: False}, recording=False, bufX=[], bufR=[], bufT=[], prev_xy=None, w=w, h=h, ts=0)
     mw, in_range, appended, has_prev = np.zeros(F), np.zeros(F, bool), np.zeros(F, bool), np.zeros(F, bool)
     feats = np.zeros((F, 2 * K + 4), np.float32)
     for f in range(F):
         if recording[f] and not ns["recording"]:  # "r" pressed: :334-336
             ns["bufX"], ns["bufR"] = [], []
             ns["prev_xy"] = None
-        ns["recording"] = bool(recording[f])
+        ns["recording"], ns["ts"] = bool(recording[f]), 33 * f
         face = [None] * 478
         for i, k in pos.items():
             face[i] = P(*lm[f, k])
@@ -711,10 +713,10 @@ def gen_live_loop(live):
             feats[f] = ns["bufX"][-1]
         has_prev[f] = ns["prev_xy"] is not None
     assert feats.dtype == np.float32
-    np.savez_compressed(os.path.join(HERE, "live_loop.npz"), lm=lm, idxs=np.asarray(idxs, np.int32), wh=np.asarray([w, h], np.int32),
+    np.savez_compressed(os.path.join(HERE, out_name), lm=lm, idxs=np.asarray(idxs, np.int32), wh=np.asarray([w, h], np.int32),
                         recording=recording, mouth_w=mw, in_range=in_range, appended=appended, has_prev=has_prev, feats=feats,
                         band=np.asarray([live.MOUTH_W_MIN_PX, live.MOUTH_W_MAX_PX], np.float64))
-    print("wrote live_loop: %d frames, %d appended, %d out of band while recording, %d resets of prev_xy" % (
+    print("wrote " + out_name + ": %d frames, %d appended, %d out of band while recording, %d resets of prev_xy" % (
         F, int(appended.sum()), int((recording & ~in_range).sum()), int((np.diff(has_prev.astype(int)) < 0).sum())))
 
 
@@ -736,6 +738,7 @@ def main():
         gen_serving()
         gen_serving_loops()
         gen_live_loop(live)
+        gen_live_loop(rec, "record_landmarks_official.py", "SAVE_ROI", "record_loop.npz")
         return
     for i, case in enumerate(MODEL_CASES):
         if not only or case[0] in only:
@@ -751,6 +754,7 @@ def main():
     gen_serving()
     gen_serving_loops()
     gen_live_loop(live)
+    gen_live_loop(rec, "record_landmarks_official.py", "SAVE_ROI", "record_loop.npz")
 
 
 if __name__ == "__main__":

@@ -908,7 +908,8 @@ def test_mouth_openness_against_the_reference_functions(ss, golden_dir):
     assert np.array_equal(mouth_openness(lm, "width_norm", (13, 14, 61, 291)).cpu().numpy(), d["openness83"])
 
 
-def test_live_front_end_against_the_references_own_loop_statements(ss, golden_dir):
+@pytest.mark.parametrize("variant", ["live", "record"])
+def test_live_front_end_against_the_references_own_loop_statements(ss, golden_dir, variant):
     """tests/golden/live_loop.npz = what the reference's own statements of live_infer_official.py:272-296 did on a 260-frame trace
     (mouth width through and across both band edges, recording switched off and on).  ``LiveFrontEnd`` (``ss_feature_fuse_stream``,
     the state of ``prev_xy`` in HBM) on the same trace: the same frames kept, velocity exactly 0 wherever the reference had
@@ -918,11 +919,11 @@ def test_live_front_end_against_the_references_own_loop_statements(ss, golden_di
     from silent_speech_amd import features as Fm
     from silent_speech_amd.serving import LiveFrontEnd
 
-    d = np.load(os.path.join(golden_dir, "live_loop.npz"))
+    d = np.load(os.path.join(golden_dir, variant + "_loop.npz"))  # "record": the recorder's loop, record_landmarks_official.py:182-201
     idxs = [int(i) for i in d["idxs"]]
     w, h = (int(v) for v in d["wh"])
     K = len(idxs)
-    fe = LiveFrontEnd(1, idxs, (w, h), roi_hw=None, variant="live")
+    fe = LiveFrontEnd(1, idxs, (w, h), roi_hw=None, variant=variant)
     lm = torch.from_numpy(d["lm"]).cuda()
     was_rec, n_zero_vel = False, 0
     for f in range(len(d["lm"])):
@@ -938,7 +939,8 @@ def test_live_front_end_against_the_references_own_loop_statements(ss, golden_di
             got, ref = X[0].cpu().numpy(), d["feats"][f]
             np.testing.assert_allclose(got[: 2 * K], ref[: 2 * K], rtol=0, atol=2e-7)
             np.testing.assert_allclose(got[2 * K:], ref[2 * K:], rtol=5e-7, atol=2e-7)
-            assert got[2 * K + 2] == ref[2 * K + 2]  # the mouth width itself: bit for bit (live variant)
+            if variant == "live":
+                assert got[2 * K + 2] == ref[2 * K + 2]  # the mouth width itself: bit for bit
             if ref[2 * K] == 0.0:
                 assert got[2 * K] == 0.0
                 n_zero_vel += 1
