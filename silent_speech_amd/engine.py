@@ -166,12 +166,31 @@ def check_gru_sync(ws) -> None:
                            "arrived); results since then are poisoned with NaN")
 
 
-def make_workspace(cfg: Config, B: int, T: int, roi_hw, device, train: bool):
+_SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def side_stream(device, slot=0) -> "torch.cuda.Stream":
+    """The side stream of a training workspace: ONE per device and micro-batch slot, shared by every workspace of the process.
+    A stream per workspace looked harmless until a process had built a handful of them (bench.py's default run: config 2, config 5,
+    two shipped shapes, ...): HIP multiplexes streams onto a few hardware queues, the sixth workspace's side stream landed on the
+    queue of the caller's stream, its weight-gradient GEMMs queued behind the critical path instead of running beside it, and the
+    same step took 1.705 instead of 1.555 ms (gpurun_out/r4_b15.log against r4_b14_*.log).  Workspaces are used one after the
+    other, so sharing costs nothing; slots that ARE in flight together (Trainer(micro_batches=M)) keep one stream each.
+    Lowest priority: it must never delay the dispatch of the critical-path kernels on the caller's stream."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), slot if isinstance(slot, int) else 0)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=torch.cuda.Stream.priority_range()[0])
+    return st
+
+
+def make_workspace(cfg: Config, B: int, T: int, roi_hw, device, train: bool, slot=0):
     if cfg.precision == "bf16":
         from .engine_bf16 import WorkspaceBf16
 
-        return WorkspaceBf16(cfg, B, T, roi_hw, device, train)
-    return Workspace(cfg, B, T, roi_hw, device, train)
+        return WorkspaceBf16(cfg, B, T, roi_hw, device, train, slot)
+    return Workspace(cfg, B, T, roi_hw, device, train, slot)
 
 
 class Workspace:
@@ -179,7 +198,7 @@ class Workspace:
 
     bf16 = False
 
-    def __init__(self, cfg: Config, B: int, T: int, roi_hw, device, train: bool):
+    def __init__(self, cfg: Config, B: int, T: int, roi_hw, device, train: bool, slot=0):
         self.cfg, self.B, self.T, self.roi_hw, self.train = cfg, B, T, roi_hw, train
         self.stash_gen, self.stash_live = 0, False  # model._Fn: which autograd node the stashed activations belong to
         N, H = B * T, cfg.hidden
@@ -191,8 +210,7 @@ class Workspace:
         nb = L.gru_sync_bytes(B, T, H) if USE_SPLIT_GRU else 0
         self.gru_sync = torch.zeros(nb // 4, device=device, dtype=torch.int32) if nb else None
         # weight-gradient GEMMs run on a side stream next to the (32-CU) recurrence of the layer below
-        # (lowest priority: it must never delay the dispatch of the critical-path kernels on the caller's stream)
-        self.side = torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[0]) if train else None
+        self.side = side_stream(device, slot) if train else None
         self.ev_fork = torch.cuda.Event() if train else None
         self.ev_join = torch.cuda.Event() if train else None
         self.ev_cnn_fwd = torch.cuda.Event() if train else None  # recorded after the ROI-CNN forward (micro-batch stagger)

@@ -141,14 +141,17 @@ class WorkspaceBf16:
 
     bf16 = True
 
-    def __init__(self, cfg, B: int, T: int, roi_hw, device, train: bool):
+    def __init__(self, cfg, B: int, T: int, roi_hw, device, train: bool, slot=0):
         check_config(cfg, roi_hw if cfg.use_roi else ROI_HW)
         self.cfg, self.B, self.T, self.roi_hw, self.train = cfg, B, T, roi_hw, train
         self.stash_gen, self.stash_live = 0, False
         self.stagger = False
         # weight-gradient GEMMs of a layer run on a side stream beside the BPTT steps of the layer below (a step is a tiny,
         # latency-bound launch that leaves the matrix pipes idle)
-        self.side = torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[0]) if train else None
+        # (one stream per device and micro-batch slot, shared by all workspaces: engine.side_stream)
+        from .engine import side_stream
+
+        self.side = side_stream(device, slot) if train else None
         self.ev_fork = torch.cuda.Event() if train else None
         self.ev_join = torch.cuda.Event() if train else None
         self.ev_cnn_fwd = torch.cuda.Event() if train else None  # recorded after the ROI-CNN forward (Trainer's micro-batch stagger)

@@ -235,7 +235,7 @@ class BiGRUClassifier(nn.Module):
         key = (B, T, hw, train, X.device, slot)
         ws = self._ws_cache.get(key)
         if ws is None:
-            ws = E.make_workspace(self.cfg, B, T, hw, X.device, train)
+            ws = E.make_workspace(self.cfg, B, T, hw, X.device, train, slot)
             self._ws_cache[key] = ws
         return ws
 
