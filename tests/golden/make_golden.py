@@ -132,6 +132,7 @@ def gen_model_case(tmo, live, name, cls, x_dim, C, roi_hw, B, T, lengths, layers
         opt.step()
         out["loss2"] = float(loss2)
         out["logits_after2"] = m(X, L, R).detach().numpy()
+        _check_against_the_loop_statements(tmo, sd, x_dim, C, use_roi, X, L, R, y, m, float(loss2))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("wrote", name, "logits", out["logits"][0][:3])
 
@@ -718,6 +719,34 @@ def gen_live_loop(live, script="live_infer_official.py", roi_flag="use_roi", out
                         band=np.asarray([live.MOUTH_W_MIN_PX, live.MOUTH_W_MAX_PX], np.float64))
     print("wrote " + out_name + ": %d frames, %d appended, %d out of band while recording, %d resets of prev_xy" % (
         F, int(appended.sum()), int((recording & ~in_range).sum()), int((np.diff(has_prev.astype(int)) < 0).sum())))
+
+
+def _check_against_the_loop_statements(tmo, sd, x_dim, C, use_roi, X, L, R, y, m_after2, loss2):
+    """The two steps above are written out here; this runs the SAME two steps from the reference's own statements -- the optimiser
+    and loss construction (train_model_official.py:403-406) and the body of its batch loop (:427-440), taken out of ``main()`` --
+    on a second copy of the model and requires bit-equal parameters and loss: what the fixtures call "the reference's step" is the
+    reference's loop, not a paraphrase of it."""
+    import ast
+
+    assigns, aug, if_on, cv2_call = _ast_preds()
+    path = os.path.join(REF, "train_model_official.py")
+    is_step = lambda n: isinstance(n, ast.Expr) and isinstance(n.value, ast.Call) and ast.unparse(n.value.func) == "opt.step"
+    setup, n0 = _statements_between(path, assigns("opt"), assigns("loss_fn"))
+    body, n1 = _statements_between(path, assigns("X"), is_step, list_has=is_step)
+    assert n0 == 2 and n1 == 10, (n0, n1)  # X / lengths / y to the device, ``if use_roi``, logits, loss, zero_grad, backward, clip, step
+    model = tmo.BiGRUClassifier(x_dim, C, use_roi=use_roi, roi_emb=32, hidden=192)
+    model.load_state_dict(sd)
+    model.eval()  # as above: both dropouts off
+    ns = dict(vars(tmo))
+    ns.update(model=model, use_roi=use_roi, DEVICE="cpu")
+    exec(setup, ns)
+    for _ in range(2):
+        ns.update(X=X, lengths=L, R=R, y=y)
+        exec(body, ns)
+    assert float(ns["loss"]) == loss2, (float(ns["loss"]), loss2)
+    for (k, a), (_, b) in zip(model.state_dict().items(), m_after2.state_dict().items()):
+        assert torch.equal(a, b), k
+    print("   two steps of the reference's own loop statements: identical parameters and loss")
 
 
 def lt5_landmark_idxs():
