@@ -52,10 +52,14 @@ template <> struct ImgLayout<96, 12> { static constexpr int PS = 112, RS = 1600;
 
 // TR = true: the image is read by the transposing reads of a weight-gradient kernel (ds_read_b64_tr_b16, two groups of 32 lanes):
 // those keep the round-2 strides (measured: conv3's weight gradient 0.25 -> 0.30 ms on the ds_read_b128 layout of its input).
+#ifndef SS_TR_PAD
+#define SS_TR_PAD 8
+#endif
+constexpr int TR_PAD = SS_TR_PAD;  // elements added to a pixel of an image (C >= 32) that the transposing reads walk
 template <int C_, int H_, int W_, bool TR = false>
 struct Img {
   static constexpr int C = C_, H = H_, W = W_;
-  static constexpr int PS = TR ? (C >= 32 ? C + 8 : C) : ImgLayout<C, W>::PS;
+  static constexpr int PS = TR ? (C >= 32 ? C + TR_PAD : C) : ImgLayout<C, W>::PS;
   static constexpr int RS = TR ? (C >= 32 ? (W + 2) * PS : row_stride_half_bank((W + 2) * PS)) : ImgLayout<C, W>::RS;
   static_assert(PS >= C && PS % 8 == 0 && RS >= (W + 2) * PS && RS % 8 == 0, "image strides");
   static constexpr int ELEMS = (H + 2) * RS;

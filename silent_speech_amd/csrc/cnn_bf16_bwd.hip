@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
   STAMP_ENTRY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using IA = Img<CIN, BH, W, true>;
-  constexpr int PSD = COUT + 8, RSD = W * PSD;           // dense dy band, no halo
+  constexpr int PSD = COUT + TR_PAD, RSD = W * PSD;      // dense dy band, no halo
   constexpr int DY_BYTES = BH * RSD * 2;
   constexpr int NCO = COUT / 16 / WCO, NCI = CIN / 16 / WCI;
   constexpr int NPIX = BH * W, NCH = (NPIX + 31) / 32;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvBwdParams p) {
     bias1 = *reinterpret_cast<const f32x4*>(p.b1 + 4 * g);  // channels 4g .. 4g+3 (conv1_rows)
     if ((int)blockIdx.x < p.N) load_px(blockIdx.x);
   }
-  static_assert((COUT + 8) * 2 <= ZB, "zero pixel");
+  static_assert((COUT + TR_PAD) * 2 <= ZB, "zero pixel");
   zero_lds(smem, DY_BYTES + IA::BYTES + ZB, tid);
 
   f32x4 acc[NCO][NCI][9];
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 template <int CIN, int COUT, int W, int BH, bool RC = false>
 constexpr int wgrad_lds() {
-  const int operands = BH * W * (COUT + 8) * 2 + Img<CIN, BH, W, true>::BYTES + 256 + (64 + 96 + 96) * 4 +
+  const int operands = BH * W * (COUT + TR_PAD) * 2 + Img<CIN, BH, W, true>::BYTES + 256 + (64 + 96 + 96) * 4 +
                        (RC ? round_up(98 * RS0 * 2, 16) + 256 * 4 + 12 * 64 * 16 : 0);
   const int halves = (COUT * CIN * 9 * 4 > 120 * 1024) ? 2 : 1;
   const int flush = COUT / halves * CIN * 9 * 4;  // the [co][ci][tap] image the gradients leave through
