@@ -215,10 +215,11 @@ class Workspace:
         self.ev_join = torch.cuda.Event() if train else None
         self.ev_cnn_fwd = torch.cuda.Event() if train else None  # recorded after the ROI-CNN forward (micro-batch stagger)
         self.stagger = False  # set by the trainer when another micro-batch waits for ev_cnn_fwd
-        self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi else None
+        # roi_hw None with use_roi: a workspace for forward(..., z_ready=True) -- rows that already hold the embeddings (serving.py)
+        self.Z = torch.empty(N, cfg.in_dim, **f32) if cfg.use_roi and roi_hw is not None else None
         # ROI sizes the fused, LDS-resident CNN kernels are not built for run layer by layer (cnn_generic.py)
         self.cnn_generic = None
-        if cfg.use_roi:
+        if cfg.use_roi and roi_hw is not None:
             from . import cnn_generic
 
             if not cnn_generic.fused_supported(*roi_hw):
@@ -269,7 +270,7 @@ class Workspace:
                 self.st_feat = torch.empty(N, n_feat, **f32)  # 24 features, 24 counts, mean, std, pad
         # [0] = how many rows (b, t) lie inside their clip, [1 ...] = those rows: the fused CNN kernels walk only them
         self.frames = (torch.empty(1 + N, device=device, dtype=torch.int32)
-                       if cfg.use_roi and self.cnn_generic is None and SKIP_PADDED_FRAMES else None)
+                       if cfg.use_roi and roi_hw is not None and self.cnn_generic is None and SKIP_PADDED_FRAMES else None)
         # The backward kernel pays 1 % for the list (roi_cnn_bwd.hip: 48 instead of 38 spilled scalar registers), so a training
         # workspace keeps the count of the last batch it has SEEN FINISH in pinned memory -- an 8-byte copy on the side stream,
         # never waited for -- and a step that follows a batch of full clips launches the kernels without the list.  A wrong guess
@@ -281,8 +282,10 @@ class Workspace:
 
 
 def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Tensor, R: Optional[torch.Tensor], *,
-            train: bool, stash: bool = False, seed: int = 0, ce=None, x_in_place: bool = False) -> torch.Tensor:
+            train: bool, stash: bool = False, seed: int = 0, ce=None, x_in_place: bool = False, z_ready: bool = False) -> torch.Tensor:
     """Runs the forward kernels; returns ws.logits (B,C).  ``ws.lengths`` must already hold the int32 lengths.
+    ``z_ready``: X (B,T,in_dim) already holds torch.cat((landmark features, ROI embeddings)) of train_model_official.py:297 -- the
+    embeddings were made when the frames arrived (sliding-window serving) -- and the ROI branch is skipped (inference only).
     ``train`` turns the two dropouts on (p from cfg); ``stash`` keeps what ``backward`` needs (needs a
     Workspace built with train=True).  ``ce = (y_ptr, label_smoothing, denom, loss_ptr, correct_ptr)`` makes the
     fused tail kernel also evaluate the loss and leave d(loss)/d(logits) in ``ws.d_logits``."""
@@ -295,7 +298,11 @@ def forward(P: Dict[str, torch.Tensor], cfg: Config, ws: Workspace, X: torch.Ten
     if stash and not ws.train:
         raise RuntimeError("stash=True needs a training workspace")
     # ---- ROI branch: normalise + CNN -> columns [x_dim, x_dim+E) of Z; X -> columns [0, x_dim)
-    if cfg.use_roi:
+    if z_ready:
+        if stash or train or not cfg.use_roi or X.shape[2] != cfg.in_dim:
+            raise RuntimeError("z_ready: inference on rows of width in_dim = x_dim + roi_emb of a use_roi model")
+        layer_in, ld_in = X.data_ptr(), cfg.in_dim
+    elif cfg.use_roi:
         Hh, Ww = ws.roi_hw
         ws_Z = ws.Z
         if not x_in_place:  # (the trainer's prologue kernel has already put X there)

@@ -273,6 +273,41 @@ class BiGRUClassifier(nn.Module):
             if R is None or R.dtype != torch.uint8 or R.dim() != 4 or R.shape[:2] != X.shape[:2]:
                 raise RuntimeError("use_roi=True needs R: uint8 (B,T,H,W)")
 
+    # ------------------------------------------------------------------ sliding-window serving: embeddings made once per frame
+    def embed_rois(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None, ld_out: Optional[int] = None) -> torch.Tensor:
+        """TinyROICNN (with the per-frame normalisation of train_model_official.py:286-291) on n separate frames: (n,H,W) uint8 ->
+        (n, roi_emb).  A frame's embedding depends on that frame alone, so a sliding window need not recompute the 58 frames it
+        shares with the window before (serving.StreamServer caches them).  ``out`` / ``ld_out``: write into rows of a wider matrix."""
+        if not self.use_roi or self.cfg.precision != "f32":
+            raise RuntimeError("embed_rois needs an f32 use_roi model")
+        if frames.dtype != torch.uint8 or frames.dim() != 3 or not frames.is_cuda:
+            raise RuntimeError("frames must be uint8 (n,H,W) on the HIP device")
+        n, Hh, Ww = frames.shape
+        E_ = self.cfg.roi_emb
+        if out is None:
+            out, ld_out = torch.empty(n, E_, device=frames.device), E_
+        P = self._param_dict()
+        cw = [P[k].data_ptr() for k in ("roi_cnn.net.0.weight", "roi_cnn.net.0.bias", "roi_cnn.net.3.weight", "roi_cnn.net.3.bias",
+                                        "roi_cnn.net.6.weight", "roi_cnn.net.6.bias", "roi_cnn.fc.weight", "roi_cnn.fc.bias")]
+        E.L.call("ss_roi_cnn_fwd", frames.contiguous().data_ptr(), n, Hh, Ww, int(self.cfg.roi_standardize), *cw, E_, out.data_ptr(),
+                 int(ld_out), E.L.stream())
+        return out
+
+    def forward_embedded(self, Z: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        """Logits from rows that already hold torch.cat((X, roi_emb)) (train_model_official.py:297): everything behind the ROI branch.
+        Inference only."""
+        if not self.use_roi or self.cfg.precision != "f32" or Z.dim() != 3 or Z.shape[2] != self.cfg.in_dim or not Z.is_cuda:
+            raise RuntimeError(f"Z must be (B,T,{self.cfg.in_dim}) on the HIP device of a use_roi model")
+        Z = Z.contiguous().float()
+        B, T, _ = Z.shape
+        key = (B, T, "embedded", False, Z.device, 0)
+        ws = self._ws_cache.get(key)
+        if ws is None:
+            ws = self._ws_cache[key] = E.make_workspace(self.cfg, B, T, None, Z.device, False)
+        ws.lengths.copy_(lengths.to(torch.int32), non_blocking=True)
+        with torch.no_grad():
+            return E.forward(self._param_dict(), self.cfg, ws, Z, None, train=False, z_ready=True).clone()
+
     def forward(self, X, lengths, R=None):
         self._check_inputs(X, lengths, R)
         X = X.contiguous().float()

@@ -109,16 +109,31 @@ class LiveFrontEnd:
 
 
 class StreamServer:
+    """``cache_embeddings`` (default: on for an f32 ROI model whose frame size the fused CNN kernels are built for): a frame's ROI
+    embedding depends on that frame alone (the normalisation is per frame, train_model_official.py:286-291), and consecutive windows of
+    a stream share all but ``pred_every`` frames -- so the CNN runs ONCE per frame, when it is pushed, the ring keeps the row
+    torch.cat((features, embedding)) (:297) instead of the 4.6 KB of pixels, and a prediction is the recurrence, the pool and the
+    head on rows that are already there.  Same logits, bit for bit, as recomputing every window from its pixels
+    (``cache_embeddings=False``; test_stream_server_embedding_cache_changes_nothing)."""
+
     def __init__(self, model: BiGRUClassifier, n_streams: int, max_t: int, roi_hw=None, pred_every: int = PRED_EVERY,
-                 warmup_min: Optional[int] = None, device="cuda"):
+                 warmup_min: Optional[int] = None, device="cuda", cache_embeddings: Optional[bool] = None):
         L.load()
         self.model, self.S, self.max_t, self.roi_hw = model.eval(), n_streams, max_t, roi_hw
-        self.D = model.cfg.x_dim
+        from .cnn_generic import fused_supported
+
+        can_cache = bool(roi_hw) and model.use_roi and model.cfg.precision == "f32" and fused_supported(*roi_hw)
+        if cache_embeddings and not can_cache:
+            raise ValueError("cache_embeddings needs an f32 ROI model and a frame size of the fused CNN kernels")
+        self.cache = can_cache if cache_embeddings is None else bool(cache_embeddings)
+        self.Dx = model.cfg.x_dim                                   # landmark features per frame
+        self.D = model.cfg.in_dim if self.cache else model.cfg.x_dim  # width of a ring row
         self.pred_every = pred_every
         self.warmup_min = min(10, max_t) if warmup_min is None else warmup_min
         dev = self.device = torch.device(device)
         self.ring_x = torch.zeros(n_streams, max_t, self.D, device=dev)
-        self.ring_r = torch.zeros(n_streams, max_t, roi_hw[0], roi_hw[1], device=dev, dtype=torch.uint8) if roi_hw else None
+        self.ring_r = (torch.zeros(n_streams, max_t, roi_hw[0], roi_hw[1], device=dev, dtype=torch.uint8)
+                       if roi_hw and not self.cache else None)
         self.head = torch.zeros(n_streams, device=dev, dtype=torch.int32)
         self.count = torch.zeros(n_streams, device=dev, dtype=torch.int32)
         self.frames_seen = torch.zeros(n_streams, device=dev, dtype=torch.int32)
@@ -141,7 +156,14 @@ class StreamServer:
         ids_d = torch.from_numpy(ids).to(dev)
         feats = feats.to(dev, torch.float32).contiguous()
         rois = rois.to(dev).contiguous() if rois is not None else None
-        fb = self.roi_hw[0] * self.roi_hw[1] if self.roi_hw else 0
+        if self.cache:  # the row the ring keeps: features | embedding of this frame (made now, once)
+            if rois is None or tuple(rois.shape) != (n, *self.roi_hw) or tuple(feats.shape) != (n, self.Dx):
+                raise ValueError(f"feats must be ({n}, {self.Dx}) and rois uint8 ({n}, {self.roi_hw[0]}, {self.roi_hw[1]})")
+            rows = torch.empty(n, self.D, device=dev)
+            L.call("ss_copy_rows_f32", feats.data_ptr(), self.Dx, rows.data_ptr(), self.D, n, self.Dx, L.stream())
+            self.model.embed_rois(rois, out=rows[:, self.Dx:], ld_out=self.D)
+            feats, rois = rows, None
+        fb = self.roi_hw[0] * self.roi_hw[1] if (self.roi_hw and not self.cache) else 0
         L.call("ss_ring_push", self.ring_x.data_ptr(), L.ptr(self.ring_r), self.S, self.max_t, self.D, fb, ids_d.data_ptr(), n,
                feats.data_ptr(), L.ptr(rois) if self.ring_r is not None else None, self.head.data_ptr(), self.count.data_ptr(),
                self.frames_seen.data_ptr(), L.stream())
@@ -156,7 +178,7 @@ class StreamServer:
             return None
         X, T, R = self.windows(due)
         with torch.no_grad():
-            logits = self.model(X, T, R if self.model.use_roi else None)
+            logits = self.model.forward_embedded(X, T) if self.cache else self.model(X, T, R if self.model.use_roi else None)
         return due, logits, T
 
     def skip(self, stream_ids: Sequence[int]) -> None:
@@ -173,8 +195,8 @@ class StreamServer:
 
     def attach_front_end(self, idxs: Sequence[int], frame_wh, variant: str = "live", band=(None, None)) -> "LiveFrontEnd":
         """Landmarks + camera frames in, instead of ready-made feature rows: see ``push_landmarks``."""
-        if 2 * len(idxs) + 4 != self.D:
-            raise ValueError(f"the model takes {self.D} features per frame, {len(idxs)} landmarks give {2 * len(idxs) + 4}")
+        if 2 * len(idxs) + 4 != self.Dx:
+            raise ValueError(f"the model takes {self.Dx} features per frame, {len(idxs)} landmarks give {2 * len(idxs) + 4}")
         self.front = LiveFrontEnd(self.S, idxs, frame_wh, self.roi_hw, variant, band, self.device)
         return self.front
 
@@ -195,7 +217,8 @@ class StreamServer:
         return kept, res
 
     def windows(self, ids: np.ndarray):
-        """Zero-padded windows (oldest frame first) of the given streams: X (n,max_t,D), lengths (n,), R or None."""
+        """Zero-padded windows (oldest frame first) of the given streams: X (n,max_t,D), lengths (n,), R or None.  With cached
+        embeddings a row of X is torch.cat((features, embedding)) and there is no R."""
         dev, n, mt = self.device, len(ids), self.max_t
         ids_d = torch.from_numpy(np.asarray(ids, np.int32)).to(dev)
         fmap = torch.empty(n, mt, device=dev, dtype=torch.int32)

@@ -717,7 +717,7 @@ def test_stream_server_matches_the_restated_loop(ss):
     m = ss.BiGRUClassifier(Dm, 5, use_roi=True)
     m.load_state_dict(sd)
     m.cuda().eval()
-    srv = ss.StreamServer(m, S, max_t, roi_hw=hw)
+    srv = ss.StreamServer(m, S, max_t, roi_hw=hw, cache_embeddings=False)  # (the pixel-level ring: windows are compared as ROI bytes)
     refs = [SR.StreamRef(max_t, Dm, hw) for _ in range(S)]
     n_pred = 0
     for tick in range(45):
@@ -748,6 +748,51 @@ def test_stream_server_matches_the_restated_loop(ss):
     assert n_pred > 40
 
 
+def test_stream_server_embedding_cache_changes_nothing(ss):
+    """A frame's ROI embedding depends on that frame alone (per-frame normalisation, train_model_official.py:286-291), so the
+    sliding-window server makes it ONCE, when the frame is pushed, and keeps torch.cat((features, embedding)) in the ring instead
+    of the pixels.  Against the server that keeps pixels and recomputes every window: the same streams are due on the same ticks,
+    the logits are bit-equal, the cached rows are [features | TinyROICNN(frame)], and faceless ticks (``skip``) count alike."""
+    rng = np.random.default_rng(21)
+    S, max_t, Dm, hw = 6, 12, 84, (48, 96)
+    sd = W.make_state_dict(4, Dm, 5, True)
+    m = ss.BiGRUClassifier(Dm, 5, use_roi=True)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    cached = ss.StreamServer(m, S, max_t, roi_hw=hw)
+    pixels = ss.StreamServer(m, S, max_t, roi_hw=hw, cache_embeddings=False)
+    assert cached.cache and cached.ring_r is None and cached.D == Dm + 32 and not pixels.cache
+    n_pred = 0
+    for tick in range(40):
+        ids = np.flatnonzero(rng.random(S) < 0.8)
+        gone = np.setdiff1d(np.flatnonzero(rng.random(S) < 0.1), ids)
+        cached.skip(gone)
+        pixels.skip(gone)
+        if len(ids) == 0:
+            continue
+        feats = torch.from_numpy(rng.normal(size=(len(ids), Dm)).astype(np.float32)).cuda()
+        rois = torch.from_numpy(rng.integers(0, 256, (len(ids),) + hw, dtype=np.uint8)).cuda()
+        a, b = cached.push(ids, feats, rois), pixels.push(ids, feats, rois)
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        assert a[0].tolist() == b[0].tolist() and torch.equal(a[2], b[2])
+        assert torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())
+        n_pred += len(a[0])
+        if tick % 9 == 0:  # the rows of a cached window
+            Z, T, R = cached.windows(a[0])
+            Xp, Tp, Rp = pixels.windows(a[0])
+            assert R is None and torch.equal(T, Tp) and torch.equal(Z[:, :, :Dm], Xp)
+            k, t = 0, int(T[0]) - 1
+            assert torch.equal(Z[k, t, Dm:], m.embed_rois(Rp[k, t:t + 1])[0])
+            assert float(Z[k, int(T[0]):].abs().max() if int(T[0]) < max_t else 0.0) == 0.0
+    assert n_pred > 40
+    ref = MR.forward(sd, Xp.cpu(), Tp.cpu(), Rp.cpu(), impl="aten")
+    assert float((m.forward_embedded(Z, T).cpu() - ref).abs().max()) < TIGHT
+    with pytest.raises(ValueError):
+        ss.StreamServer(ss.BiGRUClassifier(Dm, 5, use_roi=False).cuda(), S, max_t, cache_embeddings=True)
+
+
 def test_live_chain_one_entry_point_band_leave_and_reentry(ss):
     """landmarks + camera frames in, windows + logits out, as ONE device entry point
     (``StreamServer.push_landmarks`` = live_infer_official.py:264-296 per stream: width gate -> extract_feature with the stream's
@@ -768,7 +813,7 @@ def test_live_chain_one_entry_point_band_leave_and_reentry(ss):
     m = ss.BiGRUClassifier(Dm, 10, use_roi=True)
     m.load_state_dict(sd)
     m.cuda().eval()
-    srv = ss.StreamServer(m, S, max_t, roi_hw=hw)
+    srv = ss.StreamServer(m, S, max_t, roi_hw=hw, cache_embeddings=False)
     srv.attach_front_end(idxs, (w, h), variant="live")
     with pytest.raises(ValueError):
         ss.StreamServer(m, S, max_t, roi_hw=hw).attach_front_end(idxs[:40], (w, h))
