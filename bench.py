@@ -465,6 +465,42 @@ def ragged(lengths, T, frac, spec):
     return out
 
 
+def stream_block(ss, dev, D, C, roi, S, Ts, steps):
+    """S camera streams, one new frame per stream and tick, a prediction per stream every 2nd tick on its zero-padded
+    sliding window (inactive/live_feed.py:155-213) -- rings, window assembly and forward all on the device.  Two servers on the
+    same inputs: the one that ships (a frame's ROI embedding made once, when it is pushed, and kept in the ring) and the one that
+    keeps pixels and runs the CNN over every window again -- the same logits either way (tests/test_gpu_model.py)."""
+    model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).eval()
+    ids = list(range(S))
+    feats = torch.randn(S, D, device=dev)
+    rois = torch.randint(0, 256, (S, roi, roi), device=dev, dtype=torch.uint8)
+    op = torch.rand(S, device=dev) * 0.05
+    res, el, n_keep = {}, 1.0, 0
+    for name, cache in (("embeddings_cached", True), ("every_window_from_pixels", False)):
+        srv = ss.StreamServer(model, S, Ts, roi_hw=(roi, roi), device=dev, cache_embeddings=cache)
+        for _ in range(Ts + (Ts % 2)):  # fill the rings; ends on an even frame count
+            srv.push(ids, feats, rois, op)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_pred = 0
+        for _ in range(2 * steps):
+            got = srv.push(ids, feats, rois, op)
+            n_pred += 0 if got is None else len(got[0])
+        torch.cuda.synchronize()
+        el_ = time.perf_counter() - t0
+        res[name] = {"windows_per_sec": round(n_pred / el_, 1), "ms_per_tick_pair": round(1000 * el_ / steps, 3)}
+        if cache:
+            el, n_keep = el_, n_pred
+        del srv
+        torch.cuda.empty_cache()
+    return {"metric": "windows/sec (sliding %d-frame windows of %d streams, push + assemble + forward)" % (Ts, S),
+            "value": round(n_keep / el, 1), "unit": "windows/s", "n_gpus": 1, "steps": steps, "warmup": 0,
+            "ms_per_step": round(1000 * el / steps, 3), "higher_is_better": True, "dtype": "f32",
+            "data": "synthetic", "frames_ingested_per_sec": round(2 * steps * S / el, 1), "variants": res,
+            "config": {"workload": "SURVEY 8f-4: %d streams x T=%d, one frame per stream and tick, prediction every "
+                                   "2nd tick, landmark + %dx%d ROI CNN + BiGRU forward" % (S, Ts, roi, roi)}}
+
+
 def padded_block(ss, L, dev, B, T, K, roi, C, X, R, y, steps=20, warmup=5):
     """The headline's workload with clips of unequal length, as a recorded data set has them (the reference pads every clip to T
     frames, train_model_official.py:93-172): lengths uniform in [0.3 T, T].  Timed twice on the same inputs: the fused ROI-CNN
@@ -699,42 +735,8 @@ def main():
                                        "algorithmic_bytes_per_launch": crop_bytes, "avg_launch_ms": round(ms, 4)}}))
         return
     if args.mode == "stream":
-        # S camera streams, one new frame per stream and tick, a prediction per stream every 2nd tick on its
-        # zero-padded sliding window (inactive/live_feed.py:155-213) -- rings, window assembly and forward all on the device
         S, Ts = (4096, 60) if (args.batch, args.frames) == (256, 30) else (args.batch, args.frames)
-        model = ss.BiGRUClassifier(D, C, use_roi=True).to(dev).eval()
-        ids = list(range(S))
-        feats = torch.randn(S, D, device=dev)
-        rois = torch.randint(0, 256, (S, roi, roi), device=dev, dtype=torch.uint8)
-        op = torch.rand(S, device=dev) * 0.05
-        res = {}
-        # the server as it ships (a frame's embedding made once, when it is pushed) and the one that keeps pixels and runs the CNN
-        # over every window again -- the same logits either way
-        for name, cache in (("embeddings_cached", True), ("every_window_from_pixels", False)):
-            srv = ss.StreamServer(model, S, Ts, roi_hw=(roi, roi), device=dev, cache_embeddings=cache)
-            for _ in range(Ts + (Ts % 2)):  # fill the rings; ends on an even frame count
-                srv.push(ids, feats, rois, op)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n_pred = 0
-            for _ in range(2 * args.steps):
-                got = srv.push(ids, feats, rois, op)
-                n_pred += 0 if got is None else len(got[0])
-            torch.cuda.synchronize()
-            el_ = time.perf_counter() - t0
-            res[name] = {"windows_per_sec": round(n_pred / el_, 1), "ms_per_tick_pair": round(1000 * el_ / args.steps, 3)}
-            if cache:
-                el = el_
-                n_keep = n_pred
-            del srv
-            torch.cuda.empty_cache()
-        n_pred = n_keep
-        print(json.dumps({"metric": "windows/sec (sliding %d-frame windows of %d streams, push + assemble + forward)" % (Ts, S),
-                          "value": round(n_pred / el, 1), "unit": "windows/s", "n_gpus": 1, "steps": args.steps, "warmup": 0,
-                          "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True, "dtype": "f32",
-                          "data": "synthetic", "frames_ingested_per_sec": round(2 * args.steps * S / el, 1), "variants": res,
-                          "config": {"workload": "SURVEY 8f-4: %d streams x T=%d, one frame per stream and tick, prediction every "
-                                                 "2nd tick, landmark + %dx%d ROI CNN + BiGRU forward" % (S, Ts, roi, roi)}}))
+        print(json.dumps(stream_block(ss, dev, D, C, roi, S, Ts, args.steps)))
         return
     if args.mode == "live":
         # the live chain as one device entry point (live_infer_official.py:264-296 per stream + the sliding-window rule): landmarks and
@@ -849,6 +851,11 @@ def main():
         out["config4"] = config4_block(ss, dev, D, C, roi, 20, 3)
     if solo and args.config == 2 and args.min_len_frac >= 1.0 and not args.no_padded:
         out["padded_batches"] = padded_block(ss, L, dev, B, T, K, roi, C, X, R, y)
+    if solo and args.config == 2 and not args.no_config4:
+        # beside config 4 (4 096 INDEPENDENT windows through the whole model): the same count of camera streams served as what they
+        # are, windows that slide by two frames -- not config 4's number, which recomputes every frame of every window
+        torch.cuda.empty_cache()
+        out["sliding_window_serving"] = stream_block(ss, dev, D, C, roi, 4096, 60, 10)
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, D, C, args.config)
         if "config5" in out:

@@ -31,3 +31,5 @@ if cb:
             print("cpu", k, d[k]["cpu_baseline"]["value"])
 if "padded_batches" in d:
     print("padded batches:", d["padded_batches"])
+if "sliding_window_serving" in d:
+    print("sliding-window serving:", d["sliding_window_serving"]["value"], d["sliding_window_serving"]["variants"])
